@@ -1,0 +1,55 @@
+"""Pin the importable part of the oracle to vectors captured from the reference
+(tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import loss_oracle as LO
+from oracle import msplat_oracle as MO
+
+
+def test_ssim_small_value_and_grad(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ssim_small.npz"))
+    for a, b, val, grad in (("img1", "img2", "value", "grad1"), ("img3", "img4", "value34", "grad3")):
+        x = torch.from_numpy(g[a]).requires_grad_(True)
+        y = torch.from_numpy(g[b])
+        v = LO.ssim(x, y)
+        v.backward()
+        assert abs(v.item() - float(g[val])) < 2e-6
+        np.testing.assert_allclose(x.grad.numpy(), g[grad], rtol=1e-4, atol=1e-8)
+
+
+def test_ssim_480p_probes(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ssim_480p.npz"))
+    gen = torch.Generator().manual_seed(int(g["seed"]))
+    x = torch.rand(1, 3, 480, 854, generator=gen)
+    y = (x + 0.1 * torch.rand(1, 3, 480, 854, generator=gen)).clamp(0, 1)
+    x.requires_grad_(True)
+    v = LO.ssim(x, y)
+    v.backward()
+    assert abs(v.item() - float(g["value"])) < 2e-6
+    for (c, i, j), ref in zip(g["probes"], g["grad_probes"]):
+        assert abs(x.grad[0, c, i, j].item() - ref) <= 1e-4 * abs(ref) + 1e-12
+
+
+def test_pix2world(golden_dir):
+    g = np.load(os.path.join(golden_dir, "pix2world.npz"))
+    uv, d, intr = (torch.from_numpy(g[k]) for k in ("uv", "depth", "intr"))
+    for e, o in (("extr_id", "xyz_id"), ("extr_rt", "xyz_rt")):
+        out = LO.pix2world(uv, d, intr, torch.from_numpy(g[e]))
+        np.testing.assert_allclose(out.numpy(), g[o], rtol=1e-5, atol=1e-6)
+    # the value SURVEY.md 8c quotes
+    out = LO.pix2world(torch.tensor([[10., 20.]]), torch.tensor([[1.5]]), torch.tensor([427., 427., 427., 240.]),
+                       torch.eye(4)[:3])
+    np.testing.assert_allclose(out.numpy(), [[-1.4649, -0.7728, 1.5]], atol=1e-4)
+
+
+def test_colormap(golden_dir):
+    g = np.load(os.path.join(golden_dir, "colormap.npz"))
+    lut = MO.turbo_lut()
+    np.testing.assert_array_equal(lut.numpy(), g["turbo"])
+    out = MO.apply_float_colormap(torch.from_numpy(g["depth_vec"]), lut, non_zero=True)
+    np.testing.assert_array_equal(out.numpy(), g["turbo_non_zero"])
+    rb = MO.apply_float_colormap(torch.from_numpy(g["ramp"]), torch.from_numpy(g["gist_rainbow"]))
+    np.testing.assert_array_equal(rb.numpy(), g["rainbow_ramp"])
