@@ -1,0 +1,200 @@
+"""Benchmark of the hot path: one "step" = one optimisation iteration of the GFlow
+first-frame fit (rasterise forward, photometric+SSIM+depth+var loss, rasterise
+backward, Adam) at BASELINE.json configs[1]: 480x854, 60 000 splats, synthetic frame.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Each rank fits its own synthetic clip frame (no data-path collective, "weak" scaling);
+one all-reduce(MAX) of the wall time and one all-reduce(SUM) of a small metrics vector
+at the end.  Rank 0 prints ONE JSON line.
+
+value = frames/s: iterations/s divided by the iterations GFlow spends per frame with
+the README flags on a 60-frame clip, (500 + 59*(150+300))/60 = 450.83 (README.md:89-107).
+Inputs are resident in HBM before the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+H, W, N_SPLATS = 480, 854, 60000
+ITERS_PER_FRAME = (500 + 59 * (150 + 300)) / 60.0
+HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes(kind, N, K, P):
+    """Bytes one launch must move at minimum (DESIGN.md 'Kernels')."""
+    if kind == "blend_bwd":
+        return 44 * K + 24 * P + 40 * N        # gather splat records, read dL + aux, write reduced grads
+    if kind == "blend_fwd":
+        return 44 * K + 24 * P                 # gather splat records, write 4 planes + final_T + n_contrib
+    if kind == "loss":
+        return 48 * P                          # read render 16 + gt 16, write dL 16
+    raise KeyError(kind)
+
+
+class KernelTimer:
+    """HIP events on the stream the kernels are launched on (torch's current stream),
+    recorded around the library calls whose names are listed in ``watch``."""
+
+    def __init__(self, lib, watch):
+        self.events = {k: [] for k in watch}
+        self._orig = {}
+        self.lib = lib
+        for kind, fn_name in watch.items():
+            orig = getattr(lib, fn_name)
+            self._orig[fn_name] = orig
+
+            def wrapped(*a, _o=orig, _k=kind):
+                if not self.enabled:
+                    return _o(*a)
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = _o(*a)
+                e1.record()
+                self.events[_k].append((e0, e1))
+                return rc
+            setattr(lib, fn_name, wrapped)
+        self.enabled = False
+
+    def mean_ms(self):
+        return {k: (sum(a.elapsed_time(b) for a, b in v) / len(v) if v else None) for k, v in self.events.items()}
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The oracle's fit iteration on the host cores, same workload, bounded sample."""
+    from gflow_amd import synthetic as S
+    from oracle.fit_oracle import OracleFit
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    frame = S.make_frame(H, W, seed=0)
+    raw = S.init_splats(frame, N_SPLATS, seed=0, grown=True)
+    fit = OracleFit(raw, raw["intr"], frame, lr=4e-3, iterations=500, lambda_depth=0.1, lambda_var=10.0)
+    fit.step()                                   # warm-up (allocator, thread pool)
+    t0 = time.time()
+    n = 0
+    while n < 2 or (time.time() - t0 < seconds_budget and n < 8):
+        fit.step()
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"value": (1.0 / dt) / ITERS_PER_FRAME, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} fit iterations (after 1 warm-up) of the same 480x854 / 60k-splat frame with the "
+                      f"eager-PyTorch CPU oracle (own restatement; the reference has no CPU rasteriser), "
+                      f"{dt * 1000:.0f} ms/iteration",
+            "ms_per_step": dt * 1000.0}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from gflow_amd import _lib
+    from gflow_amd import synthetic as S
+    from gflow_amd.trainer import SimpleGaussian
+    lib = _lib.load()
+    timer = KernelTimer(lib, {"blend_fwd": "gfl_blend_fwd", "blend_bwd": "gfl_blend_bwd", "loss": "gfl_loss_fwd_bwd"})
+
+    frame = S.make_frame(H, W, seed=rank)
+    raw = S.init_splats(frame, N_SPLATS, seed=rank, grown=True)
+    tr = SimpleGaussian(frame["image"], frame["depth"], num_points=N_SPLATS, device=dev, seed=rank)
+    tr.load_camera(focal=frame["focal"], pp=frame["pp"])
+    for k in ("xyz", "scale", "rotate", "opacity", "rgb"):
+        tr._attributes[k] = raw[k].to(dev)
+    total = args.warmup + args.steps
+    kw = dict(lr=4e-3, lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0, move_mask=frame["move_mask"],
+              densify_interval=0, snapshot_interval=0)
+    stepper = tr.make_stepper(iterations=500, **kw)
+    for _ in range(args.warmup):
+        stepper()
+    timer.enabled = True
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stepper()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+
+    K = int(tr.last_K)
+    psnr = float(tr.psnr_of(stepper.last_render))
+    stats = torch.tensor([elapsed, float(args.steps), psnr, float(K)], dtype=torch.float64, device=dev)
+    tmax = stats[:1].clone()
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    wall = float(tmax.item())
+    total_steps = float(stats[1].item())
+    if rank == 0:
+        it_per_s = total_steps / wall
+        kern = timer.mean_ms()
+        P = H * W
+        roof = {}
+        for kind, ms in kern.items():
+            if ms:
+                b = algorithmic_bytes(kind, N_SPLATS, K, P)
+                roof[kind] = {"ms": ms, "algorithmic_bytes": b, "GBps": b / (ms * 1e-3) / 1e9}
+        dom = max(roof, key=lambda k: roof[k]["ms"])
+        out = {
+            "metric": "GFlow fit_video frames/sec (fwd+bwd+step) @60k Gaussians 480p",
+            "value": it_per_s / ITERS_PER_FRAME,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1000.0,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: first-frame fit iteration, 480x854, 60000 splats (grown footprint), "
+                                   "lambda rgb/depth/var = 1/0.1/10, one clip per GPU",
+                       "iterations_per_frame": ITERS_PER_FRAME, "splat_tile_pairs_K": K,
+                       "parallelism": f"clip-sharded x{world}"},
+            "iterations_per_s": it_per_s,
+            "rasterisations_fwd_bwd_per_s": it_per_s,
+            "psnr_mean_db": float(stats[2].item()) / world,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": roof[dom]["GBps"], "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": roof[dom]["GBps"] / HBM_PEAK_GBPS, "traffic": None},
+            "kernels": roof,
+            "end_to_end_algorithmic_GBps": (724 * N_SPLATS + 124 * K + 96 * P) * it_per_s / world / 1e9,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

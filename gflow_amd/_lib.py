@@ -1,0 +1,103 @@
+"""ctypes binding of libgflow_hip.so (the C ABI declared in include/gflow_hip.h).
+
+There is NO CPU fallback: if the library is missing or a tensor is not on a HIP
+device the call raises.  The library is built in-tree by ``build()`` (hipcc
+cross-compiles gfx950 without a GPU) and travels with the repository snapshot.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libgflow_hip.so")
+
+_lock = threading.Lock()
+_lib = None
+
+c_void_p, c_int, c_float, c_size_t, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_int64
+
+# name -> (restype, argtypes); mirrors include/gflow_hip.h one to one
+_P = c_void_p
+SIGNATURES = {
+    "gfl_version": (c_int, []),
+    "gfl_status_string": (ctypes.c_char_p, [c_int]),
+    "gfl_last_hip_error": (c_int, []),
+    "gfl_reduce_workspace_bytes": (c_size_t, [c_int]),
+    "gfl_project_point_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P]),
+    "gfl_project_point_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_size_t, _P]),
+    "gfl_cov3d_fwd": (c_int, [_P, _P, _P, c_int, _P, _P]),
+    "gfl_cov3d_bwd": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P]),
+    "gfl_ewa_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "gfl_ewa_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "gfl_bin_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "gfl_bin_count": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P]),
+    "gfl_bin_sort": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "gfl_blend_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_float, c_int, c_int, _P, _P, _P, _P]),
+    "gfl_blend_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_float, c_int, c_int, _P, _P, _P, c_int,
+                              _P, _P, _P, _P, c_int, _P]),
+    "gfl_colormap_nonzero": (c_int, [_P, c_int, _P, _P, _P, c_size_t, _P]),
+    "gfl_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "gfl_loss_fwd_bwd": (c_int, [_P, _P, _P, _P, _P, c_float, c_float, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "gfl_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, c_float, c_float, c_float, c_float, _P, c_float, c_int, _P]),
+    "gfl_step_increment": (c_int, [_P, _P]),
+}
+
+
+def build(force=False, quiet=True):
+    """Compile libgflow_hip.so for gfx950 with hipcc (in-tree, via the Makefile)."""
+    if force:
+        subprocess.run(["make", "-C", _CSRC, "clean"], check=True, capture_output=quiet)
+    res = subprocess.run(["make", "-C", _CSRC, "-j8"], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libgflow_hip.so failed:\n" + res.stdout + res.stderr)
+    return LIB_PATH
+
+
+def load():
+    """dlopen the library and attach prototypes; raises if it is not there."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C gflow_amd/csrc`).  gflow_amd has no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the ABI drifted
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        lib = load()
+        msg = lib.gfl_status_string(rc).decode()
+        extra = f" (hipError {lib.gfl_last_hip_error()})" if rc == -3 else ""
+        raise RuntimeError(f"libgflow_hip: {what}: {msg}{extra}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def need_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("gflow_amd: tensors must be on a HIP (cuda) device; there is no CPU fallback")
+
+
+def scratch(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)

@@ -1,0 +1,26 @@
+"""Back-projection helpers on the hot path (reference: gflow/utils/geometry.py:95-120)."""
+import torch
+
+
+def inv(mat):
+    return torch.linalg.inv(mat)
+
+
+def depth2pts3d(depth, xys, focal, pp):
+    """depth (N,1), xys (N,2) pixels -> camera-space points (N,3) (geometry.py:118-119)."""
+    return torch.cat((depth * (xys - pp) / focal, depth), dim=-1)
+
+
+def geotrf(Trf, pts):
+    """Apply a 4x4 rigid transform to (N,3) points (the only case pix2world uses)."""
+    return pts @ Trf[:3, :3].T + Trf[:3, 3]
+
+
+def pix2world(uv, depth, intr, extr):
+    """uv (N,2), depth (N,1), intr (4,) [fx,fy,cx,cy], extr (3,4) world->camera.
+    Like the reference (geometry.py:105-106) the single focal intr[0] is used for both
+    axes."""
+    rel = depth2pts3d(depth, uv, intr[0], intr[2:])
+    bottom = torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=extr.device, dtype=extr.dtype)
+    cam2world = inv(torch.cat((extr, bottom), dim=0))
+    return geotrf(cam2world, rel)

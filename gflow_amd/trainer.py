@@ -1,0 +1,478 @@
+"""Per-frame optimiser -- the counterpart of gflow/trainer.py :: SimpleGaussian.
+
+Same public surface for the hot path (``__init__``, ``load_camera``,
+``init_gaussians_from_image``, ``get_attribute``, ``get_extr``, ``add_optimizer``,
+``train``, ``project_points``, ``save_checkpoint`` / ``load_checkpoint``,
+``densify_by_pixels``) and the same optimisation semantics, including the quirks
+SURVEY.md A13 lists (Adam + LinearLR rebuilt on every ``train`` call; densification
+replaces the optimiser with a constant-lr Adam over the attributes only).
+
+What is different on purpose (results unchanged):
+  * rgb and depth are composited in ONE 4-channel blend instead of two;
+  * ``depth_map_color`` / ``center`` are rendered only on the iterations whose
+    snapshots are kept (every 10th, trainer.py:573-582), not on all of them;
+  * no host synchronisation inside an iteration: loss scalars stay on the device
+    (the reference calls .item() on every term for its progress bar), the colour map
+    runs on the device, masked losses are evaluated as mask-weighted sums rather than
+    boolean gathers;
+  * densification samples on the device (torch.multinomial) instead of moving the
+    error map to the host for np.random.choice.
+Visualisation-only pieces (concave-hull segmentation, PNG/MP4 writers) are out of
+scope.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import geometry, losses, msplat
+from . import render as render_mod
+from .optim import Adam, LinearLR
+from .sampling import complex_texture_sampling
+
+
+def pose_to_extr(pose):
+    """pose [qx,qy,qz,qw,tx,ty,tz] (XYZW, identity [0,0,0,1,0,0,0]) -> (3,4) world->camera:
+    what roma.RigidUnitQuat(Q,T).normalize().to_homogeneous()[:3] gives
+    (trainer.py:115-121; signed_expm1 is the identity, utils/__init__.py:11-15)."""
+    q = pose[:4] / torch.linalg.norm(pose[:4])
+    x, y, z, w = q[0], q[1], q[2], q[3]
+    R = torch.stack([
+        1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+        2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+        2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]).reshape(3, 3)
+    return torch.cat([R, pose[4:7].unsqueeze(1)], dim=1)
+
+
+def rotmat_to_unitquat_xyzw(R):
+    """roma.rotmat_to_unitquat restated (XYZW, w >= 0 branch-free variant)."""
+    m = R.double()
+    t = m[0, 0] + m[1, 1] + m[2, 2]
+    cands = torch.stack([
+        torch.stack([m[2, 1] - m[1, 2], m[0, 2] - m[2, 0], m[1, 0] - m[0, 1], 1 + t]),
+        torch.stack([1 + m[0, 0] - m[1, 1] - m[2, 2], m[0, 1] + m[1, 0], m[0, 2] + m[2, 0], m[2, 1] - m[1, 2]]),
+        torch.stack([m[0, 1] + m[1, 0], 1 - m[0, 0] + m[1, 1] - m[2, 2], m[1, 2] + m[2, 1], m[0, 2] - m[2, 0]]),
+        torch.stack([m[0, 2] + m[2, 0], m[1, 2] + m[2, 1], 1 - m[0, 0] - m[1, 1] + m[2, 2], m[1, 0] - m[0, 1]]),
+    ])
+    best = torch.argmax(torch.stack([1 + t, 1 + m[0, 0] - m[1, 1] - m[2, 2], 1 - m[0, 0] + m[1, 1] - m[2, 2],
+                                     1 - m[0, 0] - m[1, 1] + m[2, 2]]))
+    q = cands[best]
+    return (q / torch.linalg.norm(q)).to(R.dtype)
+
+
+class _Stepper:
+    """State of one ``train`` call; calling it runs one iteration."""
+
+    def __call__(self):
+        self.fn()
+
+
+def _within(uv, W, H):
+    return (uv[:, 0] > 0) & (uv[:, 0] < W - 1) & (uv[:, 1] > 0) & (uv[:, 1] < H - 1)
+
+
+class SimpleGaussian:
+    def __init__(self, gt_image, gt_depth=None, gt_flow=None, num_points=100000, background="black",
+                 device=None, log_dir=None, seed=None):
+        self.device = torch.device(device if device is not None else "cuda")
+        if self.device.type != "cuda":
+            raise RuntimeError("gflow_amd.trainer needs a HIP device (there is no CPU rasteriser)")
+        self.gt_image = gt_image.to(self.device)
+        self.gt_depth = gt_depth.to(self.device) if gt_depth is not None else None
+        self.gt_flow = gt_flow.to(self.device) if gt_flow is not None else None
+        self.num_points = num_points
+        H, W, _ = gt_image.shape
+        self.H, self.W = H, W
+        self.bg = {"black": 0.0, "white": 1.0, "cyan": 0.33}.get(background, 0.0)     # trainer.py:29-36
+        fov = math.pi / 2.0
+        fx = 0.5 * float(W) / math.tan(0.5 * fov)
+        fy = 0.5 * float(H) / math.tan(0.5 * fov)
+        self.intr = torch.tensor([fx, fy, W / 2.0, H / 2.0], device=self.device)
+        self.pose = torch.tensor([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], device=self.device)
+        self.rng = np.random.default_rng(seed)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(0 if seed is None else int(seed))
+        N = int(num_points)
+        self._activations = {
+            "scale": torch.abs,
+            "rotate": F.normalize,
+            "opacity": lambda x: torch.sigmoid(x * 10.0),
+            "rgb": torch.sigmoid,
+        }
+        self._activations_inv = {
+            "scale": torch.abs,
+            "rotate": F.normalize,
+            "opacity": lambda x: torch.logit(x) / 10.0,
+            "rgb": torch.logit,
+        }
+        rand = lambda *s: torch.rand(*s, device=self.device, generator=self.gen)
+        self._attributes = {
+            "xyz": rand(N, 3) * 2 - 1,
+            "scale": rand(N, 3),
+            "rotate": F.normalize(rand(N, 4)),
+            "opacity": self._activations_inv["opacity"](0.99 * torch.ones(N, 1, device=self.device)),
+            "rgb": rand(N, 3),
+        }
+        self.dir = log_dir
+        if log_dir is not None:
+            os.makedirs(log_dir, exist_ok=True)
+        self.move_seg = None
+        self.iterations_done = 0          # bookkeeping for throughput reports
+        self.rasterisations_done = 0
+
+    # ------------------------------------------------------------------ camera
+    def get_extr(self):
+        return pose_to_extr(self.pose)
+
+    def load_camera(self, focal=None, pp=None, extr=None, scale=None, show=False):
+        if focal is not None:
+            self.intr[:2] = torch.tensor([focal, focal], dtype=torch.float32, device=self.device)
+        if pp is not None:
+            self.intr[2:] = torch.tensor(pp, dtype=torch.float32, device=self.device)
+        if extr is not None:
+            extr = torch.as_tensor(extr, dtype=torch.float32, device=self.device)
+            T = extr[:3, 3] * (scale if scale is not None else 1.0)
+            pose = self.pose.detach().clone()
+            pose[0:4] = rotmat_to_unitquat_xyzw(extr[:3, :3])
+            pose[4:7] = T
+            self.pose = pose
+        if show:
+            print("[camera] intr:", self.intr, "\n[camera] extr:\n", self.get_extr())
+
+    # -------------------------------------------------------------- parameters
+    def current_pts_num(self):
+        return self._attributes["xyz"].shape[0]
+
+    def get_attribute(self, name):
+        if name not in self._attributes:
+            raise ValueError(f"Attribute or activation for {name} is not VALID!")
+        act = self._activations.get(name)
+        return act(self._attributes[name]) if act is not None else self._attributes[name]
+
+    def init_gaussians_from_image(self, gt_image, gt_depth=None, num_points=None, mask=None, drop_to=None):
+        """trainer.py:206-238."""
+        num_points = self.num_points if num_points is None else num_points
+        xys, depths, scales, rgbs, gt_depth = complex_texture_sampling(
+            gt_image, gt_depth.cpu(), num_points=num_points, mask=mask, drop_to=drop_to, rng=self.rng)
+        n = xys.shape[0]
+        xys = torch.from_numpy(xys).float().to(self.device)
+        depths = depths.float().to(self.device)
+        self.gt_depth = gt_depth.float().to(self.device)
+        self._attributes["xyz"] = geometry.pix2world(xys, depths, self.intr, self.get_extr().detach())
+        scales = scales * (depths / depths.min()).squeeze().cpu().numpy()
+        scales = torch.from_numpy(scales).float().unsqueeze(1).repeat(1, 3).to(self.device)
+        self._attributes["scale"] = self._activations_inv["scale"](torch.clamp(scales, max=1e-3))
+        rgbs = torch.clamp(torch.from_numpy(rgbs).float().contiguous().to(self.device), 1e-15, 1 - 1e-15)
+        self._attributes["rgb"] = self._activations_inv["rgb"](rgbs)
+        self._attributes["opacity"] = self._activations_inv["opacity"](0.99 * torch.ones(n, 1, device=self.device))
+        self._attributes["rotate"] = F.normalize(torch.rand(n, 4, device=self.device, generator=self.gen))
+
+    def add_optimizer(self, lr=1e-2, lr_camera=0.0, depth_invariant=True):
+        """trainer.py:123-153: group "attributes" (lr), "extr" = pose (lr_camera), depth_a / depth_b
+        (lr).  depth_a and depth_b live in one (2,) tensor here."""
+        self.lr, self.lr_camera = lr, lr_camera
+        for k in self._attributes:
+            self._attributes[k] = nn.Parameter(self._attributes[k].detach().contiguous()).requires_grad_(True)
+        self.pose = nn.Parameter(self.pose.detach().clone()).requires_grad_(True)
+        self.depth_ab = nn.Parameter(torch.tensor([1.0, 0.0], device=self.device)).requires_grad_(depth_invariant)
+        groups = [{"params": list(self._attributes.values()), "lr": lr, "name": "attributes"},
+                  {"params": [self.pose], "lr": lr_camera, "name": "extr"}]
+        if depth_invariant:
+            groups.append({"params": [self.depth_ab], "lr": lr, "name": "depth_ab"})
+        self.optimizer = Adam(groups)
+
+    # ------------------------------------------------------------------ render
+    def _input_group(self, sel=None, detach=False):
+        g = []
+        for k in ("xyz", "scale", "rotate", "opacity", "rgb"):
+            a = self.get_attribute(k)
+            if detach:
+                a = a.detach()
+            if sel is not None:
+                a = a[:sel.shape[0]][sel]
+            g.append(a)
+        return g + [self.intr, self.get_extr(), self.bg, self.W, self.H]
+
+    def _render_rgbd(self, want_extras):
+        """One pass of the rasteriser: uv, depth and the 4-plane render (rgb + depth_map);
+        optionally the two snapshot-only images."""
+        xyz, scale, rotate, opacity, rgb, intr, extr, bg, W, H = self._input_group()
+        uv, depth = msplat.project_point(xyz, intr, extr, W, H)
+        visible = depth != 0
+        cov3d = msplat.compute_cov3d(scale, rotate, visible)
+        conic, radius, tiles = msplat.ewa_project(xyz, cov3d, intr, extr, uv, W, H, visible)
+        ids, tile_range = msplat.sort_gaussian(uv, depth, W, H, radius, tiles)
+        self.last_K = ids.numel()
+        render4 = msplat.alpha_blending(uv, conic, opacity, torch.cat([rgb, depth], dim=1), ids, tile_range, bg, W, H)
+        extras = None
+        if want_extras:
+            with torch.no_grad():
+                dc = render_mod.apply_float_colormap(depth.detach(), "turbo", non_zero=True)
+                depth_color = msplat.alpha_blending(uv.detach(), conic.detach(), opacity.detach(), dc, ids,
+                                                    tile_range, bg, W, H)
+                unit = torch.tensor([1.0, 0.0, 1.0], device=self.device)
+                center = msplat.alpha_blending(uv.detach(), torch.ones_like(conic) * unit,
+                                               torch.ones_like(opacity.detach()), rgb.detach(), ids, tile_range, bg,
+                                               W, H)
+            extras = (depth_color, center)
+        self.rasterisations_done += 1
+        return uv, depth, render4, extras
+
+    # ------------------------------------------------------------------- train
+    def make_stepper(self, iterations=500, lr=1e-2, lr_camera=0.0, lambda_rgb=1.0, lambda_depth=0.0,
+                     lambda_flow=0.0, lambda_var=0.0, lambda_still=0.0, lambda_scale=0.0, move_mask=None,
+                     densify_interval=500, densify_times=1, mask=None, camera_only=False, densify_occ_percent=0.1,
+                     densify_err_thre=1e-2, densify_err_percent=0.2, snapshot_interval=10, log_interval=0):
+        """Set up one ``train`` call (pre-update, fresh Adam + LinearLR, trainer.py:347-384) and
+        return a callable that runs ONE iteration of trainer.py:387-582 per call."""
+        W, H, dev = self.W, self.H, self.device
+        if move_mask is not None:
+            move_mask = move_mask.to(dev).bool()
+
+        # ---- pre-update: carry moving splats along the GT flow (trainer.py:348-376)
+        if not camera_only and hasattr(self, "still_mask"):
+            n_last = self.last_still_mask.shape[0]
+            moving = ~self.last_still_mask
+            uv_last = self.last_uv[:n_last]
+            inside = _within(uv_last, W, H) & moving
+            yx = uv_last.long()
+            flow_at = self.gt_flow[yx[:, 1].clamp(0, H - 1), yx[:, 0].clamp(0, W - 1)]
+            uv_new = uv_last + flow_at
+            yn = uv_new[:, 1].long().clamp(0, H - 1)
+            xn = uv_new[:, 0].long().clamp(0, W - 1)
+            depth_new = self.gt_depth[yn, xn]
+            xyz_new = geometry.pix2world(uv_new, depth_new.reshape(-1, 1), self.intr, self.get_extr().detach())
+            xyz = self._attributes["xyz"].detach().clone()
+            xyz[:n_last] = torch.where(inside.unsqueeze(1), xyz_new, xyz[:n_last])
+            self._attributes["xyz"] = xyz
+
+        self.add_optimizer(lr, lr_camera, depth_invariant=True)
+        self.scheduler = LinearLR(self.optimizer, start_factor=1.0, end_factor=0.1, total_iters=iterations)
+        later_frame = hasattr(self, "last_xyz")
+        has_still = hasattr(self, "still_mask")
+        n_still = self.still_mask.shape[0] if has_still else 0
+        st = _Stepper()
+        st.frames, st.frames_depth, st.frames_center, st.log = [], [], [], []
+        st.iteration = 0
+        st.move_mask, st.camera_only = move_mask, camera_only
+
+        def one_iteration():
+            iteration = st.iteration
+            snap = bool(snapshot_interval) and iteration % snapshot_interval == 0
+            uv, depth, render4, extras = self._render_rgbd(want_extras=snap)
+            within = _within(uv.detach(), W, H)
+            self.within_index = within
+            mm = move_mask
+            if hasattr(self, "still_mask_tentative") and camera_only:
+                # moving-splat footprint joins the move mask (trainer.py:427-451)
+                with torch.no_grad():
+                    grp = self._input_group(sel=~self.still_mask_tentative, detach=True)
+                    mrgb = render_mod.render_multiple(grp, ["rgb"])["rgb"]
+                    self.rasterisations_done += 1
+                    grey = 0.299 * mrgb[0] + 0.587 * mrgb[1] + 0.114 * mrgb[2]
+                    mm = (grey > 0.0) | move_mask
+                st.move_mask = mm
+            loss, loss_rgb_pixel, l_rgb, l_depth = losses.image_loss(
+                render4, self.gt_image, self.gt_depth if lambda_depth > 0 else None, self.depth_ab,
+                lambda_rgb if lambda_rgb > 0 else 0.0, lambda_depth if lambda_depth > 0 else 0.0,
+                mm if camera_only else None)
+            terms = {"rgb": l_rgb, "depth": l_depth}
+
+            valid = within
+            if has_still:
+                valid = within.clone()
+                valid[:n_still] = (self.still_mask if camera_only else ~self.still_mask) & valid[:n_still]
+            if lambda_var:
+                l_var = losses.var_loss(self.get_attribute("scale"))
+                loss = loss + lambda_var * l_var
+                terms["var"] = l_var
+            if lambda_scale:
+                # trainer.py:495-502 (scale rows selected by within_index, depths by valid)
+                l_scale = losses.scale_loss(self.get_attribute("scale"), self.within_index, depth[valid])
+                loss = loss + lambda_scale * l_scale
+                terms["scale"] = l_scale
+            if lambda_still and has_still:
+                m = self.last_still_mask
+                diff = torch.norm(self.get_attribute("xyz")[:m.shape[0]] - self.last_xyz[:m.shape[0]], dim=1)
+                l_still = (diff * m).sum() / m.sum()
+                loss = loss + lambda_still * l_still
+                terms["still"] = l_still
+            if lambda_flow and self.gt_flow is not None and hasattr(self, "last_uv"):
+                and_mask = _within(self.last_uv, W, H)
+                if has_still:
+                    and_mask = and_mask.clone()
+                    and_mask[:n_still] = (self.still_mask if camera_only else ~self.still_mask) & and_mask[:n_still]
+                yx = self.last_uv.long()
+                gt_f = self.gt_flow[yx[:, 1].clamp(0, H - 1), yx[:, 0].clamp(0, W - 1)]
+                d = (uv[:self.last_num] - self.last_uv - gt_f) ** 2
+                l_flow = (d * and_mask.unsqueeze(1)).sum() / (2.0 * and_mask.sum())      # mse over selected rows
+                loss = loss + lambda_flow * l_flow
+                terms["flow"] = l_flow
+
+            self.optimizer.zero_grad()
+            loss.backward()
+
+            # ---- gradient control (trainer.py:535-551)
+            if later_frame and self._attributes["rgb"].grad is not None:
+                self._attributes["rgb"].grad.zero_()
+            if has_still and self._attributes["xyz"].grad is not None:
+                self._attributes["xyz"].grad[:n_still] *= (~self.still_mask).unsqueeze(1)
+            if camera_only:
+                for p in self._attributes.values():
+                    if p.grad is not None:
+                        p.grad.zero_()
+            self.optimizer.step()
+            self.scheduler.step()
+            self.iterations_done += 1
+            if log_interval and iteration % log_interval == 0:
+                st.log.append({k: float(v) for k, v in terms.items()} | {"total": float(loss), "it": iteration})
+
+            # ---- densification (trainer.py:560-571)
+            if not camera_only and iteration == 0 and later_frame and mask is not None:
+                if mask.sum() > 0:
+                    self.densify_by_pixels(torch.ones_like(loss_rgb_pixel), error_threshold=0.0,
+                                           percent=densify_occ_percent, mask=mask)
+            if (not camera_only and densify_interval and (iteration + 1) % densify_interval == 0
+                    and (iteration + 1) // densify_interval <= densify_times):
+                self.densify_by_pixels(loss_rgb_pixel, error_threshold=densify_err_thre, percent=densify_err_percent,
+                                       mask=None)
+            if snap:
+                st.frames.append(render_mod.render2img(render4[:3]))
+                st.frames_depth.append(render_mod.render2img(extras[0]))
+                st.frames_center.append(render_mod.render2img(extras[1]))
+            st.uv, st.depth, st.last_render = uv.detach(), depth.detach(), render4.detach()
+            st.iteration += 1
+
+        st.fn = one_iteration
+        return st
+
+    def train(self, iterations=500, save_ckpt=False, ckpt_name="ckpt", snapshot_interval=10, **kw):
+        """One call = the optimisation of one frame (trainer.py:332-711); keyword arguments
+        as ``make_stepper``.  Returns (frames, frames_center, frames_depth, still_rgb,
+        still_center, move_rgb, move_center, move_seg) like the reference; the frame lists
+        hold (H,W,3) uint8 snapshots taken every ``snapshot_interval`` iterations (0 = none)."""
+        W, H, dev = self.W, self.H, self.device
+        st = self.make_stepper(iterations=iterations, snapshot_interval=snapshot_interval, **kw)
+        for _ in range(iterations):
+            st()
+        self.train_log = st.log
+        camera_only, move_mask = st.camera_only, kw.get("move_mask")
+        if move_mask is not None:
+            move_mask = move_mask.to(dev).bool()
+
+        # ---- post-update (trainer.py:588-625)
+        uv_d, depth_d = st.uv, st.depth
+        if not camera_only:
+            within = _within(uv_d, W, H)
+            yx = uv_d.long()
+            labels = ~move_mask[yx[:, 1].clamp(0, H - 1), yx[:, 0].clamp(0, W - 1)]
+            n_now = self.current_pts_num()
+            still = torch.ones(n_now, dtype=torch.bool, device=dev)
+            still[:uv_d.shape[0]] = torch.where(within, labels, still[:uv_d.shape[0]])
+            self.still_mask = still
+            self.still_mask_tentative = still.clone()
+            if hasattr(self, "last_still_mask"):
+                self.still_mask[:self.last_still_mask.shape[0]] = self.last_still_mask
+            self.last_still_mask = self.still_mask.detach()
+            self.last_uv = uv_d
+            self.last_depth = depth_d
+            self.last_xyz = self.get_attribute("xyz").detach()
+            self.last_num = self.last_xyz.shape[0]
+
+        still_rgb = still_center = move_rgb = move_center = None
+        if hasattr(self, "still_mask") and snapshot_interval:
+            with torch.no_grad():
+                o = render_mod.render_multiple(self._input_group(sel=self.still_mask, detach=True), ["rgb", "center"])
+                still_rgb, still_center = render_mod.render2img(o["rgb"]), render_mod.render2img(o["center"])
+                o = render_mod.render_multiple(self._input_group(sel=~self.still_mask, detach=True), ["rgb", "center"])
+                move_rgb, move_center = render_mod.render2img(o["rgb"]), render_mod.render2img(o["center"])
+                self.rasterisations_done += 2
+        self.last_render = st.last_render
+        if save_ckpt:
+            self.save_checkpoint(ckpt_name=ckpt_name)
+        return st.frames, st.frames_center, st.frames_depth, still_rgb, still_center, move_rgb, move_center, self.move_seg
+
+    # ------------------------------------------------------------ densification
+    def densify_by_pixels(self, error_map, error_threshold=1e-3, percent=0.1, mask=None):
+        """trainer.py:878-939 with the sampling on the device."""
+        H, W, dev = self.H, self.W, self.device
+        err = error_map.detach().float()
+        pos = err[err > 0]
+        err = err + (pos.min() if pos.numel() else 0.0)           # uniform floor (trainer.py:884)
+        if mask is None:
+            m = err > error_threshold
+        else:
+            m = mask.detach().to(dev).squeeze()
+            if m.dim() == 3:
+                m = m[..., 0] if m.shape[-1] in (1, 3) else m[0]
+            m = m > 0
+        err = err * m[:, :err.shape[1]]
+        mask_ratio = float(m.sum().item()) / m.numel()
+        densify_num = int(self.num_points * mask_ratio * percent)
+        num_before = self.current_pts_num()
+        if densify_num > 0 and float(err.sum()) > 0:
+            flat = err.flatten()
+            idx = torch.multinomial(flat / flat.sum(), densify_num, replacement=True, generator=self.gen)
+            ys, xs = idx // W, idx % W
+            xys = torch.stack([xs, ys], dim=1).float()
+            depths = self.gt_depth[ys, xs].reshape(-1, 1).float()
+            scales = torch.ones(densify_num, device=dev) * (1.0 / self.num_points)
+            scales = scales * (depths / depths.min()).squeeze(1)
+            new_xyz = geometry.pix2world(xys, depths, self.intr, self.get_extr().detach())
+            new_scale = torch.abs(scales.unsqueeze(1).repeat(1, 3))
+            new_rgb = torch.logit(torch.clamp(self.gt_image[ys, xs].contiguous(), 1e-15, 1 - 1e-15))
+            new_rot = torch.tensor([1.0, 0.0, 0.0, 0.0], device=dev).repeat(densify_num, 1)
+            new_op = torch.logit(0.99 * torch.ones(densify_num, 1, device=dev)) / 10.0
+            self.densification_postfix(new_xyz, new_scale, new_rot, new_op, new_rgb)
+        return num_before, self.current_pts_num()
+
+    def densification_postfix(self, new_xyz, new_scale, new_rotate, new_opacity, new_rgb):
+        """trainer.py:941-951 -- including the quirk that the new optimiser covers only the
+        attributes, with a constant lr and fresh moments."""
+        new = {"xyz": new_xyz, "scale": new_scale, "rotate": new_rotate, "opacity": new_opacity, "rgb": new_rgb}
+        for k in self._attributes:
+            cat = torch.cat((self._attributes[k].detach(), new[k]), dim=0).contiguous()
+            self._attributes[k] = nn.Parameter(cat).requires_grad_(True)
+        self.optimizer = Adam(list(self._attributes.values()), lr=self.lr)
+
+    # -------------------------------------------------------------- checkpoint
+    def save_checkpoint(self, ckpt_name=None):
+        """Same dict keys as trainer.py:252-272."""
+        ckpt = {
+            "attributes": {k: v.detach() for k, v in self._attributes.items()},
+            "intr": self.intr,
+            "extr": self.get_extr().detach(),
+            "still_mask": getattr(self, "still_mask", None),
+            "move_seg": self.move_seg,
+            "last_uv": getattr(self, "last_uv", None),
+            "width": self.W,
+            "height": self.H,
+        }
+        os.makedirs(os.path.join(self.dir, "ckpt"), exist_ok=True)
+        self.checkpoint_path = os.path.join(self.dir, "ckpt", f"{ckpt_name or 'ckpt'}.tar")
+        torch.save(ckpt, self.checkpoint_path)
+
+    def load_checkpoint(self, checkpoint_path):
+        ckpt = torch.load(checkpoint_path, map_location=self.device, weights_only=False)
+        self._attributes = {k: v.to(self.device) for k, v in ckpt["attributes"].items()}
+        self.intr = ckpt["intr"].to(self.device)
+        self.load_camera(extr=ckpt["extr"])
+        for k in ("still_mask", "move_seg", "last_uv"):
+            if ckpt.get(k) is not None:
+                setattr(self, k, ckpt[k])
+
+    def project_points(self, points):
+        return msplat.project_point(points, self.intr, self.get_extr(), self.W, self.H)
+
+    def psnr(self):
+        return self.psnr_of(self.last_render)
+
+    def psnr_of(self, render4):
+        """PSNR of a rendered frame against the ground truth (clamped like the saved PNGs the
+        reference evaluates, benchmark.py:191-230)."""
+        img = torch.clamp(render4[:3].permute(1, 2, 0), 0.0, 1.0)
+        mse = ((img - self.gt_image) ** 2).mean()
+        return -10.0 * torch.log10(mse)

@@ -1,0 +1,160 @@
+/*
+ * gflow_hip.h -- C ABI of libgflow_hip.so, the MI355X (gfx950) native rasteriser,
+ * loss and optimiser kernels behind GFlow's per-frame Gaussian-splatting fit.
+ *
+ * This is the drop-in boundary: the five operators GFlow calls on the external
+ * CUDA extension `msplat` (gflow/utils/render.py:21-105, gflow/trainer.py:955)
+ * plus the loss / Adam pieces of the iteration loop (gflow/trainer.py:387-558).
+ * msplat's own binding layer is not visible in the reference tree, so each entry
+ * point cites the REFERENCE CALL SITE it serves.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless named h_*; tensors are dense,
+ *     row-major, float32 unless stated; `stream` is a hipStream_t (NULL = default);
+ *   - no allocation, no host synchronisation and no global state inside: the
+ *     caller supplies outputs and workspaces, all work is enqueued on `stream`
+ *     (graph-capturable);
+ *   - return value: GFL_OK or a negative gfl_status; HIP launch errors are
+ *     returned as GFL_ERR_HIP and the hipError_t is kept in gfl_last_hip_error();
+ *   - *_bwd functions OVERWRITE their gradient outputs (they zero what they
+ *     accumulate into).
+ */
+#ifndef GFLOW_HIP_H
+#define GFLOW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gfl_stream_t; /* hipStream_t */
+
+typedef enum gfl_status {
+    GFL_OK = 0,
+    GFL_ERR_INVALID = -1,   /* null pointer, negative size, unsupported channel count */
+    GFL_ERR_WORKSPACE = -2, /* workspace smaller than gfl_*_workspace_bytes() */
+    GFL_ERR_HIP = -3        /* a HIP call failed; see gfl_last_hip_error() */
+} gfl_status;
+
+/* Rasteriser constants.  They are internal to msplat and NOT observable from the
+ * reference: every one is an assumption taken from the published
+ * 3DGS/EWA formulation, kept here and mirrored by oracle/msplat_oracle.py. */
+#define GFL_TILE 16
+#define GFL_NEAREST 0.2f
+#define GFL_EXTENT 1.3f
+#define GFL_FOV_CLAMP 1.3f
+#define GFL_LOWPASS 0.3f
+#define GFL_EIG_FLOOR 0.1f
+#define GFL_RADIUS_SIGMA 3.0f
+#define GFL_ALPHA_MIN (1.0f / 255.0f)
+#define GFL_ALPHA_MAX 0.99f
+#define GFL_T_MIN 1e-4f
+#define GFL_MAX_BLEND_CHANNELS 4 /* per launch; the host splits wider features */
+
+int gfl_version(void);
+const char* gfl_status_string(int status);
+int gfl_last_hip_error(void);
+/* bytes of scratch any *_bwd that reduces camera gradients needs for N splats */
+size_t gfl_reduce_workspace_bytes(int N);
+
+/* ---- A4  msplat.project_point  (render.py:21-24,116-119; trainer.py:955) ------
+ * uv[N,2], depth[N,1]; culled splats get uv=(0,0), depth=0 (render.py:29). */
+int gfl_project_point_fwd(const float* xyz, const float* intr, const float* extr, int N, int W, int H,
+                          float nearest, float extent, float* uv, float* depth, gfl_stream_t stream);
+/* d_xyz[N,3], d_extr[12] from d_uv[N,2], d_depth[N,1]; `depth` is the forward output */
+int gfl_project_point_bwd(const float* xyz, const float* intr, const float* extr, const float* depth,
+                          const float* d_uv, const float* d_depth, int N, float* d_xyz, float* d_extr,
+                          void* workspace, size_t workspace_bytes, gfl_stream_t stream);
+
+/* ---- A5  msplat.compute_cov3d  (render.py:37-41) -------------------------------
+ * rotate is WXYZ; visible is uint8[N]; cov3d[N,6] = xx,xy,xz,yy,yz,zz */
+int gfl_cov3d_fwd(const float* scale, const float* rotate, const uint8_t* visible, int N, float* cov3d,
+                  gfl_stream_t stream);
+int gfl_cov3d_bwd(const float* scale, const float* rotate, const uint8_t* visible, const float* d_cov3d,
+                  int N, float* d_scale, float* d_rotate, gfl_stream_t stream);
+
+/* ---- A6  msplat.ewa_project  (render.py:44-49) ---------------------------------
+ * conic[N,3] upper-triangular inverse 2-D covariance, radius[N] int32,
+ * tiles_touched[N] int32 */
+int gfl_ewa_fwd(const float* xyz, const float* cov3d, const float* intr, const float* extr, const float* uv,
+                const uint8_t* visible, int N, int W, int H, float* conic, int32_t* radius,
+                int32_t* tiles_touched, gfl_stream_t stream);
+/* d_xyz[N,3], d_cov3d[N,6], d_extr[12] from d_conic[N,3]; `radius` is the forward output */
+int gfl_ewa_bwd(const float* xyz, const float* cov3d, const float* intr, const float* extr,
+                const int32_t* radius, const float* d_conic, int N, int W, int H, float* d_xyz,
+                float* d_cov3d, float* d_extr, void* workspace, size_t workspace_bytes, gfl_stream_t stream);
+
+/* ---- A7  msplat.sort_gaussian  (render.py:52-54) -------------------------------
+ * Two phases so the host can size gaussian_ids_sorted exactly when it wants to:
+ *   gfl_bin_count: tile_offsets[T+1] = exclusive scan of per-tile splat counts
+ *                  (tile_offsets[T] = K, the number of splat-tile pairs);
+ *   gfl_bin_sort : fills ids[0..min(K,K_cap)) ordered by (tile, depth, id) and
+ *                  tile_range[T,2]; *overflow (device int32) is set to 1 when
+ *                  K > K_cap (the lists are then truncated, never overrun).
+ * `cutoff` may be NULL; if given (float[N]) a tile is only listed when the splat's
+ * exact alpha>=1/255 disc (radius^2 = cutoff) reaches it -- output-preserving
+ * tightening used by the fused path. T = ceil(W/16)*ceil(H/16). */
+size_t gfl_bin_workspace_bytes(int N, int K_cap, int W, int H);
+int gfl_bin_count(const float* uv, const int32_t* radius, const float* cutoff, int N, int W, int H,
+                  int32_t* tile_offsets, gfl_stream_t stream);
+int gfl_bin_sort(const float* uv, const float* depth, const int32_t* radius, const float* cutoff, int N, int W,
+                 int H, const int32_t* tile_offsets, int K_cap, int32_t* ids, int32_t* tile_range,
+                 int32_t* overflow, void* workspace, size_t workspace_bytes, gfl_stream_t stream);
+
+/* ---- A8  msplat.alpha_blending  (render.py:58-64,68-74,84-90,99-105,148-154) ---
+ * feature[N,C_total]; this launch composites channels [c0, c0+C), 1<=C<=4, into
+ * out[C,H,W] (channel-planar, the caller offsets `out` for c0>0).
+ * final_T[H,W] and n_contrib[H,W] (int32) are saved for the backward. */
+int gfl_blend_fwd(const float* uv, const float* conic, const float* opacity, const float* feature,
+                  int C_total, int c0, int C, const int32_t* ids, const int32_t* tile_range, float bg, int W,
+                  int H, float* out, float* final_T, int32_t* n_contrib, gfl_stream_t stream);
+/* Accumulates d_uv[N,2], d_conic[N,3], d_opacity[N], d_feature[N,C_total] (channels
+ * c0..c0+C).  zero_first != 0 zeroes all four first (use 0 for the 2nd.. chunk). */
+int gfl_blend_bwd(const float* uv, const float* conic, const float* opacity, const float* feature,
+                  int C_total, int c0, int C, const int32_t* ids, const int32_t* tile_range, float bg, int W,
+                  int H, const float* final_T, const int32_t* n_contrib, const float* d_out, int N,
+                  float* d_uv, float* d_conic, float* d_opacity, float* d_feature, int zero_first,
+                  gfl_stream_t stream);
+
+/* ---- A9  apply_float_colormap(depth,"turbo",non_zero=True)  (color.py:24-44) ----
+ * Entirely on the device (the reference round-trips through the host every
+ * iteration).  lut[256,3]; out[N,3]; workspace >= 16 bytes. */
+int gfl_colormap_nonzero(const float* value, int N, const float* lut, float* out, void* workspace,
+                         size_t workspace_bytes, gfl_stream_t stream);
+
+/* ---- A10/A11  photometric + SSIM + depth loss, forward and backward ------------
+ * (trainer.py:452-488; utils/pytorch_ssim.py:17-37)
+ * render[4,H,W] = rgb + depth_map planes; gt_rgb[H,W,3]; gt_depth[H,W];
+ * keep[H,W] uint8 or NULL (0 = pixel of the moving region, zeroed as trainer.py:453-455,484);
+ * depth_ab[2] = (depth_a, depth_b) on the device.
+ * Outputs: d_render[4,H,W] = d(lambda_rgb*(mse + 1 - ssim) + lambda_depth*depth)/d render;
+ *          err_px[H,W] = per-pixel mse (the densification error map, trainer.py:459);
+ *          sums[8] (device) = {sum mse_px, sum ssim_map, sum depth_term, d/d depth_a, d/d depth_b, 0,0,0}
+ *          (un-normalised sums; the d/d terms already carry lambda_depth / (H*W)).
+ * workspace: gfl_loss_workspace_bytes(W,H). */
+size_t gfl_loss_workspace_bytes(int W, int H);
+int gfl_loss_fwd_bwd(const float* render, const float* gt_rgb, const float* gt_depth, const uint8_t* keep,
+                     const float* depth_ab, float lambda_rgb, float lambda_depth, int W, int H,
+                     float* d_render, float* err_px, float* sums, void* workspace, size_t workspace_bytes,
+                     gfl_stream_t stream);
+
+/* ---- A13  Adam (torch.optim.Adam defaults, trainer.py:153,554) ------------------
+ * One fused step over n floats: p -= lr * m_hat / (sqrt(v_hat) + eps) with bias
+ * correction for step `*d_step + 1` read on the device (so a captured graph can
+ * replay); `lr_scale` multiplies lr (LinearLR factor computed on the device when
+ * total_iters > 0: 1 + (lr_end_factor-1)*min(step,total)/total; trainer.py:384 uses
+ * start 1.0, end 0.1).
+ * row_zero_grad (uint8 per row of `row_len` floats, or NULL): rows flagged 1 see a
+ * zero gradient (moments still decay), which is what trainer.py:543-551 does.
+ * gfl_step_increment bumps the device step counter once all groups have stepped. */
+int gfl_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, int row_len,
+                  const uint8_t* row_zero_grad, float lr, float beta1, float beta2, float eps,
+                  const int32_t* d_step, float lr_end_factor, int total_iters, gfl_stream_t stream);
+int gfl_step_increment(int32_t* d_step, gfl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GFLOW_HIP_H */

@@ -1,0 +1,341 @@
+"""HIP-vs-oracle parity of the five rasteriser operators (run with ``-m gpu`` on the
+MI355X box).  Everything goes through the C ABI of libgflow_hip.so via
+gflow_amd.msplat.  The oracle (oracle/msplat_oracle.py) is PARITY-UNPINNED against
+real msplat (see oracle/__init__.py); tolerances below are north_star's 1e-4 relative
+on rendered values, with a stated allowance for discrete threshold flips
+(alpha >= 1/255, T >= 1e-4, radius = ceil(.)) that float32 rounding can move.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import msplat_oracle as MO
+from tests.scenes import random_scene, scene_group
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ms():
+    import gflow_amd.msplat as ms
+    return ms
+
+
+def close_frac(a, b, rtol, atol, bad_frac=0.0, hard=None, what=""):
+    """|a-b| <= atol + rtol*|b| for all but ``bad_frac`` of the entries, and never
+    beyond ``hard`` (absolute)."""
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    if a.numel() == 0:
+        return
+    err = (a - b).abs()
+    bad = err > (atol + rtol * b.abs())
+    frac = bad.double().mean().item()
+    assert frac <= bad_frac, f"{what}: {frac:.3e} of entries off (allowed {bad_frac:.1e}); max err {err.max().item():.3e}"
+    if hard is not None:
+        assert err.max().item() <= hard, f"{what}: max err {err.max().item():.3e} > {hard}"
+
+
+def to_dev(s):
+    return {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in s.items()}
+
+
+@pytest.fixture(scope="module")
+def scene():
+    return random_scene(3000, 200, 136, seed=11, sigma_px=2.5)     # ragged: 12.5 x 8.5 tiles
+
+
+# ------------------------------------------------------------------ project_point
+def test_project_point_forward_backward(scene):
+    ms = _ms()
+    s, d = scene, to_dev(scene)
+    W, H = s["W"], s["H"]
+    xyz_c = s["xyz"].clone().requires_grad_(True)
+    ext_c = s["extr"].clone().requires_grad_(True)
+    uv_c, dep_c = MO.project_point(xyz_c, s["intr"], ext_c, W, H)
+    xyz_g = d["xyz"].clone().requires_grad_(True)
+    ext_g = d["extr"].clone().requires_grad_(True)
+    uv_g, dep_g = ms.project_point(xyz_g, d["intr"], ext_g, W, H)
+    assert torch.equal((dep_g != 0).cpu(), dep_c != 0)                 # same culling decisions
+    assert int((dep_c == 0).sum()) > 0
+    close_frac(uv_g, uv_c, 1e-5, 1e-3, what="uv")
+    close_frac(dep_g, dep_c, 1e-6, 1e-6, what="depth")
+    g = torch.Generator().manual_seed(0)
+    wu, wd = torch.randn(uv_c.shape, generator=g), torch.randn(dep_c.shape, generator=g)
+    ((uv_c * wu).sum() + (dep_c * wd).sum()).backward()
+    ((uv_g * wu.to(DEV)).sum() + (dep_g * wd.to(DEV)).sum()).backward()
+    close_frac(xyz_g.grad, xyz_c.grad, 1e-4, 1e-3, what="d_xyz")
+    close_frac(ext_g.grad, ext_c.grad, 1e-4, 1e-4 * ext_c.grad.abs().max().item(), what="d_extr")
+
+
+# ------------------------------------------------------------------ compute_cov3d
+def test_cov3d_forward_backward(scene):
+    ms = _ms()
+    s, d = scene, to_dev(scene)
+    vis = torch.rand(s["xyz"].shape[0], 1, generator=torch.Generator().manual_seed(1)) > 0.1
+    sc_c, q_c = s["scale"].clone().requires_grad_(True), s["rotate"].clone().requires_grad_(True)
+    sc_g, q_g = d["scale"].clone().requires_grad_(True), d["rotate"].clone().requires_grad_(True)
+    cov_c = MO.compute_cov3d(sc_c, q_c, vis)
+    cov_g = ms.compute_cov3d(sc_g, q_g, vis.to(DEV))
+    scale_ref = cov_c.abs().max().item()
+    close_frac(cov_g, cov_c, 1e-5, 1e-6 * scale_ref, what="cov3d")
+    w = torch.randn(cov_c.shape, generator=torch.Generator().manual_seed(2))
+    (cov_c * w).sum().backward()
+    (cov_g * w.to(DEV)).sum().backward()
+    close_frac(sc_g.grad, sc_c.grad, 1e-4, 1e-5 * sc_c.grad.abs().max().item(), what="d_scale")
+    close_frac(q_g.grad, q_c.grad, 1e-4, 1e-5 * q_c.grad.abs().max().item(), what="d_rotate")
+
+
+# -------------------------------------------------------------------- ewa_project
+def _front_end(s, ops, dev):
+    uv, depth = ops.project_point(s["xyz"], s["intr"], s["extr"], s["W"], s["H"])
+    vis = depth != 0
+    cov = ops.compute_cov3d(s["scale"], s["rotate"], vis)
+    return uv, depth, vis, cov
+
+
+def test_ewa_forward_backward(scene):
+    ms = _ms()
+    s, d = scene, to_dev(scene)
+    W, H = s["W"], s["H"]
+    uv_c, dep_c, vis_c, cov_c = _front_end(s, MO, "cpu")
+    xyz_c = s["xyz"].clone().requires_grad_(True)
+    cov_cl = cov_c.detach().clone().requires_grad_(True)
+    ext_c = s["extr"].clone().requires_grad_(True)
+    con_c, rad_c, til_c = MO.ewa_project(xyz_c, cov_cl, s["intr"], ext_c, uv_c, W, H, vis_c)
+    xyz_g = d["xyz"].clone().requires_grad_(True)
+    cov_g = cov_c.detach().to(DEV).requires_grad_(True)
+    ext_g = d["extr"].clone().requires_grad_(True)
+    con_g, rad_g, til_g = ms.ewa_project(xyz_g, cov_g, d["intr"], ext_g, uv_c.to(DEV), W, H, vis_c.to(DEV))
+    assert rad_g.dtype == torch.int32 and til_g.dtype == torch.int32 and rad_g.shape == (3000, 1)
+    same = (rad_g.cpu() == rad_c).reshape(-1)
+    assert same.double().mean().item() >= 0.999      # ceil() may flip on an exact boundary
+    assert torch.equal(til_g.cpu()[same], til_c[same])
+    close_frac(con_g[same.to(DEV)], con_c[same], 2e-5, 1e-7, what="conic")
+    w = torch.randn(con_c.shape, generator=torch.Generator().manual_seed(3)) * same.unsqueeze(1)
+    (con_c * w).sum().backward()
+    (con_g * w.to(DEV)).sum().backward()
+    for name, a, b in (("d_xyz", xyz_g.grad, xyz_c.grad), ("d_cov3d", cov_g.grad, cov_cl.grad),
+                       ("d_extr", ext_g.grad, ext_c.grad)):
+        close_frac(a, b, 2e-4, 2e-5 * b.abs().max().item(), bad_frac=2e-4, what=name)
+
+
+# ------------------------------------------------------------------ sort_gaussian
+def test_sort_matches_oracle_exactly(scene):
+    ms = _ms()
+    s = scene
+    W, H = s["W"], s["H"]
+    uv, depth, vis, cov = _front_end(s, MO, "cpu")
+    conic, radius, tiles = MO.ewa_project(s["xyz"], cov, s["intr"], s["extr"], uv, W, H, vis)
+    # make some depth ties so the id tie-break is exercised
+    depth = depth.clone()
+    depth[100:140] = depth[100]
+    ids_c, tr_c = MO.sort_gaussian(uv, depth, W, H, radius, tiles)
+    ids_g, tr_g = ms.sort_gaussian(uv.to(DEV), depth.to(DEV), W, H, radius.to(DEV), tiles.to(DEV))
+    assert ids_g.dtype == torch.int32 and tr_g.dtype == torch.int32
+    assert ids_g.numel() == int(tiles.sum())
+    assert torch.equal(tr_g.cpu(), tr_c)
+    assert torch.equal(ids_g.cpu(), ids_c)
+
+
+def test_sort_large_tile_uses_global_fallback():
+    ms = _ms()
+    # 6000 splats all covering the same 2x2 tiles: segments longer than the LDS capacity
+    n, W, H = 6000, 32, 32
+    g = torch.Generator().manual_seed(5)
+    uv = 8 + 16 * torch.rand(n, 2, generator=g)
+    depth = 1 + torch.rand(n, 1, generator=g)
+    radius = torch.full((n, 1), 40, dtype=torch.int32)
+    tiles = torch.full((n, 1), 4, dtype=torch.int32)
+    ids_c, tr_c = MO.sort_gaussian(uv, depth, W, H, radius, tiles)
+    ids_g, tr_g = ms.sort_gaussian(uv.to(DEV), depth.to(DEV), W, H, radius.to(DEV), tiles.to(DEV))
+    assert torch.equal(tr_g.cpu(), tr_c) and torch.equal(ids_g.cpu(), ids_c)
+
+
+# ----------------------------------------------------------------- alpha_blending
+def _blend_inputs(s, feat_extra=None):
+    W, H = s["W"], s["H"]
+    uv, depth, vis, cov = _front_end(s, MO, "cpu")
+    conic, radius, tiles = MO.ewa_project(s["xyz"], cov, s["intr"], s["extr"], uv, W, H, vis)
+    ids, tr = MO.sort_gaussian(uv, depth, W, H, radius, tiles)
+    return uv.detach(), conic.detach(), depth.detach(), ids, tr
+
+
+@pytest.mark.parametrize("C,bg", [(3, 0.0), (1, 0.33), (4, 1.0), (6, 0.2)])
+def test_blend_forward_backward(scene, C, bg):
+    ms = _ms()
+    s = scene
+    W, H = s["W"], s["H"]
+    uv, conic, depth, ids, tr = _blend_inputs(s)
+    g = torch.Generator().manual_seed(7 + C)
+    feat = torch.rand(uv.shape[0], C, generator=g)
+    leaves_c = [t.clone().requires_grad_(True) for t in (uv, conic, s["opacity"], feat)]
+    leaves_g = [t.clone().to(DEV).requires_grad_(True) for t in (uv, conic, s["opacity"], feat)]
+    out_c = MO.alpha_blending(*leaves_c, ids, tr, bg, W, H)
+    out_g = ms.alpha_blending(*leaves_g, ids.to(DEV), tr.to(DEV), bg, W, H)
+    assert out_g.shape == (C, H, W)
+    # 1e-4 relative on rendered values; a flipped 1/255 splat moves a pixel by < 4e-3
+    close_frac(out_g, out_c, 1e-4, 1e-5, bad_frac=1e-4, hard=5e-3, what=f"blend C={C}")
+    w = torch.randn(out_c.shape, generator=g)
+    (out_c * w).sum().backward()
+    (out_g * w.to(DEV)).sum().backward()
+    for name, a, b in zip(("d_uv", "d_conic", "d_opacity", "d_feature"), leaves_g, leaves_c):
+        ref = b.grad
+        close_frac(a.grad, ref, 1e-3, 1e-4 * ref.abs().max().item(), bad_frac=2e-3, what=f"{name} C={C}")
+        # aggregate agreement is much tighter than the per-entry bound
+        rel = (a.grad.cpu() - ref).norm() / ref.norm()
+        assert rel < 2e-4, f"{name}: relative L2 error {rel:.2e}"
+
+
+def test_blend_single_blob_known_answer():
+    ms = _ms()
+    W, H = 48, 32
+    uv = torch.tensor([[20.0, 12.0]], device=DEV)
+    ids, tr = ms.sort_gaussian(uv, torch.tensor([[1.0]], device=DEV), W, H,
+                               torch.tensor([[6]], dtype=torch.int32, device=DEV),
+                               torch.tensor([[4]], dtype=torch.int32, device=DEV))
+    out = ms.alpha_blending(uv, torch.tensor([[1.0, 0.0, 1.0]], device=DEV), torch.tensor([[1.0]], device=DEV),
+                            torch.tensor([[0.2, 0.5, 0.9]], device=DEV), ids, tr, 0.33, W, H).cpu()
+    for (x, y) in [(20, 12), (21, 12), (22, 14), (17, 9), (26, 12), (46, 30)]:
+        a = min(0.99, math.exp(-0.5 * ((20 - x) ** 2 + (12 - y) ** 2)))
+        a = a if a >= 1 / 255 else 0.0
+        for c, f in enumerate([0.2, 0.5, 0.9]):
+            assert abs(out[c, y, x].item() - (a * f + (1 - a) * 0.33)) < 2e-6
+
+
+def test_blend_termination_branch():
+    ms = _ms()
+    W, H, n = 16, 16, 12
+    uv = torch.full((n, 2), 8.0)
+    con = torch.tensor([[0.05, 0.0, 0.05]]).repeat(n, 1)
+    op = torch.full((n, 1), 0.95)
+    f = torch.linspace(0.1, 1.0, n).unsqueeze(1)
+    d = torch.linspace(1.0, 2.0, n).unsqueeze(1)
+    rad = torch.full((n, 1), 10, dtype=torch.int32)
+    ids, tr = MO.sort_gaussian(uv, d, W, H, rad, rad)
+    ref, final_T, ncon = MO.alpha_blending_loops(uv, con, op, f, ids, tr, 1.0, W, H)
+    out = ms.alpha_blending(uv.to(DEV), con.to(DEV), op.to(DEV), f.to(DEV), ids.to(DEV), tr.to(DEV), 1.0, W, H)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
+    assert ncon[8, 8] == 3
+
+
+def test_empty_inputs_render_background():
+    import gflow_amd.render as R
+    W, H = 40, 24
+    s = to_dev(random_scene(0, W, H))
+    out = R.render_multiple(scene_group(s, bg=0.33), ["rgb", "depth_map", "uv", "center"])
+    assert out["rgb"].shape == (3, H, W) and torch.all(out["rgb"] == 0.33)
+    assert torch.all(out["depth_map"] == 0.33) and out["uv"].shape == (0, 2)
+    assert torch.all(out["center"] == 0.33)
+
+
+def test_api_rejects_bad_arguments():
+    ms = _ms()
+    with pytest.raises(RuntimeError):
+        ms.project_point(torch.zeros(4, 3), torch.zeros(4), torch.zeros(3, 4), 8, 8)          # CPU tensors
+    with pytest.raises(RuntimeError):
+        ms.project_point(torch.zeros(4, 2, device=DEV), torch.zeros(4, device=DEV), torch.zeros(3, 4, device=DEV), 8, 8)
+    with pytest.raises(RuntimeError):
+        ms.compute_cov3d(torch.zeros(4, 3, device=DEV, dtype=torch.float64), torch.zeros(4, 4, device=DEV),
+                         torch.ones(4, 1, device=DEV, dtype=torch.bool))
+
+
+# ---------------------------------------------------------- render_multiple, whole
+def test_render_multiple_end_to_end(scene):
+    import gflow_amd.render as R
+    s, d = scene, to_dev(scene)
+    W, H = s["W"], s["H"]
+    names = ("xyz", "scale", "rotate", "opacity", "rgb")
+    lc = [s[k].clone().requires_grad_(True) for k in names]
+    lg = [d[k].clone().requires_grad_(True) for k in names]
+    ec = s["extr"].clone().requires_grad_(True)
+    eg = d["extr"].clone().requires_grad_(True)
+    types = ["rgb", "uv", "depth", "depth_map", "depth_map_color", "center"]
+    oc = MO.render_multiple([*lc, s["intr"], ec, 0.2, W, H], types)
+    og = R.render_multiple([*lg, d["intr"], eg, 0.2, W, H], types)
+    for k in ("rgb", "depth_map", "depth_map_color", "center"):
+        close_frac(og[k], oc[k], 1e-4, 1e-5, bad_frac=3e-4, hard=2e-2, what=k)
+    close_frac(og["uv"], oc["uv"], 1e-5, 1e-3, what="uv")
+    gen = torch.Generator().manual_seed(9)
+    w_rgb, w_dm = torch.randn(3, H, W, generator=gen), torch.randn(1, H, W, generator=gen)
+    w_uv = 0.01 * torch.randn(oc["uv"].shape, generator=gen)
+    ((oc["rgb"] * w_rgb).sum() + (oc["depth_map"] * w_dm).sum() + (oc["uv"] * w_uv).sum()).backward()
+    ((og["rgb"] * w_rgb.to(DEV)).sum() + (og["depth_map"] * w_dm.to(DEV)).sum() + (og["uv"] * w_uv.to(DEV)).sum()).backward()
+    for name, a, b in zip(names, lg, lc):
+        rel = (a.grad.cpu() - b.grad).norm() / b.grad.norm()
+        assert rel < 1e-3, f"d_{name}: relative L2 error {rel:.2e}"
+        close_frac(a.grad, b.grad, 2e-3, 2e-4 * b.grad.abs().max().item(), bad_frac=5e-3, what=f"d_{name}")
+    rel = (eg.grad.cpu() - ec.grad).norm() / ec.grad.norm()
+    assert rel < 1e-3, f"d_extr: relative L2 error {rel:.2e}"
+
+
+# -------------------------------------------- full-size (480p, 60k) properties
+@pytest.fixture(scope="module")
+def big():
+    return to_dev(random_scene(60000, 854, 480, seed=21, sigma_px=1.5, behind=0.02))
+
+
+def test_fullsize_sorted_deterministic_linear(big):
+    ms = _ms()
+    s = big
+    W, H = s["W"], s["H"]
+    uv, depth = ms.project_point(s["xyz"], s["intr"], s["extr"], W, H)
+    vis = depth != 0
+    cov = ms.compute_cov3d(s["scale"], s["rotate"], vis)
+    conic, radius, tiles = ms.ewa_project(s["xyz"], cov, s["intr"], s["extr"], uv, W, H, vis)
+    ids, tr = ms.sort_gaussian(uv, depth, W, H, radius, tiles)
+    K = int(tiles.sum())
+    assert ids.numel() == K and K > 60000
+    # tile ranges partition [0,K) and every list is depth-sorted with id tie-break
+    tr_c, ids_c, dep_c = tr.cpu().long(), ids.cpu().long(), depth.cpu().reshape(-1)
+    lens = tr_c[:, 1] - tr_c[:, 0]
+    assert int(lens.sum()) == K
+    d_sorted = dep_c[ids_c]
+    starts = torch.cumsum(lens, 0) - lens
+    assert torch.equal(tr_c[lens > 0, 0], starts[lens > 0])          # segments laid out in tile order
+    seg = torch.repeat_interleave(torch.arange(tr_c.shape[0]), lens)
+    same_seg = seg[1:] == seg[:-1]
+    dd = d_sorted[1:] - d_sorted[:-1]
+    assert torch.all(dd[same_seg] >= 0)
+    tie = same_seg & (dd == 0)
+    assert torch.all(ids_c[1:][tie] > ids_c[:-1][tie])
+    # determinism: two runs, bit-identical lists and images
+    ids2, tr2 = ms.sort_gaussian(uv, depth, W, H, radius, tiles)
+    assert torch.equal(ids, ids2) and torch.equal(tr, tr2)
+    img = ms.alpha_blending(uv, conic, s["opacity"], s["rgb"], ids, tr, 0.0, W, H)
+    img2 = ms.alpha_blending(uv, conic, s["opacity"], s["rgb"], ids, tr, 0.0, W, H)
+    assert torch.equal(img, img2)
+    assert torch.isfinite(img).all() and img.min() >= 0 and img.max() <= 1.0 + 1e-5
+    # linearity in the feature (bg = 0): blend(f1 + 2 f2) = blend(f1) + 2 blend(f2)
+    f2 = torch.rand_like(s["rgb"])
+    lhs = ms.alpha_blending(uv, conic, s["opacity"], s["rgb"] + 2 * f2, ids, tr, 0.0, W, H)
+    rhs = img + 2 * ms.alpha_blending(uv, conic, s["opacity"], f2, ids, tr, 0.0, W, H)
+    assert (lhs - rhs).abs().max().item() < 2e-5
+    # constant feature 1 with bg 1 renders exactly-ish 1 everywhere (sum w + T = 1)
+    ones = ms.alpha_blending(uv, conic, s["opacity"], torch.ones_like(s["rgb"][:, :1]), ids, tr, 1.0, W, H)
+    assert (ones - 1).abs().max().item() < 1e-5
+
+
+def test_fullsize_gradient_sums(big):
+    """Backward property at full size: for out = blend(feature), sum over splats of
+    d_feature equals the image-space sum of w * (1 - T_final) when bg = 0 and the
+    feature is one channel of ones (each pixel's weights sum to 1 - T_final)."""
+    ms = _ms()
+    s = big
+    W, H = s["W"], s["H"]
+    uv, depth = ms.project_point(s["xyz"], s["intr"], s["extr"], W, H)
+    vis = depth != 0
+    cov = ms.compute_cov3d(s["scale"], s["rotate"], vis)
+    conic, radius, tiles = ms.ewa_project(s["xyz"], cov, s["intr"], s["extr"], uv, W, H, vis)
+    ids, tr = ms.sort_gaussian(uv, depth, W, H, radius, tiles)
+    feat = torch.ones(uv.shape[0], 1, device=DEV, requires_grad=True)
+    out = ms.alpha_blending(uv, conic, s["opacity"], feat, ids, tr, 0.0, W, H)
+    w = torch.rand_like(out)
+    (out * w).sum().backward()
+    lhs = feat.grad.double().sum().item()
+    rhs = (out.detach().double() * w.double()).sum().item()     # out = sum of weights = 1 - T_final
+    assert abs(lhs - rhs) <= 1e-4 * abs(rhs)
