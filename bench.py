@@ -41,40 +41,26 @@ def algorithmic_bytes(kind, N, K, P):
     raise KeyError(kind)
 
 
-class KernelTimer:
-    """HIP events on the stream the kernels are launched on (torch's current stream),
-    recorded around the library calls whose names are listed in ``watch``."""
+STAGES = ["preprocess", "colscan", "scatter", "tile_sort", "blend_fwd", "loss", "blend_bwd", "pre_bwd_adam", "camera"]
 
-    def __init__(self, lib, watch):
-        self.events = {k: [] for k in watch}
-        self._orig = {}
-        self.lib = lib
-        for kind, fn_name in watch.items():
-            orig = getattr(lib, fn_name)
-            self._orig[fn_name] = orig
 
-            def wrapped(*a, _o=orig, _k=kind):
-                if not self.enabled:
-                    return _o(*a)
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-                rc = _o(*a)
-                e1.record()
-                self.events[_k].append((e0, e1))
-                return rc
-            setattr(lib, fn_name, wrapped)
-        self.enabled = False
-
-    def mean_ms(self):
-        return {k: (sum(a.elapsed_time(b) for a, b in v) / len(v) if v else None) for k, v in self.events.items()}
+def profile_read(lib):
+    """Average milliseconds per stage from the HIP events the library recorded on the
+    launch stream (gfl_profile_enable / gfl_profile_read, include/gflow_hip.h)."""
+    import ctypes
+    tot = (ctypes.c_double * len(STAGES))()
+    cnt = (ctypes.c_int * len(STAGES))()
+    lib.gfl_profile_read(tot, cnt, len(STAGES))
+    return {STAGES[i]: tot[i] / cnt[i] for i in range(len(STAGES)) if cnt[i]}
 
 
 def cpu_baseline(seconds_budget=25.0):
     """The oracle's fit iteration on the host cores, same workload, bounded sample."""
     from gflow_amd import synthetic as S
     from oracle.fit_oracle import OracleFit
-    cores = os.cpu_count() or 1
+    # eager torch on hundreds of threads thrashes on the many small index ops of the
+    # oracle (measured: 256 threads are ~100x slower than 8); use at most 16
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     frame = S.make_frame(H, W, seed=0)
     raw = S.init_splats(frame, N_SPLATS, seed=0, grown=True)
@@ -82,7 +68,7 @@ def cpu_baseline(seconds_budget=25.0):
     fit.step()                                   # warm-up (allocator, thread pool)
     t0 = time.time()
     n = 0
-    while n < 2 or (time.time() - t0 < seconds_budget and n < 8):
+    while n < 1 or (time.time() - t0 < seconds_budget and n < 8):
         fit.step()
         n += 1
     dt = (time.time() - t0) / n
@@ -118,7 +104,6 @@ def main():
     from gflow_amd import synthetic as S
     from gflow_amd.trainer import SimpleGaussian
     lib = _lib.load()
-    timer = KernelTimer(lib, {"blend_fwd": "gfl_blend_fwd", "blend_bwd": "gfl_blend_bwd", "loss": "gfl_loss_fwd_bwd"})
 
     frame = S.make_frame(H, W, seed=rank)
     raw = S.init_splats(frame, N_SPLATS, seed=rank, grown=True)
@@ -132,7 +117,8 @@ def main():
     stepper = tr.make_stepper(iterations=500, **kw)
     for _ in range(args.warmup):
         stepper()
-    timer.enabled = True
+    # HIP events around the three heaviest stages only, to keep the timed region undisturbed
+    lib.gfl_profile_enable((1 << 4) | (1 << 5) | (1 << 6))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -143,9 +129,17 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    timer.enabled = False
+    lib.gfl_profile_enable(0)
+    kern = profile_read(lib)
+    # untimed extra pass with every stage instrumented, for the per-kernel table
+    lib.gfl_profile_enable((1 << len(STAGES)) - 1)
+    for _ in range(10):
+        stepper()
+    torch.cuda.synchronize()
+    lib.gfl_profile_enable(0)
+    kern_all = profile_read(lib)
 
-    K = int(tr.last_K)
+    K = tr.engine.K if tr.engine is not None else int(tr.last_K)
     psnr = float(tr.psnr_of(stepper.last_render))
     stats = torch.tensor([elapsed, float(args.steps), psnr, float(K)], dtype=torch.float64, device=dev)
     tmax = stats[:1].clone()
@@ -156,7 +150,6 @@ def main():
     total_steps = float(stats[1].item())
     if rank == 0:
         it_per_s = total_steps / wall
-        kern = timer.mean_ms()
         P = H * W
         roof = {}
         for kind, ms in kern.items():
@@ -187,6 +180,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": roof[dom]["GBps"], "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": roof[dom]["GBps"] / HBM_PEAK_GBPS, "traffic": None},
             "kernels": roof,
+            "stage_ms_untimed_pass": kern_all,
             "end_to_end_algorithmic_GBps": (724 * N_SPLATS + 124 * K + 96 * P) * it_per_s / world / 1e9,
         }
         if world == 1 and not args.no_cpu_baseline:

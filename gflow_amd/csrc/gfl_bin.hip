@@ -225,4 +225,12 @@ int gfl_bin_sort(const float* uv, const float* depth, const int32_t* radius, con
     return check_launch();
 }
 
+int gfl_tile_sort_only(const int32_t* tile_offsets, int T, int K_cap, void* keys, int32_t* ids, int32_t* tile_range,
+                       gfl_stream_t stream) {
+    if (T <= 0 || K_cap < 0 || !tile_offsets || !keys || !tile_range || (K_cap > 0 && !ids)) return GFL_ERR_INVALID;
+    bin_tile_sort_kernel<<<T, 256, 0, (hipStream_t)stream>>>(tile_offsets, K_cap, (unsigned long long*)keys, ids,
+                                                             tile_range);
+    return check_launch();
+}
+
 }  // extern "C"

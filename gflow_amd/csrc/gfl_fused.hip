@@ -1,0 +1,765 @@
+// Fused fit iteration: the whole of gflow/trainer.py:387-558 (activations, render,
+// losses, backward, gradient masking, Adam) as ~10 kernel launches issued by ONE
+// library call, with no host read-back and every launch sized by N, T or the image
+// (never by the data-dependent pair count K) -> graph-capturable.
+//
+// Data layout in HBM (288 GB: capacity-based, nothing is reallocated when N grows)
+//   params / adam_m / adam_v : [cap][16] f32, one 64-byte row per splat
+//        x y z | sx sy sz | qw qx qy qz | opacity | r g b | pad pad      (raw values)
+//   rec   : [cap][12] f32, what a pixel needs from a splat (3 x 16-byte loads)
+//        u v A B | C opacity r g | b depth cutoff radius(int bits)
+//   d_rec : [cap][12] f32, gradient of the loss wrt the first 10 entries of rec
+//   keys  : [K_cap] u64 (depth bits << 32 | id), ids : [K_cap] i32, tile_range [T][2]
+//   hist  : [n_bin_blocks][T] i32 per-block tile histogram -> per-block base offsets
+//
+// Binning without global atomics (measured: 258k L2 atomics cost 70-100 us):
+//   preprocess  : each 512-splat block counts its splat-tile pairs in an LDS histogram
+//                 and writes the row hist[b][*];
+//   colscan     : one workgroup turns the columns into exclusive per-block bases and the
+//                 tile totals into tile_offsets (exclusive scan);
+//   scatter     : each block re-walks its splats, ranks pairs with LDS atomics and writes
+//                 keys[tile_offsets[t] + base[b][t] + rank];
+//   tile sort   : per-tile bitonic sort of the unique 64-bit keys (gfl_bin.hip) ->
+//                 order is independent of the LDS-atomic arrival order.
+#include "gfl_math.hpp"
+#include "gfl_profile.hpp"
+
+namespace gfl {
+
+constexpr int BIN_BLOCK = 512;
+constexpr int ROW = 16;   // floats per params row
+constexpr int REC = 12;   // floats per rec row
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// pose [qx,qy,qz,qw,tx,ty,tz] -> camera (trainer.py:115-121)
+__device__ __forceinline__ Cam cam_from_pose(const float* __restrict__ intr, const float* __restrict__ pose) {
+    Cam c;
+    c.fx = intr[0]; c.fy = intr[1]; c.cx = intr[2]; c.cy = intr[3];
+    float x = pose[0], y = pose[1], z = pose[2], w = pose[3];
+    const float inv = 1.0f / sqrtf(x * x + y * y + z * z + w * w);
+    x *= inv; y *= inv; z *= inv; w *= inv;
+    c.r00 = 1.f - 2.f * (y * y + z * z); c.r01 = 2.f * (x * y - w * z); c.r02 = 2.f * (x * z + w * y);
+    c.r10 = 2.f * (x * y + w * z); c.r11 = 1.f - 2.f * (x * x + z * z); c.r12 = 2.f * (y * z - w * x);
+    c.r20 = 2.f * (x * z - w * y); c.r21 = 2.f * (y * z + w * x); c.r22 = 1.f - 2.f * (x * x + y * y);
+    c.t0 = pose[4]; c.t1 = pose[5]; c.t2 = pose[6];
+    return c;
+}
+
+struct Splat {           // activated parameters of one splat
+    float x, y, z;
+    float s[3], raw_s[3];
+    float q[4], raw_q[4], qn;
+    float o, c[3];
+};
+
+__device__ __forceinline__ Splat load_splat(const float* __restrict__ params, int i) {
+    const float4* row = reinterpret_cast<const float4*>(params + (size_t)i * ROW);
+    const float4 a = row[0], b = row[1], c = row[2], d = row[3];
+    Splat s;
+    s.x = a.x; s.y = a.y; s.z = a.z;
+    s.raw_s[0] = a.w; s.raw_s[1] = b.x; s.raw_s[2] = b.y;
+    s.raw_q[0] = b.z; s.raw_q[1] = b.w; s.raw_q[2] = c.x; s.raw_q[3] = c.y;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s.s[k] = fabsf(s.raw_s[k]);                       // trainer.py:65
+    s.qn = fmaxf(sqrtf(s.raw_q[0] * s.raw_q[0] + s.raw_q[1] * s.raw_q[1] + s.raw_q[2] * s.raw_q[2] +
+                       s.raw_q[3] * s.raw_q[3]), 1e-12f);                         // F.normalize, trainer.py:66
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s.q[k] = s.raw_q[k] / s.qn;
+    s.o = sigmoidf_(10.0f * c.z);                                                 // trainer.py:58-59,67
+    s.c[0] = sigmoidf_(c.w); s.c[1] = sigmoidf_(d.x); s.c[2] = sigmoidf_(d.y);    // trainer.py:68
+    return s;
+}
+
+// squared radius of the disc outside which alpha < 1/255 for every pixel, with a
+// safety margin so that a culled (splat, tile) pair is skipped by the blend as well
+__device__ __forceinline__ float alpha_cutoff(float o, float lam) {
+    if (o < GFL_ALPHA_MIN) return -1.0f;                 // never visible
+    const float r = 255.0f * o;
+    if (r < 1.05f) return 3.0e38f;                       // too close to the threshold: no culling
+    return 2.0f * __logf(r) * lam * 1.002f + 0.01f;
+}
+
+__device__ __forceinline__ bool tile_hit2(float u, float v, float cutoff, int tx, int ty) {
+    const float x_lo = (float)(tx * GFL_TILE), x_hi = x_lo + (float)(GFL_TILE - 1);
+    const float y_lo = (float)(ty * GFL_TILE), y_hi = y_lo + (float)(GFL_TILE - 1);
+    const float ddx = fmaxf(fmaxf(x_lo - u, u - x_hi), 0.f);
+    const float ddy = fmaxf(fmaxf(y_lo - v, v - y_hi), 0.f);
+    return ddx * ddx + ddy * ddy <= cutoff;
+}
+
+// ------------------------------------------------------------------ preprocess fwd
+__global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
+    const float* __restrict__ params, const float* __restrict__ intr, const float* __restrict__ pose, int N, int W, int H,
+    float nearest, float extent, int gx, int gy, float* __restrict__ rec, float* __restrict__ d_rec,
+    int32_t* __restrict__ hist_g, float* __restrict__ extr_out) {
+    extern __shared__ int32_t hist[];
+    const int T = gx * gy;
+    for (int t = threadIdx.x; t < T; t += BIN_BLOCK) hist[t] = 0;
+    __syncthreads();
+    const Cam c = cam_from_pose(intr, pose);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        extr_out[0] = c.r00; extr_out[1] = c.r01; extr_out[2] = c.r02; extr_out[3] = c.t0;
+        extr_out[4] = c.r10; extr_out[5] = c.r11; extr_out[6] = c.r12; extr_out[7] = c.t1;
+        extr_out[8] = c.r20; extr_out[9] = c.r21; extr_out[10] = c.r22; extr_out[11] = c.t2;
+    }
+    const int i = blockIdx.x * BIN_BLOCK + threadIdx.x;
+    if (i < N) {
+        const Splat s = load_splat(params, i);
+        const Proj p = project_fwd(c, s.x, s.y, s.z, W, H, nearest, extent);
+        float u = 0.f, v = 0.f, depth = 0.f, A = 0.f, B = 0.f, C = 0.f, cutoff = 0.f;
+        int rad = 0;
+        if (p.vis) {
+            u = p.u; v = p.v; depth = p.pz;
+            float cov[6];
+            cov3d_fwd(s.s, s.q, cov);
+            const Ewa e = ewa_fwd(c, p.px, p.py, p.pz, cov, W, H);
+            if (e.ok) {
+                const int r = ewa_radius(e);
+                int x0, x1, y0, y1;
+                tile_rect(u, v, r, gx, gy, x0, x1, y0, y1);
+                if ((x1 - x0) * (y1 - y0) > 0) {
+                    rad = r;
+                    A = e.c / e.det; B = -e.b / e.det; C = e.a / e.det;
+                    cutoff = alpha_cutoff(s.o, e.lam);
+                    for (int ty = y0; ty < y1; ++ty)
+                        for (int tx = x0; tx < x1; ++tx)
+                            if (tile_hit2(u, v, cutoff, tx, ty)) atomicAdd(&hist[ty * gx + tx], 1);
+                }
+            }
+        }
+        float4* r4 = reinterpret_cast<float4*>(rec + (size_t)i * REC);
+        r4[0] = make_float4(u, v, A, B);
+        r4[1] = make_float4(C, s.o, s.c[0], s.c[1]);
+        r4[2] = make_float4(s.c[2], depth, cutoff, __int_as_float(rad));
+        float4* g4 = reinterpret_cast<float4*>(d_rec + (size_t)i * REC);
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        g4[0] = z; g4[1] = z; g4[2] = z;
+    }
+    __syncthreads();
+    int32_t* row = hist_g + (size_t)blockIdx.x * T;
+    for (int t = threadIdx.x; t < T; t += BIN_BLOCK) row[t] = hist[t];
+}
+
+// columns of hist -> exclusive per-block bases (in place); tile totals -> tile_offsets
+__global__ void __launch_bounds__(1024) bin_colscan_kernel(int32_t* __restrict__ hist_g, int nblk, int T,
+                                                          int32_t* __restrict__ tile_offsets) {
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < T; base += 1024) {
+        const int t = base + tid;
+        int run = 0;
+        if (t < T) {
+            for (int b = 0; b < nblk; ++b) {
+                const int cnt = hist_g[(size_t)b * T + t];
+                hist_g[(size_t)b * T + t] = run;
+                run += cnt;
+            }
+        }
+        int s = run;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int n = __shfl_up(s, off);
+            if (lane >= off) s += n;
+        }
+        if (lane == 63) wsum[wid] = s;
+        __syncthreads();
+        int wprefix = 0;
+        for (int w = 0; w < wid; ++w) wprefix += wsum[w];
+        const int carry = carry_s;
+        if (t < T) tile_offsets[t] = carry + wprefix + s - run;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + wprefix + s;
+        __syncthreads();
+    }
+    if (tid == 0) tile_offsets[T] = carry_s;
+}
+
+__global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* __restrict__ rec, int N, int gx, int gy,
+                                                                  const int32_t* __restrict__ hist_g,
+                                                                  const int32_t* __restrict__ tile_offsets, int K_cap,
+                                                                  unsigned long long* __restrict__ keys,
+                                                                  int32_t* __restrict__ overflow) {
+    extern __shared__ int32_t cursor[];
+    const int T = gx * gy;
+    const int32_t* base_row = hist_g + (size_t)blockIdx.x * T;
+    for (int t = threadIdx.x; t < T; t += BIN_BLOCK) cursor[t] = tile_offsets[t] + base_row[t];
+    __syncthreads();
+    const int i = blockIdx.x * BIN_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)i * REC);
+    const float4 p0 = r4[0], p2 = r4[2];
+    const int rad = __float_as_int(p2.w);
+    if (rad <= 0) return;
+    const float u = p0.x, v = p0.y, cutoff = p2.z;
+    int x0, x1, y0, y1;
+    tile_rect(u, v, rad, gx, gy, x0, x1, y0, y1);
+    const unsigned long long key = ((unsigned long long)__float_as_uint(p2.y) << 32) | (unsigned long long)(unsigned)i;
+    for (int ty = y0; ty < y1; ++ty)
+        for (int tx = x0; tx < x1; ++tx) {
+            if (!tile_hit2(u, v, cutoff, tx, ty)) continue;
+            const int pos = atomicAdd(&cursor[ty * gx + tx], 1);
+            if (pos < K_cap) keys[pos] = key;
+            else *overflow = 1;
+        }
+}
+
+// ------------------------------------------------------------------- blend (C = 4)
+constexpr int FB = 256;   // staged splats per batch
+
+struct RecLDS {
+    float4 p0, p1, p2;    // p2 = (b, depth, cutoff, radius bits)
+};
+
+__device__ __forceinline__ bool splat_alpha2(const float4& p0, const float4& p1, float fx, float fy, float& alpha,
+                                             float& G) {
+#pragma clang fp contract(off)
+    const float dx = p0.x - fx, dy = p0.y - fy;
+    const float q = __builtin_fmaf(p0.z * dx, dx, (p1.x * dy) * dy);
+    const float power = __builtin_fmaf(-0.5f, q, -((p0.w * dx) * dy));
+    if (power > 0.f) return false;
+    G = __expf(power);
+    alpha = fminf(GFL_ALPHA_MAX, p1.y * G);
+    return alpha >= GFL_ALPHA_MIN;
+}
+
+// which of the tile's four 8x8 pixel blocks the alpha>=1/255 disc of a splat reaches
+__device__ __forceinline__ unsigned block_mask(float u, float v, float cutoff, int px0, int py0) {
+    unsigned m = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float x_lo = (float)(px0 + (w & 1) * 8), x_hi = x_lo + 7.f;
+        const float y_lo = (float)(py0 + (w >> 1) * 8), y_hi = y_lo + 7.f;
+        const float ddx = fmaxf(fmaxf(x_lo - u, u - x_hi), 0.f);
+        const float ddy = fmaxf(fmaxf(y_lo - v, v - y_hi), 0.f);
+        if (ddx * ddx + ddy * ddy <= cutoff) m |= 1u << w;
+    }
+    return m;
+}
+
+__global__ void __launch_bounds__(256) fused_blend_fwd_kernel(const float* __restrict__ rec,
+                                                              const int32_t* __restrict__ ids,
+                                                              const int32_t* __restrict__ tile_range, float bg, int W,
+                                                              int H, int gx, float* __restrict__ out,
+                                                              float* __restrict__ final_T,
+                                                              int32_t* __restrict__ n_contrib) {
+    __shared__ RecLDS recs[FB];
+    __shared__ unsigned char s_mask[FB];
+    const int tile = blockIdx.x;
+    const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int px = tx * GFL_TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * GFL_TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float fx = (float)px, fy = (float)py;
+    const int start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
+
+    float T = 1.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int last = 0;
+    bool done = !inside;
+
+    for (int base = start; base < end; base += FB) {
+        if (__syncthreads_and(done)) break;
+        const int idx = base + tid;
+        if (idx < end) {
+            const int g = ids[idx];
+            const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g * REC);
+            const float4 p0 = r4[0], p1 = r4[1], p2 = r4[2];
+            recs[tid].p0 = p0; recs[tid].p1 = p1; recs[tid].p2 = p2;
+            s_mask[tid] = (unsigned char)block_mask(p0.x, p0.y, p2.z, tx * GFL_TILE, ty * GFL_TILE);
+        }
+        __syncthreads();
+        const int cnt = min(FB, end - base);
+        if (__all(done)) continue;      // this wave is finished; keep meeting the barriers
+        for (int c0 = 0; c0 < cnt; c0 += 64) {
+            const int slot = c0 + lane;
+            const bool hit = slot < cnt && ((s_mask[slot] >> wave) & 1);
+            unsigned long long bits = __ballot(hit);
+            while (bits) {
+                const int j = c0 + (int)__builtin_ctzll(bits);
+                bits &= bits - 1;
+                if (done) continue;
+                const float4 p0 = recs[j].p0;
+                const float4 p1 = recs[j].p1;
+                float alpha, G;
+                if (!splat_alpha2(p0, p1, fx, fy, alpha, G)) continue;
+                const float test_T = T * (1.f - alpha);
+                if (test_T < GFL_T_MIN) { done = true; continue; }
+                const float w = alpha * T;
+                const float4 p2 = recs[j].p2;
+                a0 = fmaf(p1.z, w, a0); a1 = fmaf(p1.w, w, a1); a2 = fmaf(p2.x, w, a2); a3 = fmaf(p2.y, w, a3);
+                T = test_T;
+                last = base - start + j + 1;
+            }
+        }
+    }
+    if (inside) {
+        const size_t pix = (size_t)py * W + px, plane = (size_t)H * W;
+        out[pix] = fmaf(T, bg, a0);
+        out[plane + pix] = fmaf(T, bg, a1);
+        out[2 * plane + pix] = fmaf(T, bg, a2);
+        out[3 * plane + pix] = fmaf(T, bg, a3);
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+    }
+}
+
+__global__ void __launch_bounds__(256) fused_blend_bwd_kernel(const float* __restrict__ rec,
+                                                              const int32_t* __restrict__ ids,
+                                                              const int32_t* __restrict__ tile_range, float bg, int W,
+                                                              int H, int gx, const float* __restrict__ final_T,
+                                                              const int32_t* __restrict__ n_contrib,
+                                                              const float* __restrict__ d_out,
+                                                              float* __restrict__ d_rec) {
+    __shared__ RecLDS recs[FB];
+    __shared__ int32_t rec_id[FB];
+    __shared__ unsigned char s_mask[FB];
+    __shared__ int32_t s_max_last;
+    const int tile = blockIdx.x;
+    const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int px = tx * GFL_TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * GFL_TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float fx = (float)px, fy = (float)py;
+    const int start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
+    const int total = end - start;
+
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, T = 1.f, S = 0.f;
+    int last = 0;
+    if (inside) {
+        const size_t pix = (size_t)py * W + px, plane = (size_t)H * W;
+        T = final_T[pix];
+        last = n_contrib[pix];
+        g0 = d_out[pix]; g1 = d_out[plane + pix]; g2 = d_out[2 * plane + pix]; g3 = d_out[3 * plane + pix];
+        S = T * bg * (g0 + g1 + g2 + g3);
+    }
+    if (tid == 0) s_max_last = 0;
+    __syncthreads();
+    int wave_last = last;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, off));
+    if (lane == 0) atomicMax(&s_max_last, wave_last);
+    __syncthreads();
+    const int depth_n = min(total, (int)s_max_last);
+
+    for (int r0 = 0; r0 < depth_n; r0 += FB) {
+        const int pos_t = depth_n - 1 - r0 - tid;     // slot tid <-> list position pos_t
+        __syncthreads();
+        if (pos_t >= 0) {
+            const int g = ids[start + pos_t];
+            const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g * REC);
+            const float4 p0 = r4[0], p1 = r4[1], p2 = r4[2];
+            recs[tid].p0 = p0; recs[tid].p1 = p1; recs[tid].p2 = p2;
+            rec_id[tid] = g;
+            s_mask[tid] = (unsigned char)block_mask(p0.x, p0.y, p2.z, tx * GFL_TILE, ty * GFL_TILE);
+        }
+        __syncthreads();
+        const int cnt = min(FB, depth_n - r0);
+        for (int c0 = 0; c0 < cnt; c0 += 64) {
+            const int slot = c0 + lane;
+            const int spos = depth_n - 1 - r0 - slot;
+            const bool hit = slot < cnt && spos < wave_last && ((s_mask[slot] >> wave) & 1);
+            unsigned long long bits = __ballot(hit);
+            while (bits) {
+                const int j = c0 + (int)__builtin_ctzll(bits);
+                bits &= bits - 1;
+                const int pos = depth_n - 1 - r0 - j;
+                const float4 p0 = recs[j].p0;
+                const float4 p1 = recs[j].p1;
+                float alpha = 0.f, G = 0.f;
+                const bool valid = (pos < last) && splat_alpha2(p0, p1, fx, fy, alpha, G);
+                if (__ballot(valid) == 0ull) continue;
+                float v_u = 0.f, v_v = 0.f, v_a = 0.f, v_b = 0.f, v_c = 0.f, v_o = 0.f;
+                float v_f0 = 0.f, v_f1 = 0.f, v_f2 = 0.f, v_f3 = 0.f;
+                if (valid) {
+                    const float4 p2 = recs[j].p2;
+                    const float om = 1.f - alpha;
+                    T = T / om;
+                    const float h = fmaf(g0, p1.z, fmaf(g1, p1.w, fmaf(g2, p2.x, g3 * p2.y)));
+                    const float dalpha = T * h - S / om;
+                    const float w = alpha * T;
+                    S = fmaf(h, w, S);
+                    v_f0 = w * g0; v_f1 = w * g1; v_f2 = w * g2; v_f3 = w * g3;
+                    const float dx = p0.x - fx, dy = p0.y - fy;
+                    v_o = G * dalpha;
+                    const float dpow = p1.y * G * dalpha;
+                    v_a = -0.5f * dx * dx * dpow;
+                    v_c = -0.5f * dy * dy * dpow;
+                    v_b = -dx * dy * dpow;
+                    v_u = -(p0.z * dx + p0.w * dy) * dpow;
+                    v_v = -(p1.x * dy + p0.w * dx) * dpow;
+                }
+                v_u = wave_sum_to_lane63(v_u); v_v = wave_sum_to_lane63(v_v);
+                v_a = wave_sum_to_lane63(v_a); v_b = wave_sum_to_lane63(v_b); v_c = wave_sum_to_lane63(v_c);
+                v_o = wave_sum_to_lane63(v_o);
+                v_f0 = wave_sum_to_lane63(v_f0); v_f1 = wave_sum_to_lane63(v_f1);
+                v_f2 = wave_sum_to_lane63(v_f2); v_f3 = wave_sum_to_lane63(v_f3);
+                if (lane == 63) {
+                    float* d = d_rec + (size_t)rec_id[j] * REC;
+                    atomicAdd(d + 0, v_u); atomicAdd(d + 1, v_v); atomicAdd(d + 2, v_a); atomicAdd(d + 3, v_b);
+                    atomicAdd(d + 4, v_c); atomicAdd(d + 5, v_o); atomicAdd(d + 6, v_f0); atomicAdd(d + 7, v_f1);
+                    atomicAdd(d + 8, v_f2); atomicAdd(d + 9, v_f3);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------- preprocess backward + Adam (A13)
+struct AdamCfg {
+    float lr, b1, b2, eps, lr_end_factor;
+    int total_iters;
+};
+
+__device__ __forceinline__ void adam_scalars(const AdamCfg& a, int e, float lr, float& step_size, float& inv_sqrt_bc2) {
+    const float t = (float)(e + 1);
+    if (a.total_iters > 0) lr *= 1.f + (a.lr_end_factor - 1.f) * (float)min(e, a.total_iters) / (float)a.total_iters;
+    step_size = lr / (1.f - powf(a.b1, t));
+    inv_sqrt_bc2 = 1.f / sqrtf(1.f - powf(a.b2, t));
+}
+
+__device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, const AdamCfg& a, float step_size,
+                                             float inv_sqrt_bc2) {
+    m = fmaf(a.b1, m, (1.f - a.b1) * g);
+    v = fmaf(a.b2, v, (1.f - a.b2) * g * g);
+    const float denom = sqrtf(v) * inv_sqrt_bc2 + a.eps;
+    return p - step_size * (m / denom);
+}
+
+struct RegCfg {                 // per-splat regularisers (trainer.py:490-530)
+    float lambda_var;           // lambda_var / N
+    float lambda_flow;          // lambda_flow (per-row weight in flow_w carries 1/(2 count))
+    float lambda_still;         // lambda_still (per-row weight in still_w carries 1/count)
+    int freeze_rgb;             // trainer.py:537-540
+    int freeze_all;             // camera_only, trainer.py:548-551
+};
+
+__global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel(
+    float* __restrict__ params, float* __restrict__ adam_m, float* __restrict__ adam_v, const float* __restrict__ intr,
+    const float* __restrict__ pose, const float* __restrict__ rec, const float* __restrict__ d_rec, int N, int W, int H,
+    const float* __restrict__ flow_target, const float* __restrict__ flow_w, const float* __restrict__ still_target,
+    const float* __restrict__ still_w, const uint8_t* __restrict__ row_flags, RegCfg rc, AdamCfg ac,
+    const int32_t* __restrict__ d_step, float* __restrict__ partial) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float e[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) e[k] = 0.f;
+    if (i < N) {
+        const Cam c = cam_from_pose(intr, pose);
+        const Splat s = load_splat(params, i);
+        const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)i * REC);
+        const float4 rp0 = r4[0], rp2 = r4[2];
+        const float4* g4 = reinterpret_cast<const float4*>(d_rec + (size_t)i * REC);
+        const float4 d0 = g4[0], d1 = g4[1], d2 = g4[2];   // du dv dA dB | dC do dr dg | db ddepth
+        float g[14];
+#pragma unroll
+        for (int k = 0; k < 14; ++k) g[k] = 0.f;
+        const bool vis = rp2.y != 0.f;                      // depth != 0  (render.py:29)
+        if (vis) {
+            float du = d0.x, dv = d0.y, dd = d2.y;
+            if (flow_w) {                                   // flow term acts on uv (trainer.py:520-528)
+                const float w = rc.lambda_flow * flow_w[i];
+                if (w != 0.f) {
+                    du += 2.f * w * (rp0.x - flow_target[2 * i]);
+                    dv += 2.f * w * (rp0.y - flow_target[2 * i + 1]);
+                }
+            }
+            const float px = c.r00 * s.x + c.r01 * s.y + c.r02 * s.z + c.t0;
+            const float py = c.r10 * s.x + c.r11 * s.y + c.r12 * s.z + c.t1;
+            const float pz = c.r20 * s.x + c.r21 * s.y + c.r22 * s.z + c.t2;
+            float gx_, gy_, gz_;
+            project_bwd_cam(c, px, py, pz, du, dv, dd, gx_, gy_, gz_);
+            if (__float_as_int(rp2.w) > 0) {                // radius > 0: the conic was produced
+                float cov[6];
+                cov3d_fwd(s.s, s.q, cov);
+                const Ewa f = ewa_fwd(c, px, py, pz, cov, W, H);
+                float gcov[6], ex, ey, ez;
+                ewa_bwd(c, f, px, py, cov, d0.z, d0.w, d1.x, gcov, ex, ey, ez, e);
+                gx_ += ex; gy_ += ey; gz_ += ez;
+                float ds[3], dq[4];
+                cov3d_bwd(s.s, s.q, gcov, ds, dq);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) g[3 + k] = ds[k];
+                // through F.normalize: q = raw / n
+                const float dot = s.q[0] * dq[0] + s.q[1] * dq[1] + s.q[2] * dq[2] + s.q[3] * dq[3];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[6 + k] = (dq[k] - s.q[k] * dot) / s.qn;
+            }
+            cam_grad_to_world(c, s.x, s.y, s.z, gx_, gy_, gz_, g[0], g[1], g[2], e);
+        }
+        // blended attributes: opacity = sigmoid(10 x), rgb = sigmoid(x)
+        g[10] = d1.y * 10.f * s.o * (1.f - s.o);
+        g[11] = d1.z * s.c[0] * (1.f - s.c[0]);
+        g[12] = d1.w * s.c[1] * (1.f - s.c[1]);
+        g[13] = d2.x * s.c[2] * (1.f - s.c[2]);
+        // scale: |x| backward, then the variance regulariser (trainer.py:490-493)
+        if (rc.lambda_var != 0.f) {
+            const float mean = (s.s[0] + s.s[1] + s.s[2]) * (1.f / 3.f);
+            const float var = 0.5f * ((s.s[0] - mean) * (s.s[0] - mean) + (s.s[1] - mean) * (s.s[1] - mean) +
+                                      (s.s[2] - mean) * (s.s[2] - mean));
+            const float sd = sqrtf(var);
+            if (sd != 0.f) {                                // torch masks the 0/0 of std's backward to 0
+#pragma unroll
+                for (int k = 0; k < 3; ++k) g[3 + k] += rc.lambda_var * (s.s[k] - mean) / (2.f * sd);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g[3 + k] *= (s.raw_s[k] > 0.f) ? 1.f : ((s.raw_s[k] < 0.f) ? -1.f : 0.f);
+        if (still_w) {                                      // trainer.py:505-509
+            const float w = rc.lambda_still * still_w[i];
+            if (w != 0.f) {
+                const float ax = s.x - still_target[3 * i], ay = s.y - still_target[3 * i + 1],
+                            az = s.z - still_target[3 * i + 2];
+                const float n = sqrtf(ax * ax + ay * ay + az * az);
+                if (n != 0.f) { g[0] += w * ax / n; g[1] += w * ay / n; g[2] += w * az / n; }
+            }
+        }
+        // gradient control (trainer.py:535-551)
+        if (rc.freeze_rgb) { g[11] = 0.f; g[12] = 0.f; g[13] = 0.f; }
+        if (row_flags && (row_flags[i] & 1)) { g[0] = 0.f; g[1] = 0.f; g[2] = 0.f; }
+        if (rc.freeze_all) {
+#pragma unroll
+            for (int k = 0; k < 14; ++k) g[k] = 0.f;
+        }
+        // Adam over the 64-byte row
+        float step_size, isb2;
+        adam_scalars(ac, *d_step, ac.lr, step_size, isb2);
+        float4* prow = reinterpret_cast<float4*>(params + (size_t)i * ROW);
+        float4* mrow = reinterpret_cast<float4*>(adam_m + (size_t)i * ROW);
+        float4* vrow = reinterpret_cast<float4*>(adam_v + (size_t)i * ROW);
+        float pv[16], mv[16], vv[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a = prow[q], b = mrow[q], d = vrow[q];
+            pv[4 * q] = a.x; pv[4 * q + 1] = a.y; pv[4 * q + 2] = a.z; pv[4 * q + 3] = a.w;
+            mv[4 * q] = b.x; mv[4 * q + 1] = b.y; mv[4 * q + 2] = b.z; mv[4 * q + 3] = b.w;
+            vv[4 * q] = d.x; vv[4 * q + 1] = d.y; vv[4 * q + 2] = d.z; vv[4 * q + 3] = d.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 14; ++k) pv[k] = adam_update(pv[k], g[k], mv[k], vv[k], ac, step_size, isb2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            prow[q] = make_float4(pv[4 * q], pv[4 * q + 1], pv[4 * q + 2], pv[4 * q + 3]);
+            mrow[q] = make_float4(mv[4 * q], mv[4 * q + 1], mv[4 * q + 2], mv[4 * q + 3]);
+            vrow[q] = make_float4(vv[4 * q], vv[4 * q + 1], vv[4 * q + 2], vv[4 * q + 3]);
+        }
+    }
+    block_reduce_store<12, REDUCE_BLOCK>(e, partial);
+}
+
+// camera + depth affine: fold the extr partials, chain to the pose, Adam, step += 1
+__global__ void __launch_bounds__(256) fused_camera_adam_kernel(const float* __restrict__ partial, int rows,
+                                                                float* __restrict__ pose, float* __restrict__ pose_m,
+                                                                float* __restrict__ pose_v, float* __restrict__ depth_ab,
+                                                                float* __restrict__ ab_m, float* __restrict__ ab_v,
+                                                                const float* __restrict__ sums, AdamCfg ac_cam,
+                                                                AdamCfg ac_ab, int step_camera, int32_t* __restrict__ d_step,
+                                                                float* __restrict__ d_extr_out) {
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) acc[k] += partial[(size_t)r * 12 + k];
+    }
+    __shared__ float red[4][12];
+    __shared__ float ge[12];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const float s = wave_sum_to_lane63(acc[k]);
+        if (lane == 63) red[wid][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        ge[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        d_extr_out[threadIdx.x] = ge[threadIdx.x];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int e = *d_step;
+        if (step_camera) {
+            // d_extr (rows R|t) -> d_pose; q = raw/|raw| in XYZW order
+            const float rx = pose[0], ry = pose[1], rz = pose[2], rw = pose[3];
+            const float n = sqrtf(rx * rx + ry * ry + rz * rz + rw * rw);
+            const float x = rx / n, y = ry / n, z = rz / n, w = rw / n;
+            const float* dR = ge;   // dR[i][j] = ge[4 i + j]
+            const float d00 = dR[0], d01 = dR[1], d02 = dR[2], d10 = dR[4], d11 = dR[5], d12 = dR[6], d20 = dR[8],
+                        d21 = dR[9], d22 = dR[10];
+            float dq[4];   // x y z w
+            dq[3] = 2.f * (-z * d01 + y * d02 + z * d10 - x * d12 - y * d20 + x * d21);
+            dq[0] = 2.f * (y * d01 + z * d02 + y * d10 - 2.f * x * d11 - w * d12 + z * d20 + w * d21 - 2.f * x * d22);
+            dq[1] = 2.f * (-2.f * y * d00 + x * d01 + w * d02 + x * d10 + z * d12 - w * d20 + z * d21 - 2.f * y * d22);
+            dq[2] = 2.f * (-2.f * z * d00 - w * d01 + x * d02 + w * d10 - 2.f * z * d11 + y * d12 + x * d20 + y * d21);
+            const float qh[4] = {x, y, z, w};
+            const float dot = qh[0] * dq[0] + qh[1] * dq[1] + qh[2] * dq[2] + qh[3] * dq[3];
+            float gp[7];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gp[k] = (dq[k] - qh[k] * dot) / n;
+            gp[4] = ge[3]; gp[5] = ge[7]; gp[6] = ge[11];
+            float ss, isb;
+            adam_scalars(ac_cam, e, ac_cam.lr, ss, isb);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) pose[k] = adam_update(pose[k], gp[k], pose_m[k], pose_v[k], ac_cam, ss, isb);
+            adam_scalars(ac_ab, e, ac_ab.lr, ss, isb);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) depth_ab[k] = adam_update(depth_ab[k], sums[3 + k], ab_m[k], ab_v[k], ac_ab, ss, isb);
+        }
+        *d_step = e + 1;
+    }
+}
+
+}  // namespace gfl
+
+using namespace gfl;
+
+extern "C" {
+
+static inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+// other translation units
+size_t gfl_loss_workspace_bytes(int W, int H);
+
+static inline int fit_nblk(int N) { return (N + BIN_BLOCK - 1) / BIN_BLOCK; }
+
+size_t gfl_fit_workspace_bytes(int cap, int K_cap, int W, int H) {
+    if (cap < 0 || K_cap < 0 || W <= 0 || H <= 0) return 0;
+    const size_t T = (size_t)((W + GFL_TILE - 1) / GFL_TILE) * ((H + GFL_TILE - 1) / GFL_TILE);
+    return up256((size_t)fit_nblk(cap > 0 ? cap : 1) * T * sizeof(int32_t))      // hist / bases
+           + up256((size_t)K_cap * sizeof(unsigned long long))                      // keys
+           + up256((size_t)reduce_rows(cap > 0 ? cap : 1) * 12 * sizeof(float))    // extr partials
+           + up256(gfl_loss_workspace_bytes(W, H)) + 256;
+}
+
+struct FitWs {
+    int32_t* hist;
+    unsigned long long* keys;
+    float* partial;
+    void* loss_ws;
+    size_t loss_ws_bytes;
+};
+
+static FitWs carve(const gfl_fit_state* st) {
+    const size_t T = (size_t)((st->W + GFL_TILE - 1) / GFL_TILE) * ((st->H + GFL_TILE - 1) / GFL_TILE);
+    char* p = (char*)st->workspace;
+    FitWs w;
+    w.hist = (int32_t*)p;
+    p += up256((size_t)fit_nblk(st->cap > 0 ? st->cap : 1) * T * sizeof(int32_t));
+    w.keys = (unsigned long long*)p;
+    p += up256((size_t)st->K_cap * sizeof(unsigned long long));
+    w.partial = (float*)p;
+    p += up256((size_t)reduce_rows(st->cap > 0 ? st->cap : 1) * 12 * sizeof(float));
+    w.loss_ws = p;
+    w.loss_ws_bytes = up256(gfl_loss_workspace_bytes(st->W, st->H));
+    return w;
+}
+
+static int fit_check(const gfl_fit_state* st, const gfl_fit_hyper* hp) {
+    if (!st || !hp) return GFL_ERR_INVALID;
+    if (st->N < 0 || st->N > st->cap || st->W <= 0 || st->H <= 0 || st->K_cap < 0) return GFL_ERR_INVALID;
+    if (!st->params || !st->rec || !st->d_rec || !st->pose || !st->intr || !st->extr || !st->render || !st->final_T ||
+        !st->n_contrib || !st->tile_offsets || !st->ids || !st->tile_range || !st->overflow || !st->workspace)
+        return GFL_ERR_INVALID;
+    if (st->workspace_bytes < gfl_fit_workspace_bytes(st->cap, st->K_cap, st->W, st->H)) return GFL_ERR_WORKSPACE;
+    return GFL_OK;
+}
+
+// kernels of gfl_bin.hip / gfl_loss.hip reused through their C entry points
+// (gfl_loss_fwd_bwd, gfl_tile_sort_only: declared in gflow_hip.h)
+
+int gfl_fit_forward(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream) {
+    int rc = fit_check(st, hp);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int gx = (st->W + GFL_TILE - 1) / GFL_TILE, gy = (st->H + GFL_TILE - 1) / GFL_TILE, T = gx * gy;
+    const FitWs w = carve(st);
+    const int nblk = fit_nblk(st->N > 0 ? st->N : 1);
+    const size_t lds = (size_t)T * sizeof(int32_t);
+    rc = check(hipMemsetAsync(st->overflow, 0, sizeof(int32_t), s));
+    if (rc) return rc;
+    if (lds > 64 * 1024) return GFL_ERR_INVALID;   // tile grid too large for the LDS histogram
+    {
+        StageScope p(ST_PREPROCESS, s);
+        fused_preprocess_fwd_kernel<<<nblk, BIN_BLOCK, lds, s>>>(st->params, st->intr, st->pose, st->N, st->W, st->H,
+                                                                hp->nearest, hp->extent, gx, gy, st->rec, st->d_rec,
+                                                                w.hist, st->extr);
+    }
+    {
+        StageScope p(ST_COLSCAN, s);
+        bin_colscan_kernel<<<1, 1024, 0, s>>>(w.hist, nblk, T, st->tile_offsets);
+    }
+    {
+        StageScope p(ST_SCATTER, s);
+        fused_scatter_kernel<<<nblk, BIN_BLOCK, lds, s>>>(st->rec, st->N, gx, gy, w.hist, st->tile_offsets, st->K_cap,
+                                                          w.keys, st->overflow);
+    }
+    {
+        StageScope p(ST_TILE_SORT, s);
+        rc = gfl_tile_sort_only(st->tile_offsets, T, st->K_cap, w.keys, st->ids, st->tile_range, stream);
+    }
+    if (rc) return rc;
+    {
+        StageScope p(ST_BLEND_FWD, s);
+        fused_blend_fwd_kernel<<<T, 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx, st->render,
+                                                 st->final_T, st->n_contrib);
+    }
+    return check_launch();
+}
+
+int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream) {
+    int rc = fit_check(st, hp);
+    if (rc) return rc;
+    if (!st->adam_m || !st->adam_v || !st->pose_m || !st->pose_v || !st->depth_ab || !st->depth_ab_m ||
+        !st->depth_ab_v || !st->step || !st->gt_rgb || !st->d_render || !st->err_px || !st->sums || !st->d_extr)
+        return GFL_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int gx = (st->W + GFL_TILE - 1) / GFL_TILE, gy = (st->H + GFL_TILE - 1) / GFL_TILE, T = gx * gy;
+    const FitWs w = carve(st);
+    {
+        StageScope p(ST_LOSS, s);
+        rc = gfl_loss_fwd_bwd(st->render, st->gt_rgb, st->gt_depth, st->keep, st->depth_ab, hp->lambda_rgb,
+                              hp->lambda_depth, st->W, st->H, st->d_render, st->err_px, st->sums, w.loss_ws,
+                              w.loss_ws_bytes, stream);
+    }
+    if (rc) return rc;
+    {
+        StageScope p(ST_BLEND_BWD, s);
+        fused_blend_bwd_kernel<<<T, 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx, st->final_T,
+                                                 st->n_contrib, st->d_render, st->d_rec);
+    }
+    const int rows = reduce_rows(st->N > 0 ? st->N : 1);
+    RegCfg rcfg;
+    rcfg.lambda_var = st->N > 0 ? hp->lambda_var / (float)st->N : 0.f;
+    rcfg.lambda_flow = hp->lambda_flow;
+    rcfg.lambda_still = hp->lambda_still;
+    rcfg.freeze_rgb = hp->freeze_rgb;
+    rcfg.freeze_all = hp->freeze_all_splats;
+    AdamCfg ac = {hp->lr, hp->beta1, hp->beta2, hp->eps, hp->lr_end_factor, hp->total_iters};
+    AdamCfg ac_cam = ac;
+    ac_cam.lr = hp->lr_camera;
+    {
+        StageScope p(ST_PRE_BWD_ADAM, s);
+        fused_preprocess_bwd_adam_kernel<<<rows, REDUCE_BLOCK, 0, s>>>(
+            st->params, st->adam_m, st->adam_v, st->intr, st->pose, st->rec, st->d_rec, st->N, st->W, st->H,
+            st->flow_target, st->flow_w, st->still_target, st->still_w, st->row_flags, rcfg, ac, st->step, w.partial);
+    }
+    {
+        StageScope p(ST_CAMERA, s);
+        fused_camera_adam_kernel<<<1, 256, 0, s>>>(w.partial, rows, st->pose, st->pose_m, st->pose_v, st->depth_ab,
+                                                   st->depth_ab_m, st->depth_ab_v, st->sums, ac_cam, ac, hp->step_camera,
+                                                   st->step, st->d_extr);
+    }
+    return check_launch();
+}
+
+int gfl_fit_iteration(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream) {
+    int rc = gfl_fit_forward(st, hp, stream);
+    if (rc) return rc;
+    return gfl_fit_backward_step(st, hp, stream);
+}
+
+}  // extern "C"

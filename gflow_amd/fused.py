@@ -1,0 +1,220 @@
+"""Fused fit engine: one library call per optimisation iteration.
+
+``FitEngine`` owns the capacity-based HBM buffers the fused kernels work on (packed
+64-byte parameter rows + Adam moments, per-splat render records, tile lists, image
+planes) and drives ``gfl_fit_forward`` / ``gfl_fit_backward_step`` /
+``gfl_fit_iteration`` (include/gflow_hip.h).  Nothing in an iteration touches the host:
+no allocation, no read-back, launch sizes depend on N, the tile grid and the image only,
+so a whole iteration can be captured in a hipGraph and replayed.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+ROW = 16
+REC = 12
+COLS = {"xyz": (0, 3), "scale": (3, 6), "rotate": (6, 10), "opacity": (10, 11), "rgb": (11, 14)}
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int32
+
+
+class FitState(ctypes.Structure):          # mirrors gfl_fit_state
+    _fields_ = [("N", _I), ("cap", _I), ("W", _I), ("H", _I), ("K_cap", _I), ("reserved", _I),
+                ("params", _P), ("adam_m", _P), ("adam_v", _P), ("rec", _P), ("d_rec", _P),
+                ("flow_target", _P), ("flow_w", _P), ("still_target", _P), ("still_w", _P), ("row_flags", _P),
+                ("pose", _P), ("pose_m", _P), ("pose_v", _P),
+                ("depth_ab", _P), ("depth_ab_m", _P), ("depth_ab_v", _P),
+                ("intr", _P), ("extr", _P), ("d_extr", _P), ("step", _P),
+                ("gt_rgb", _P), ("gt_depth", _P), ("keep", _P),
+                ("render", _P), ("final_T", _P), ("n_contrib", _P),
+                ("d_render", _P), ("err_px", _P), ("sums", _P),
+                ("tile_offsets", _P), ("ids", _P), ("tile_range", _P), ("overflow", _P),
+                ("workspace", _P), ("workspace_bytes", ctypes.c_size_t)]
+
+
+class FitHyper(ctypes.Structure):          # mirrors gfl_fit_hyper
+    _fields_ = [("bg", ctypes.c_float), ("nearest", ctypes.c_float), ("extent", ctypes.c_float),
+                ("lambda_rgb", ctypes.c_float), ("lambda_depth", ctypes.c_float), ("lambda_var", ctypes.c_float),
+                ("lambda_flow", ctypes.c_float), ("lambda_still", ctypes.c_float),
+                ("lr", ctypes.c_float), ("lr_camera", ctypes.c_float), ("beta1", ctypes.c_float),
+                ("beta2", ctypes.c_float), ("eps", ctypes.c_float), ("lr_end_factor", ctypes.c_float),
+                ("total_iters", _I), ("freeze_rgb", _I), ("freeze_all_splats", _I), ("step_camera", _I)]
+
+
+def _declare(lib):
+    if getattr(lib, "_fit_declared", False):
+        return
+    lib.gfl_fit_workspace_bytes.restype = ctypes.c_size_t
+    lib.gfl_fit_workspace_bytes.argtypes = [ctypes.c_int] * 4
+    for name in ("gfl_fit_forward", "gfl_fit_backward_step", "gfl_fit_iteration"):
+        fn = getattr(lib, name)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.POINTER(FitState), ctypes.POINTER(FitHyper), _P]
+    lib._fit_declared = True
+
+
+class FitEngine:
+    def __init__(self, W, H, capacity, device, K_cap=None, bg=0.0):
+        self.lib = L.load()
+        _declare(self.lib)
+        self.dev = torch.device(device)
+        if self.dev.type != "cuda":
+            raise RuntimeError("FitEngine needs a HIP device (there is no CPU path)")
+        self.W, self.H = int(W), int(H)
+        self.gx, self.gy = (self.W + 15) // 16, (self.H + 15) // 16
+        self.T = self.gx * self.gy
+        self.N = 0
+        self.hp = FitHyper(bg=bg, nearest=0.2, extent=1.3, lambda_rgb=1.0, lambda_depth=0.0, lambda_var=0.0,
+                           lambda_flow=0.0, lambda_still=0.0, lr=1e-2, lr_camera=0.0, beta1=0.9, beta2=0.999,
+                           eps=1e-8, lr_end_factor=0.1, total_iters=0, freeze_rgb=0, freeze_all_splats=0,
+                           step_camera=1)
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        i32 = dict(dtype=torch.int32, device=self.dev)
+        H_, W_ = self.H, self.W
+        self.pose = torch.tensor([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], **f32)
+        self.pose_m, self.pose_v = torch.zeros(7, **f32), torch.zeros(7, **f32)
+        self.depth_ab = torch.tensor([1.0, 0.0], **f32)
+        self.ab_m, self.ab_v = torch.zeros(2, **f32), torch.zeros(2, **f32)
+        self.intr = torch.zeros(4, **f32)
+        self.extr = torch.zeros(12, **f32)
+        self.d_extr = torch.zeros(12, **f32)
+        self.step = torch.zeros(1, **i32)
+        self.render = torch.zeros(4, H_, W_, **f32)
+        self.final_T = torch.zeros(H_, W_, **f32)
+        self.n_contrib = torch.zeros(H_, W_, **i32)
+        self.d_render = torch.zeros(4, H_, W_, **f32)
+        self.err_px = torch.zeros(H_, W_, **f32)
+        self.sums = torch.zeros(8, **f32)
+        self.tile_offsets = torch.zeros(self.T + 1, **i32)
+        self.tile_range = torch.zeros(self.T, 2, **i32)
+        self.overflow = torch.zeros(1, **i32)
+        self.gt_rgb = self.gt_depth = self.keep = None
+        self.flow_target = self.flow_w = self.still_target = self.still_w = self.row_flags = None
+        self.cap = 0
+        self.K_cap_req = K_cap
+        self._alloc(int(capacity))
+
+    # ------------------------------------------------------------------ storage
+    def _alloc(self, cap):
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        old = getattr(self, "params", None)
+        n = self.N
+        self.cap = cap
+        self.params = torch.zeros(cap, ROW, **f32)
+        self.adam_m = torch.zeros(cap, ROW, **f32)
+        self.adam_v = torch.zeros(cap, ROW, **f32)
+        self.rec = torch.zeros(cap, REC, **f32)
+        self.d_rec = torch.zeros(cap, REC, **f32)
+        if old is not None and n:
+            self.params[:n] = old[:n]
+        self.K_cap = int(self.K_cap_req) if self.K_cap_req else max(4_000_000, 48 * cap)
+        self.ids = torch.zeros(self.K_cap, dtype=torch.int32, device=self.dev)
+        nbytes = self.lib.gfl_fit_workspace_bytes(cap, self.K_cap, self.W, self.H)
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+        self._state = None
+
+    def ensure_capacity(self, n):
+        if n > self.cap:
+            self._alloc(max(n, 2 * self.cap))
+
+    def set_splats(self, attrs):
+        """attrs: dict xyz (N,3), scale (N,3), rotate (N,4), opacity (N,1), rgb (N,3) RAW values.
+        Copies them into the packed rows (moments are NOT touched)."""
+        n = attrs["xyz"].shape[0]
+        self.ensure_capacity(n)
+        self.N = n
+        for k, (a, b) in COLS.items():
+            self.params[:n, a:b] = attrs[k].detach().reshape(n, b - a).to(self.dev)
+        self.params[:n, 14:] = 0
+        self._state = None
+
+    def views(self):
+        """Live (N, k) views of the packed parameter rows."""
+        return {k: self.params[:self.N, a:b] for k, (a, b) in COLS.items()}
+
+    def reset_optimizer(self, splats=True, camera=True):
+        """Fresh Adam state (trainer.py:153 builds a new optimiser on every train call)."""
+        if splats:
+            self.adam_m.zero_()
+            self.adam_v.zero_()
+        if camera:
+            self.pose_m.zero_(); self.pose_v.zero_(); self.ab_m.zero_(); self.ab_v.zero_()
+        self.step.zero_()
+
+    def set_targets(self, gt_image, gt_depth=None, keep=None):
+        self.gt_rgb = gt_image.to(self.dev).float().contiguous()
+        self.gt_depth = None if gt_depth is None else gt_depth.to(self.dev).float().reshape(self.H, self.W).contiguous()
+        self.keep = None if keep is None else keep.to(self.dev).reshape(self.H, self.W).to(torch.uint8).contiguous()
+        self._state = None
+
+    def set_regularisers(self, flow_target=None, flow_w=None, still_target=None, still_w=None, row_flags=None):
+        def pad(t, width, dtype):
+            if t is None:
+                return None
+            out = torch.zeros((self.cap, width) if width else (self.cap,), dtype=dtype, device=self.dev)
+            out[:t.shape[0]] = t.to(self.dev).reshape((t.shape[0], width) if width else (t.shape[0],))
+            return out
+        self.flow_target, self.flow_w = pad(flow_target, 2, torch.float32), pad(flow_w, 0, torch.float32)
+        self.still_target, self.still_w = pad(still_target, 3, torch.float32), pad(still_w, 0, torch.float32)
+        self.row_flags = pad(row_flags, 0, torch.uint8)
+        self._state = None
+
+    # ------------------------------------------------------------------- struct
+    def state(self):
+        if self._state is None:
+            p = L.ptr
+            s = FitState()
+            s.N, s.cap, s.W, s.H, s.K_cap = self.N, self.cap, self.W, self.H, self.K_cap
+            for name, t in (("params", self.params), ("adam_m", self.adam_m), ("adam_v", self.adam_v),
+                            ("rec", self.rec), ("d_rec", self.d_rec), ("flow_target", self.flow_target),
+                            ("flow_w", self.flow_w), ("still_target", self.still_target), ("still_w", self.still_w),
+                            ("row_flags", self.row_flags), ("pose", self.pose), ("pose_m", self.pose_m),
+                            ("pose_v", self.pose_v), ("depth_ab", self.depth_ab), ("depth_ab_m", self.ab_m),
+                            ("depth_ab_v", self.ab_v), ("intr", self.intr), ("extr", self.extr),
+                            ("d_extr", self.d_extr), ("step", self.step), ("gt_rgb", self.gt_rgb),
+                            ("gt_depth", self.gt_depth), ("keep", self.keep), ("render", self.render),
+                            ("final_T", self.final_T), ("n_contrib", self.n_contrib), ("d_render", self.d_render),
+                            ("err_px", self.err_px), ("sums", self.sums), ("tile_offsets", self.tile_offsets),
+                            ("ids", self.ids), ("tile_range", self.tile_range), ("overflow", self.overflow),
+                            ("workspace", self.workspace)):
+                setattr(s, name, None if t is None else t.data_ptr())
+            s.workspace_bytes = self.workspace.numel()
+            self._state = s
+        return self._state
+
+    # -------------------------------------------------------------------- calls
+    def forward(self):
+        L.check(self.lib.gfl_fit_forward(ctypes.byref(self.state()), ctypes.byref(self.hp), L.stream()), "fit forward")
+
+    def backward_step(self):
+        L.check(self.lib.gfl_fit_backward_step(ctypes.byref(self.state()), ctypes.byref(self.hp), L.stream()),
+                "fit backward/step")
+
+    def iteration(self):
+        L.check(self.lib.gfl_fit_iteration(ctypes.byref(self.state()), ctypes.byref(self.hp), L.stream()),
+                "fit iteration")
+
+    # ------------------------------------------------------------------ outputs
+    @property
+    def uv(self):
+        return self.rec[:self.N, 0:2]
+
+    @property
+    def depth(self):
+        return self.rec[:self.N, 9:10]
+
+    @property
+    def K(self):
+        return int(self.tile_offsets[self.T].item())
+
+    def check_overflow(self):
+        if int(self.overflow.item()):
+            raise RuntimeError(f"FitEngine: more than K_cap={self.K_cap} splat-tile pairs; raise K_cap")
+
+    def loss_terms(self):
+        """(loss_rgb, loss_depth) of the last backward_step as device scalars (trainer.py:460-462,485)."""
+        hw = float(self.H * self.W)
+        return self.sums[0] / hw + (1.0 - self.sums[1] / (3.0 * hw)), self.sums[2] / hw

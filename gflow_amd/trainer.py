@@ -76,7 +76,12 @@ def _within(uv, W, H):
 
 class SimpleGaussian:
     def __init__(self, gt_image, gt_depth=None, gt_flow=None, num_points=100000, background="black",
-                 device=None, log_dir=None, seed=None):
+                 device=None, log_dir=None, seed=None, fused=True):
+        """``fused=True`` (default) runs each iteration as one call into the native library
+        (gflow_amd/fused.py); ``fused=False`` composes the msplat-compatible autograd operators
+        the way the reference does (slower, same results)."""
+        self.fused = bool(fused)
+        self.engine = None
         self.device = torch.device(device if device is not None else "cuda")
         if self.device.type != "cuda":
             raise RuntimeError("gflow_amd.trainer needs a HIP device (there is no CPU rasteriser)")
@@ -249,6 +254,15 @@ class SimpleGaussian:
             xyz[:n_last] = torch.where(inside.unsqueeze(1), xyz_new, xyz[:n_last])
             self._attributes["xyz"] = xyz
 
+        if self.fused and not lambda_scale:
+            return self._make_fused_stepper(
+                iterations=iterations, lr=lr, lr_camera=lr_camera, lambda_rgb=lambda_rgb, lambda_depth=lambda_depth,
+                lambda_flow=lambda_flow, lambda_var=lambda_var, lambda_still=lambda_still, move_mask=move_mask,
+                densify_interval=densify_interval, densify_times=densify_times, mask=mask, camera_only=camera_only,
+                densify_occ_percent=densify_occ_percent, densify_err_thre=densify_err_thre,
+                densify_err_percent=densify_err_percent, snapshot_interval=snapshot_interval,
+                log_interval=log_interval)
+
         self.add_optimizer(lr, lr_camera, depth_invariant=True)
         self.scheduler = LinearLR(self.optimizer, start_factor=1.0, end_factor=0.1, total_iters=iterations)
         later_frame = hasattr(self, "last_xyz")
@@ -349,6 +363,162 @@ class SimpleGaussian:
         st.fn = one_iteration
         return st
 
+    # ------------------------------------------------------- fused (native) path
+    def _engine_for(self, n):
+        from .fused import FitEngine
+        if self.engine is None:
+            self.engine = FitEngine(self.W, self.H, max(8 * int(self.num_points), 2 * n, 65536), self.device, bg=self.bg)
+        self.engine.ensure_capacity(n)
+        return self.engine
+
+    def _pack_to_engine(self):
+        """Copy the attribute tensors into the engine's packed rows and re-point
+        ``_attributes`` at live views of them."""
+        eng = self._engine_for(self.current_pts_num())
+        eng.set_splats(self._attributes)
+        self._attributes = eng.views()
+        return eng
+
+    def _make_fused_stepper(self, iterations, lr, lr_camera, lambda_rgb, lambda_depth, lambda_flow, lambda_var,
+                            lambda_still, move_mask, densify_interval, densify_times, mask, camera_only,
+                            densify_occ_percent, densify_err_thre, densify_err_percent, snapshot_interval,
+                            log_interval):
+        """Same iteration as ``make_stepper`` but every step is ONE call into
+        libgflow_hip (gfl_fit_iteration): no autograd graph, no torch kernels, no host sync."""
+        W, H, dev = self.W, self.H, self.device
+        self.lr, self.lr_camera = lr, lr_camera
+        eng = self._pack_to_engine()
+        eng.pose.copy_(self.pose.detach())
+        self.pose = eng.pose                       # live: get_extr() follows the optimised pose
+        eng.depth_ab.copy_(torch.tensor([1.0, 0.0], device=dev))     # trainer.py:145-146: reset every train()
+        self.depth_ab = eng.depth_ab
+        eng.intr.copy_(self.intr)
+        eng.reset_optimizer()
+        later_frame = hasattr(self, "last_xyz")
+        has_still = hasattr(self, "still_mask")
+        n = eng.N
+        hp = eng.hp
+        hp.bg = self.bg
+        hp.lambda_rgb = lambda_rgb if lambda_rgb > 0 else 0.0
+        hp.lambda_depth = lambda_depth if lambda_depth > 0 else 0.0
+        hp.lambda_var, hp.lr, hp.lr_camera = lambda_var, lr, lr_camera
+        hp.lr_end_factor, hp.total_iters = 0.1, iterations          # LinearLR(1.0 -> 0.1), trainer.py:384
+        hp.freeze_rgb = 1 if later_frame else 0
+        hp.freeze_all_splats = 1 if camera_only else 0
+        hp.step_camera = 1
+        hp.lambda_flow = hp.lambda_still = 0.0
+        flow_target = flow_w = still_target = still_w = row_flags = None
+        if has_still:
+            row_flags = torch.zeros(n, dtype=torch.uint8, device=dev)
+            row_flags[:self.still_mask.shape[0]] = self.still_mask.to(torch.uint8)       # trainer.py:543-546
+        if lambda_still and has_still:
+            m = self.last_still_mask
+            still_target = torch.zeros(n, 3, device=dev)
+            still_target[:m.shape[0]] = self.last_xyz[:m.shape[0]]
+            still_w = torch.zeros(n, device=dev)
+            still_w[:m.shape[0]] = m.float() / m.sum()
+            hp.lambda_still = lambda_still
+        if lambda_flow and self.gt_flow is not None and hasattr(self, "last_uv"):
+            and_mask = _within(self.last_uv, W, H)
+            if has_still:
+                ns = self.still_mask.shape[0]
+                and_mask = and_mask.clone()
+                and_mask[:ns] = (self.still_mask if camera_only else ~self.still_mask) & and_mask[:ns]
+            yx = self.last_uv.long()
+            gt_f = self.gt_flow[yx[:, 1].clamp(0, H - 1), yx[:, 0].clamp(0, W - 1)]
+            flow_target = torch.zeros(n, 2, device=dev)
+            flow_target[:self.last_num] = self.last_uv + gt_f
+            flow_w = torch.zeros(n, device=dev)
+            flow_w[:self.last_num] = and_mask.float() / (2.0 * and_mask.sum())
+            hp.lambda_flow = lambda_flow
+        eng.set_regularisers(flow_target, flow_w, still_target, still_w, row_flags)
+        eng.set_targets(self.gt_image, self.gt_depth if lambda_depth > 0 else None,
+                        (~move_mask) if (camera_only and move_mask is not None) else None)
+
+        st = _Stepper()
+        st.frames, st.frames_depth, st.frames_center, st.log = [], [], [], []
+        st.iteration = 0
+        st.move_mask, st.camera_only = move_mask, camera_only
+        tentative = hasattr(self, "still_mask_tentative") and camera_only
+
+        def extras_from_engine():
+            """depth_map_color and center snapshots from the engine's records (render.py:76-106)."""
+            rec = eng.rec[:eng.N]
+            uv, conic = rec[:, 0:2].contiguous(), rec[:, 2:5].contiguous()
+            op, rgb, depth = rec[:, 5:6].contiguous(), rec[:, 6:9].contiguous(), rec[:, 9:10].contiguous()
+            dc = render_mod.apply_float_colormap(depth, "turbo", non_zero=True)
+            depth_color = msplat.alpha_blending(uv, conic, op, dc, eng.ids, eng.tile_range, self.bg, W, H)
+            unit = torch.tensor([1.0, 0.0, 1.0], device=dev)
+            center = msplat.alpha_blending(uv, torch.ones_like(conic) * unit, torch.ones_like(op), rgb, eng.ids,
+                                           eng.tile_range, self.bg, W, H)
+            return depth_color, center
+
+        def one_iteration():
+            iteration = st.iteration
+            snap = bool(snapshot_interval) and iteration % snapshot_interval == 0
+            if tentative:
+                # moving-splat footprint joins the move mask (trainer.py:427-451)
+                with torch.no_grad():
+                    grp = self._input_group(sel=~self.still_mask_tentative, detach=True)
+                    mrgb = render_mod.render_multiple(grp, ["rgb"])["rgb"]
+                    self.rasterisations_done += 1
+                    grey = 0.299 * mrgb[0] + 0.587 * mrgb[1] + 0.114 * mrgb[2]
+                    mm = (grey > 0.0) | move_mask
+                st.move_mask = mm
+                eng.keep.copy_((~mm).to(torch.uint8))
+            eng.forward()
+            self.rasterisations_done += 1
+            if snap:
+                with torch.no_grad():
+                    extras = extras_from_engine()
+                st.frames.append(render_mod.render2img(eng.render[:3]))
+                st.frames_depth.append(render_mod.render2img(extras[0]))
+                st.frames_center.append(render_mod.render2img(extras[1]))
+            eng.backward_step()
+            self.iterations_done += 1
+            if log_interval and iteration % log_interval == 0:
+                l_rgb, l_depth = eng.loss_terms()
+                total = hp.lambda_rgb * l_rgb + hp.lambda_depth * l_depth
+                entry = {"rgb": float(l_rgb), "depth": float(l_depth), "it": iteration}
+                if lambda_var:
+                    entry["var"] = float(losses.var_loss(torch.abs(eng.views()["scale"])))
+                    total = total + lambda_var * entry["var"]
+                entry["total"] = float(total)
+                st.log.append(entry)
+
+            # ---- densification (trainer.py:560-571)
+            densified = False
+            if not camera_only and iteration == 0 and later_frame and mask is not None:
+                if mask.sum() > 0:
+                    self.densify_by_pixels(torch.ones_like(eng.err_px), error_threshold=0.0,
+                                           percent=densify_occ_percent, mask=mask)
+                    densified = True
+            if (not camera_only and densify_interval and (iteration + 1) % densify_interval == 0
+                    and (iteration + 1) // densify_interval <= densify_times):
+                self.densify_by_pixels(eng.err_px, error_threshold=densify_err_thre, percent=densify_err_percent,
+                                       mask=None)
+                densified = True
+            st.uv, st.depth, st.last_render = eng.uv, eng.depth, eng.render
+            if densified:
+                # trainer.py:941-951: the optimiser is replaced by Adam(attributes, lr): moments and
+                # step restart, lr stays constant, pose / depth affine are no longer stepped
+                st.uv, st.depth = eng.uv.clone(), eng.depth.clone()
+                self._pack_to_engine()
+                eng.reset_optimizer(splats=True, camera=False)
+                hp.total_iters = 0
+                hp.step_camera = 0
+                rf = None
+                if has_still:
+                    rf = torch.zeros(eng.N, dtype=torch.uint8, device=dev)
+                    rf[:self.still_mask.shape[0]] = self.still_mask.to(torch.uint8)
+                grow = lambda t, w: None if t is None else torch.cat(
+                    [t[:n], torch.zeros((eng.N - n, w) if w else (eng.N - n,), device=dev, dtype=t.dtype)])
+                eng.set_regularisers(grow(flow_target, 2), grow(flow_w, 0), grow(still_target, 3), grow(still_w, 0), rf)
+            st.iteration += 1
+
+        st.fn = one_iteration
+        return st
+
     def train(self, iterations=500, save_ckpt=False, ckpt_name="ckpt", snapshot_interval=10, **kw):
         """One call = the optimisation of one frame (trainer.py:332-711); keyword arguments
         as ``make_stepper``.  Returns (frames, frames_center, frames_depth, still_rgb,
@@ -364,7 +534,7 @@ class SimpleGaussian:
             move_mask = move_mask.to(dev).bool()
 
         # ---- post-update (trainer.py:588-625)
-        uv_d, depth_d = st.uv, st.depth
+        uv_d, depth_d = st.uv.clone(), st.depth.clone()
         if not camera_only:
             within = _within(uv_d, W, H)
             yx = uv_d.long()
@@ -390,7 +560,7 @@ class SimpleGaussian:
                 o = render_mod.render_multiple(self._input_group(sel=~self.still_mask, detach=True), ["rgb", "center"])
                 move_rgb, move_center = render_mod.render2img(o["rgb"]), render_mod.render2img(o["center"])
                 self.rasterisations_done += 2
-        self.last_render = st.last_render
+        self.last_render = st.last_render.clone()
         if save_ckpt:
             self.save_checkpoint(ckpt_name=ckpt_name)
         return st.frames, st.frames_center, st.frames_depth, still_rgb, still_center, move_rgb, move_center, self.move_seg

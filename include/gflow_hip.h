@@ -154,6 +154,74 @@ int gfl_adam_step(float* param, const float* grad, float* m, float* v, int64_t n
                   const int32_t* d_step, float lr_end_factor, int total_iters, gfl_stream_t stream);
 int gfl_step_increment(int32_t* d_step, gfl_stream_t stream);
 
+/* ---- Fused fit iteration  (trainer.py:387-558 in one call) ----------------------
+ * Everything the iteration loop does between "build input_group" (trainer.py:390)
+ * and "scheduler.step()" (trainer.py:555): activations, render_multiple(["rgb","uv",
+ * "depth","depth_map"]), the rgb/SSIM/depth/var/flow/still losses, backward, gradient
+ * masking, Adam for the splats, the camera pose and the depth affine pair.
+ * Plain structs of device pointers and sizes; the host owns every buffer.
+ *   params/adam_m/adam_v [cap][16] f32 rows: x y z | sx sy sz | qw qx qy qz | opacity |
+ *                         r g b | pad pad   (raw, pre-activation values, trainer.py:79-86)
+ *   rec   [cap][12]: u v A B | C opacity r g | b depth cutoff radius   (outputs: uv =
+ *                    rec[:,0:2], depth = rec[:,9], what render.py:21-49 returns)
+ *   d_rec [cap][12]: dL/d(rec[:,0:10])
+ * Optional per-splat inputs (NULL = term absent): flow_target[cap][2] + flow_w[cap]
+ * (weight = mask/(2 count), trainer.py:511-528), still_target[cap][3] + still_w[cap]
+ * (weight = mask/count, trainer.py:505-509), row_flags[cap] (bit0: xyz gradient
+ * frozen, trainer.py:543-546). */
+typedef struct gfl_fit_state {
+    int32_t N, cap, W, H, K_cap, reserved;
+    float *params, *adam_m, *adam_v;
+    float *rec, *d_rec;
+    const float *flow_target, *flow_w, *still_target, *still_w;
+    const uint8_t* row_flags;
+    float *pose, *pose_m, *pose_v;             /* [7] qx qy qz qw tx ty tz (trainer.py:41) */
+    float *depth_ab, *depth_ab_m, *depth_ab_v; /* [2] (trainer.py:145-146) */
+    const float* intr;                          /* [4] */
+    float* extr;                                /* [12] out: world->camera used this iteration */
+    float* d_extr;                              /* [12] out: dL/d extr */
+    int32_t* step;                              /* device step counter (Adam t-1, LinearLR epoch) */
+    const float* gt_rgb;                        /* [H][W][3] */
+    const float* gt_depth;                      /* [H][W] or NULL */
+    const uint8_t* keep;                        /* [H][W] or NULL (0 = masked-out pixel) */
+    float *render, *final_T;                    /* [4][H][W], [H][W] */
+    int32_t* n_contrib;                         /* [H][W] */
+    float *d_render, *err_px, *sums;            /* [4][H][W], [H][W], [8] as gfl_loss_fwd_bwd */
+    int32_t *tile_offsets, *ids, *tile_range, *overflow; /* [T+1], [K_cap], [T][2], [1] */
+    void* workspace;
+    size_t workspace_bytes;                     /* >= gfl_fit_workspace_bytes() */
+} gfl_fit_state;
+
+typedef struct gfl_fit_hyper {
+    float bg, nearest, extent;
+    float lambda_rgb, lambda_depth, lambda_var, lambda_flow, lambda_still;
+    float lr, lr_camera, beta1, beta2, eps, lr_end_factor;
+    int32_t total_iters;       /* LinearLR total_iters, 0 = constant lr */
+    int32_t freeze_rgb;        /* trainer.py:537-540 */
+    int32_t freeze_all_splats; /* camera_only, trainer.py:548-551 */
+    int32_t step_camera;       /* 0 after densification replaced the optimiser (trainer.py:951) */
+} gfl_fit_hyper;
+
+size_t gfl_fit_workspace_bytes(int cap, int K_cap, int W, int H);
+/* render only: fills rec, ids, tile_range, render, final_T, n_contrib, extr */
+int gfl_fit_forward(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream);
+/* loss + backward + optimiser step on the state gfl_fit_forward left behind */
+int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream);
+int gfl_fit_iteration(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream);
+/* the per-tile sort of gfl_bin_sort alone (keys already scattered into segments) */
+int gfl_tile_sort_only(const int32_t* tile_offsets, int T, int K_cap, void* keys, int32_t* ids,
+                       int32_t* tile_range, gfl_stream_t stream);
+
+/* ---- optional per-stage timing of the fused iteration ---------------------------
+ * HIP events are recorded on the launch stream around the stages whose bit is set in
+ * stage_mask: 0 preprocess, 1 colscan, 2 scatter, 3 tile sort, 4 blend forward, 5 loss,
+ * 6 blend backward, 7 preprocess-backward + Adam, 8 camera/affine Adam.
+ * gfl_profile_read synchronises on the recorded events, fills total_ms[9] / counts[9]
+ * and clears the records. */
+#define GFL_PROFILE_STAGES 9
+int gfl_profile_enable(unsigned stage_mask);
+int gfl_profile_read(double* total_ms, int* counts, int n_stages);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,231 @@
+"""Parity of the fused fit iteration (gfl_fit_forward / gfl_fit_backward_step through
+gflow_amd.fused.FitEngine) against the CPU oracle's fit step and against the
+operator-by-operator path (``-m gpu``).
+
+Gradients of the fused path are read back from Adam's first moment after ONE step from
+a zero state: m = (1 - beta1) * g exactly, so g = m / 0.1.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fit_oracle as FO
+from oracle import loss_oracle as LO
+from oracle import msplat_oracle as MO
+from tests.scenes import random_scene
+from tests.test_gpu_parity import close_frac
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _raw_from_scene(s):
+    """Raw (pre-activation) parameters whose activations reproduce the scene."""
+    return dict(xyz=s["xyz"], scale=s["scale"] * torch.where(torch.rand_like(s["scale"]) > 0.3, 1.0, -1.0),
+                rotate=s["rotate"] * 1.7, opacity=torch.logit(s["opacity"].clamp(0.02, 0.98)) / 10.0,
+                rgb=torch.logit(s["rgb"].clamp(0.02, 0.98)))
+
+
+def _targets(H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand(H, W, 3, generator=g)
+    dep = 1.0 + 3.0 * torch.rand(H, W, 1, generator=g)
+    return img, dep
+
+
+def _engine(raw, s, img, dep, pose=None, **hyper):
+    from gflow_amd.fused import FitEngine
+    eng = FitEngine(s["W"], s["H"], capacity=max(2 * raw["xyz"].shape[0], 1024), device=DEV, bg=hyper.pop("bg", 0.0))
+    eng.set_splats({k: v.to(DEV) for k, v in raw.items()})
+    eng.intr.copy_(s["intr"].to(DEV))
+    if pose is not None:
+        eng.pose.copy_(pose.to(DEV))
+    eng.set_targets(img, dep if hyper.get("lambda_depth", 0) > 0 else None)
+    for k, v in hyper.items():
+        setattr(eng.hp, k, v)
+    eng.reset_optimizer()
+    return eng
+
+
+POSE = torch.tensor([0.02, -0.03, 0.01, 0.99, 0.05, -0.02, 0.08])
+
+
+@pytest.fixture(scope="module")
+def setup():
+    s = random_scene(2500, 168, 120, seed=31, sigma_px=2.5, tilt=False)
+    raw = _raw_from_scene(s)
+    img, dep = _targets(s["H"], s["W"], 5)
+    return s, raw, img, dep
+
+
+def test_fused_forward_matches_oracle_and_operator_path(setup):
+    import gflow_amd.render as R
+    s, raw, img, dep = setup
+    eng = _engine(raw, s, img, dep, pose=POSE, bg=0.2)
+    eng.forward()
+    eng.check_overflow()
+    act = FO.activate(raw)
+    extr = LO.pose_to_extr(POSE)
+    oc = MO.render_multiple([*act, s["intr"], extr, 0.2, s["W"], s["H"]], ["rgb", "depth_map", "uv", "depth"])
+    ref4 = torch.cat([oc["rgb"], oc["depth_map"]])
+    close_frac(eng.render, ref4, 1e-4, 1e-5, bad_frac=3e-4, hard=2e-2, what="fused render vs oracle")
+    close_frac(eng.uv, oc["uv"], 1e-5, 1e-3, what="uv")
+    close_frac(eng.depth, oc["depth"], 1e-6, 1e-6, what="depth")
+    np.testing.assert_allclose(eng.extr.cpu().numpy().reshape(3, 4), extr.numpy(), atol=1e-6)
+    # operator-by-operator HIP path on the same inputs
+    og = R.render_multiple([*[a.to(DEV) for a in act], s["intr"].to(DEV), extr.to(DEV), 0.2, s["W"], s["H"]],
+                           ["rgb", "depth_map"])
+    api4 = torch.cat([og["rgb"], og["depth_map"]])
+    close_frac(eng.render, api4, 2e-5, 2e-6, bad_frac=1e-4, hard=2e-2, what="fused vs operator path")
+    # the exact-disc culling only ever drops pairs: K_fused <= K_api, same image
+    vis = oc["depth"] != 0
+    tiles = MO.ewa_project(act[0], MO.compute_cov3d(act[1], act[2], vis), s["intr"], extr, oc["uv"], s["W"], s["H"],
+                           vis)[2]
+    assert 0 < eng.K <= int(tiles.sum())
+    # determinism
+    r1 = eng.render.clone()
+    ids1 = eng.ids[:eng.K].clone()
+    eng.forward()
+    assert torch.equal(r1, eng.render) and torch.equal(ids1, eng.ids[:eng.K])
+
+
+def test_fused_gradients_match_oracle(setup):
+    s, raw, img, dep = setup
+    lam = dict(lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0)
+    eng = _engine(raw, s, img, dep, pose=POSE, lr=1e-3, lr_camera=1e-3, total_iters=100, **lam)
+    eng.iteration()
+    eng.check_overflow()
+    # oracle
+    rc = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
+    pose = POSE.clone().requires_grad_(True)
+    ab = torch.tensor([1.0, 0.0], requires_grad=True)
+    frame = dict(image=img, depth=dep)
+    loss, info = FO.fit_loss(rc, pose, ab, s["intr"], frame, 0.0, lam["lambda_rgb"], lam["lambda_depth"], lam["lambda_var"])
+    loss.backward()
+    l_rgb, l_depth = eng.loss_terms()
+    assert abs(l_rgb.item() - info["l_rgb"].item()) <= 1e-4 * abs(info["l_rgb"].item())
+    assert abs(l_depth.item() - info["l_depth"].item()) <= 1e-4 * abs(info["l_depth"].item())
+    from gflow_amd.fused import COLS
+    n = raw["xyz"].shape[0]
+    g_all = eng.adam_m[:n] / (1.0 - 0.9)
+    for k, (a, b) in COLS.items():
+        ref = rc[k].grad.reshape(n, b - a)
+        got = g_all[:, a:b].cpu()
+        rel = (got - ref).norm() / ref.norm()
+        assert rel < 2e-3, f"d_{k}: relative L2 error {rel:.2e}"
+        close_frac(got, ref, 5e-3, 5e-4 * ref.abs().max().item(), bad_frac=1e-2, what=f"d_{k}")
+    gp = (eng.pose_m / 0.1).cpu()
+    rel = (gp - pose.grad).norm() / pose.grad.norm()
+    assert rel < 2e-3, f"d_pose: relative L2 error {rel:.2e}  {gp} vs {pose.grad}"
+    gab = (eng.ab_m / 0.1).cpu()
+    np.testing.assert_allclose(gab.numpy(), ab.grad.numpy(), rtol=2e-3)
+    assert int(eng.step.item()) == 1
+
+
+def test_fused_adam_update_matches_torch_adam(setup):
+    """Given the fused path's own gradients, the parameter update equals torch.optim.Adam
+    + LinearLR (trainer.py:153,384) over several steps."""
+    s, raw, img, dep = setup
+    eng = _engine(raw, s, img, dep, pose=POSE, lr=4e-3, lr_camera=1e-3, total_iters=4, lambda_rgb=1.0,
+                  lambda_depth=0.1, lambda_var=10.0)
+    n = raw["xyz"].shape[0]
+    p = eng.params[:n, :14].clone().cpu().requires_grad_(True)
+    ref = torch.optim.Adam([p], lr=4e-3)
+    sch = torch.optim.lr_scheduler.LinearLR(ref, start_factor=1.0, end_factor=0.1, total_iters=4)
+    for it in range(6):
+        m_before = eng.adam_m[:n, :14].clone()
+        eng.iteration()
+        g = ((eng.adam_m[:n, :14] - 0.9 * m_before) / 0.1).cpu()        # the gradient this step used
+        p.grad = g
+        ref.step(); sch.step()
+    err = (eng.params[:n, :14].cpu() - p.detach()).abs().max().item()
+    assert err < 5e-5, f"Adam trajectories diverge by {err:.2e}"
+
+
+def test_fused_regularisers_and_masks(setup):
+    """flow / still terms and the gradient-control flags (trainer.py:505-551)."""
+    s, raw, img, dep = setup
+    n = raw["xyz"].shape[0]
+    g = torch.Generator().manual_seed(9)
+    act = FO.activate(raw)
+    extr = LO.pose_to_extr(POSE)
+    uv0, _ = MO.project_point(act[0], s["intr"], extr, s["W"], s["H"])
+    last_uv = uv0 + torch.randn(n, 2, generator=g)
+    gt_flow = torch.randn(s["H"], s["W"], 2, generator=g)
+    still = torch.rand(n, generator=g) > 0.5
+    last_xyz = raw["xyz"] + 0.01 * torch.randn(n, 3, generator=g)
+    W, H = s["W"], s["H"]
+    and_mask = (last_uv[:, 0] > 0) & (last_uv[:, 0] < W - 1) & (last_uv[:, 1] > 0) & (last_uv[:, 1] < H - 1) & ~still
+    yx = last_uv.long()
+    gt_f = gt_flow[yx[:, 1].clamp(0, H - 1), yx[:, 0].clamp(0, W - 1)]
+    lam_flow, lam_still = 0.01, 10.0
+    eng = _engine(raw, s, img, dep, pose=POSE, lr=1e-3, lambda_rgb=1.0, lambda_flow=lam_flow, lambda_still=lam_still,
+                  freeze_rgb=1)
+    eng.set_regularisers(flow_target=last_uv + gt_f, flow_w=and_mask.float() / (2.0 * and_mask.sum()),
+                         still_target=last_xyz, still_w=still.float() / still.sum(), row_flags=still.to(torch.uint8))
+    eng.iteration()
+    rc = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
+    pose = POSE.clone().requires_grad_(True)
+    ab = torch.tensor([1.0, 0.0])
+    loss, info = FO.fit_loss(rc, pose, ab, s["intr"], dict(image=img, depth=dep), 0.0, 1.0, 0.0, 0.0)
+    loss = loss + lam_flow * LO.flow_loss(info["uv"], last_uv, gt_flow, and_mask) \
+        + lam_still * LO.still_loss(rc["xyz"], last_xyz, still)
+    loss.backward()
+    from gflow_amd.fused import COLS
+    g_all = (eng.adam_m[:n] / 0.1).cpu()
+    assert torch.all(g_all[:, 11:14] == 0)                          # rgb frozen
+    assert torch.all(g_all[still][:, 0:3] == 0)                     # xyz of still splats frozen
+    ref_xyz = rc["xyz"].grad.clone()
+    ref_xyz[still] = 0
+    rel = (g_all[:, 0:3] - ref_xyz).norm() / ref_xyz.norm()
+    assert rel < 2e-3, f"xyz gradient with flow+still terms: {rel:.2e}"
+    for k in ("scale", "rotate", "opacity"):
+        a, b = COLS[k]
+        ref = rc[k].grad.reshape(n, b - a)
+        rel = (g_all[:, a:b] - ref).norm() / ref.norm()
+        assert rel < 2e-3, f"d_{k}: {rel:.2e}"
+    # camera-only: every splat gradient is zero, the pose still gets one
+    eng2 = _engine(raw, s, img, dep, pose=POSE, lr=1e-3, lr_camera=1e-3, lambda_rgb=1.0, freeze_all_splats=1)
+    before = eng2.params[:n].clone()
+    eng2.iteration()
+    assert torch.equal(before, eng2.params[:n]) and eng2.pose_m.abs().sum() > 0
+
+
+def test_trainer_fused_and_operator_paths_agree():
+    """Short first-frame fit with densification through both trainer paths."""
+    from gflow_amd import synthetic as S
+    from gflow_amd.trainer import SimpleGaussian
+    H, W, N = 96, 128, 1500
+    frame = S.make_frame(H, W, seed=3)
+    out = {}
+    for fused in (True, False):
+        tr = SimpleGaussian(frame["image"], frame["depth"], num_points=N, device=DEV, seed=0, fused=fused)
+        tr.load_camera(focal=frame["focal"], pp=frame["pp"])
+        tr.init_gaussians_from_image(frame["image"], frame["depth"], num_points=N)
+        tr.train(iterations=24, lr=4e-3, lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0,
+                 move_mask=frame["move_mask"], densify_interval=12, densify_times=1, snapshot_interval=8,
+                 log_interval=1)
+        out[fused] = (tr.train_log, tr.current_pts_num(), tr.psnr().item())
+    lf, lo = out[True][0], out[False][0]
+    for i in (0, 5, 11):          # before the densification (its sampling differs in nothing: same generator)
+        assert abs(lf[i]["total"] - lo[i]["total"]) <= 2e-3 * abs(lo[i]["total"]), (i, lf[i], lo[i])
+    assert out[True][1] == out[False][1] and out[True][1] > N
+    assert abs(out[True][2] - out[False][2]) < 0.3
+    assert lf[-1]["total"] < lf[0]["total"]
+
+
+def test_fused_fullsize_matches_operator_path():
+    from gflow_amd import synthetic as S
+    import gflow_amd.render as R
+    H, W, N = 480, 854, 60000
+    frame = S.make_frame(H, W, seed=0)
+    raw = S.init_splats(frame, N, seed=0, grown=True)
+    s = dict(W=W, H=H, intr=raw["intr"])
+    eng = _engine({k: raw[k] for k in ("xyz", "scale", "rotate", "opacity", "rgb")}, s, frame["image"], frame["depth"])
+    eng.forward()
+    eng.check_overflow()
+    act = [a.to(DEV) for a in FO.activate(raw)]
+    og = R.render_multiple([*act, raw["intr"].to(DEV), raw["extr"].to(DEV), 0.0, W, H], ["rgb", "depth_map"])
+    api4 = torch.cat([og["rgb"], og["depth_map"]])
+    close_frac(eng.render, api4, 2e-5, 2e-6, bad_frac=1e-4, hard=2e-2, what="480p/60k fused vs operator path")
+    assert 60000 < eng.K < 4_000_000
