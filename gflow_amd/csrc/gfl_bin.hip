@@ -138,10 +138,27 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr a, int n) {
     }
 }
 
+// Optional inverse map for the fused backward: slot_rec = [cap][12] render records (u, v at 0,1,
+// radius bits at 11), slot_inv = [cap][SLOT_MAX]: for a splat whose tile rectangle has <= SLOT_MAX tiles,
+// slot_inv[g][rect-local tile index] = position of (g, tile) in the sorted lists.
+__device__ __forceinline__ void write_slot(const float* __restrict__ slot_rec, int32_t* __restrict__ slot_inv, int g,
+                                           int tile, int gx, int gy, int pos) {
+    const float* r = slot_rec + (size_t)g * 12;
+    int x0, x1, y0, y1;
+    tile_rect(r[0], r[1], __float_as_int(r[11]), gx, gy, x0, x1, y0, y1);
+    const int nx = x1 - x0;
+    if (nx * (y1 - y0) <= SLOT_MAX) {
+        const int tx = tile % gx, ty = tile / gx;
+        slot_inv[(size_t)g * SLOT_MAX + (ty - y0) * nx + (tx - x0)] = pos;
+    }
+}
+
 __global__ void __launch_bounds__(256) bin_tile_sort_kernel(const int32_t* __restrict__ offsets, int K_cap,
                                                             unsigned long long* __restrict__ keys,
                                                             int32_t* __restrict__ ids,
-                                                            int32_t* __restrict__ tile_range) {
+                                                            int32_t* __restrict__ tile_range,
+                                                            const float* __restrict__ slot_rec,
+                                                            int32_t* __restrict__ slot_inv, int gx, int gy) {
     __shared__ unsigned long long sk[SORT_LDS_KEYS];
     const int tile = blockIdx.x;
     const int start = min(offsets[tile], K_cap);
@@ -157,12 +174,22 @@ __global__ void __launch_bounds__(256) bin_tile_sort_kernel(const int32_t* __res
         for (int i = threadIdx.x; i < n; i += blockDim.x) sk[i] = seg[i];
         __syncthreads();
         if (n > 1) bitonic_sort(sk, n);
-        for (int i = threadIdx.x; i < n; i += blockDim.x) ids[start + i] = (int32_t)(unsigned)(sk[i] & 0xffffffffull);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const unsigned long long k = sk[i];
+            seg[i] = k;                                    // sorted keys stay available (fused backward bisects them)
+            const int g = (int32_t)(unsigned)(k & 0xffffffffull);
+            ids[start + i] = g;
+            if (slot_inv) write_slot(slot_rec, slot_inv, g, tile, gx, gy, start + i);
+        }
     } else {
         // oversized segment: same network directly on global memory (one CU, its
         // own L1, barriers between passes order the accesses)
         bitonic_sort((volatile unsigned long long*)seg, n);
-        for (int i = threadIdx.x; i < n; i += blockDim.x) ids[start + i] = (int32_t)(unsigned)(seg[i] & 0xffffffffull);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int g = (int32_t)(unsigned)(seg[i] & 0xffffffffull);
+            ids[start + i] = g;
+            if (slot_inv) write_slot(slot_rec, slot_inv, g, tile, gx, gy, start + i);
+        }
     }
 }
 
@@ -221,7 +248,7 @@ int gfl_bin_sort(const float* uv, const float* depth, const int32_t* radius, con
             bin_scatter_kernel<false><<<(N + 255) / 256, 256, 0, s>>>(uv, depth, radius, cutoff, N, gx, gy, tile_offsets,
                                                                       cursor, K_cap, keys, overflow);
     }
-    bin_tile_sort_kernel<<<T, 256, 0, s>>>(tile_offsets, K_cap, keys, ids, tile_range);
+    bin_tile_sort_kernel<<<T, 256, 0, s>>>(tile_offsets, K_cap, keys, ids, tile_range, nullptr, nullptr, gx, gy);
     return check_launch();
 }
 
@@ -229,7 +256,18 @@ int gfl_tile_sort_only(const int32_t* tile_offsets, int T, int K_cap, void* keys
                        gfl_stream_t stream) {
     if (T <= 0 || K_cap < 0 || !tile_offsets || !keys || !tile_range || (K_cap > 0 && !ids)) return GFL_ERR_INVALID;
     bin_tile_sort_kernel<<<T, 256, 0, (hipStream_t)stream>>>(tile_offsets, K_cap, (unsigned long long*)keys, ids,
-                                                             tile_range);
+                                                             tile_range, nullptr, nullptr, 1, T);
+    return check_launch();
+}
+
+int gfl_tile_sort_with_slots(const int32_t* tile_offsets, int W, int H, int K_cap, void* keys, int32_t* ids,
+                             int32_t* tile_range, const float* rec, int32_t* slot_inv, gfl_stream_t stream) {
+    if (W <= 0 || H <= 0 || K_cap < 0 || !tile_offsets || !keys || !tile_range || (K_cap > 0 && !ids) || !rec ||
+        !slot_inv)
+        return GFL_ERR_INVALID;
+    const int gx = (W + GFL_TILE - 1) / GFL_TILE, gy = (H + GFL_TILE - 1) / GFL_TILE;
+    bin_tile_sort_kernel<<<gx * gy, 256, 0, (hipStream_t)stream>>>(tile_offsets, K_cap, (unsigned long long*)keys, ids,
+                                                                   tile_range, rec, slot_inv, gx, gy);
     return check_launch();
 }
 

@@ -26,6 +26,7 @@ inline int check(hipError_t e) {
 }
 
 constexpr int WAVE = 64;
+constexpr int SLOT_MAX = 32;   // fused backward: list positions kept per splat (tile rect <= 32 tiles)
 
 // Camera in wave-uniform registers: the 16 floats are read with scalar loads.
 struct Cam {
@@ -60,6 +61,62 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
 __device__ __forceinline__ float wave_sum(float v) {
     v = wave_sum_to_lane63(v);
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// Reduce-scatter of ten per-lane values over the wave (blend backward: du dv dA dB dC do df0..3).
+// gfx950's v_permlane32_swap / v_permlane16_swap exchange half-waves / rows between two
+// registers, so "swap + add" halves the number of live values while summing lane pairs:
+//   stage 1  10 -> 5 values (lanes i, i+32),  stage 2  5 -> 3 values (rows 2k, 2k+1),
+//   stage 3  three 16-lane DPP reductions.      ~30 VALU ops instead of 10 x 6 dependent DPP adds.
+// Afterwards, in row r = (hi, odd) = (lane>>5, (lane>>4)&1) every lane holds
+//   x0 = sum of component 2*odd + hi,  x1 = sum of component 4 + 2*odd + hi,
+//   x2 = sum of component 8 + hi (even rows only).
+// Returns the value lane (lane & 15) in {0,1,2} owns and its component index in `comp` (-1: none).
+// NOTE (ROCm 7.2 hipcc): __builtin_amdgcn_permlane{16,32}_swap returns the updated vdst in BOTH
+// elements of its result (verified on hardware), so the swaps are issued as inline asm; the
+// leading s_nop covers the VALU-write -> permlane-read hazard that hipcc does not pad inside asm.
+__device__ __forceinline__ void permlane32_swap(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void permlane16_swap(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
+__device__ __forceinline__ float wave_reduce_scatter10(const float (&v)[10], int lane, int& comp) {
+    float w[5];
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        float a = v[2 * m], b = v[2 * m + 1];
+        permlane32_swap(a, b);        // a = {a_lo, b_lo}, b = {a_hi, b_hi}
+        w[m] = a + b;                 // lanes 0-31: component 2m, lanes 32-63: component 2m+1
+    }
+    float x[3];
+    {
+        float a = w[0], b = w[1];
+        permlane16_swap(a, b);        // a = {a_r0, b_r0, a_r2, b_r2}, b = {a_r1, b_r1, a_r3, b_r3}
+        x[0] = a + b;
+        a = w[2]; b = w[3];
+        permlane16_swap(a, b);
+        x[1] = a + b;
+        a = w[4]; b = 0.f;
+        permlane16_swap(a, b);
+        x[2] = a + b;
+    }
+#define GFL_ROW_STEP(ctrl)                                                                                            \
+    {                                                                                                                 \
+        const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x[0]), ctrl, 0xF, 0xF, true)); \
+        const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x[1]), ctrl, 0xF, 0xF, true)); \
+        const float t2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x[2]), ctrl, 0xF, 0xF, true)); \
+        x[0] += t0; x[1] += t1; x[2] += t2;                                                                           \
+    }
+    GFL_ROW_STEP(0xB1)    // quad_perm [1,0,3,2]
+    GFL_ROW_STEP(0x4E)    // quad_perm [2,3,0,1]
+    GFL_ROW_STEP(0x141)   // row_half_mirror
+    GFL_ROW_STEP(0x140)   // row_mirror
+#undef GFL_ROW_STEP
+    const int hi = lane >> 5, odd = (lane >> 4) & 1, sel = lane & 15;
+    comp = sel == 0 ? 2 * odd + hi : (sel == 1 ? 4 + 2 * odd + hi : ((sel == 2 && odd == 0) ? 8 + hi : -1));
+    return sel == 0 ? x[0] : (sel == 1 ? x[1] : x[2]);
 }
 
 // Deterministic block-level reduction of NV values -> one partial row per block.

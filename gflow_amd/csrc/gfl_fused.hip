@@ -91,7 +91,7 @@ __device__ __forceinline__ bool tile_hit2(float u, float v, float cutoff, int tx
 // ------------------------------------------------------------------ preprocess fwd
 __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
     const float* __restrict__ params, const float* __restrict__ intr, const float* __restrict__ pose, int N, int W, int H,
-    float nearest, float extent, int gx, int gy, float* __restrict__ rec, float* __restrict__ d_rec,
+    float nearest, float extent, int gx, int gy, float* __restrict__ rec, int32_t* __restrict__ slot_inv,
     int32_t* __restrict__ hist_g, float* __restrict__ extr_out) {
     extern __shared__ int32_t hist[];
     const int T = gx * gy;
@@ -132,61 +132,97 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
         r4[0] = make_float4(u, v, A, B);
         r4[1] = make_float4(C, s.o, s.c[0], s.c[1]);
         r4[2] = make_float4(s.c[2], depth, cutoff, __int_as_float(rad));
-        float4* g4 = reinterpret_cast<float4*>(d_rec + (size_t)i * REC);
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        g4[0] = z; g4[1] = z; g4[2] = z;
+        int4* iv = reinterpret_cast<int4*>(slot_inv + (size_t)i * SLOT_MAX);
+        const int4 none = make_int4(-1, -1, -1, -1);
+#pragma unroll
+        for (int q = 0; q < SLOT_MAX / 4; ++q) iv[q] = none;
     }
     __syncthreads();
     int32_t* row = hist_g + (size_t)blockIdx.x * T;
     for (int t = threadIdx.x; t < T; t += BIN_BLOCK) row[t] = hist[t];
 }
 
-// columns of hist -> exclusive per-block bases (in place); tile totals -> tile_offsets
-__global__ void __launch_bounds__(1024) bin_colscan_kernel(int32_t* __restrict__ hist_g, int nblk, int T,
-                                                          int32_t* __restrict__ tile_offsets) {
-    __shared__ int32_t wsum[16];
-    __shared__ int32_t carry_s;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) carry_s = 0;
+// Columns of hist -> exclusive per-block bases (in place) and per-tile totals.
+// 64 tiles per workgroup, four row groups per tile; loads are issued 16 at a time before any
+// store so that they overlap (an in-place load/store chain serialises on the L2 latency:
+// measured 64 us for 118 rows in the first version of this kernel).
+constexpr int CS_CHUNK = 16;
+__global__ void __launch_bounds__(256) bin_colscan_kernel(int32_t* __restrict__ hist_g, int nblk, int T,
+                                                         int32_t* __restrict__ tile_counts) {
+    __shared__ int32_t gsum[4][64];
+    const int tl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + tl;
+    const int R = (nblk + 3) / 4;
+    const int b0 = rg * R, b1 = min(nblk, b0 + R);
+    int total = 0;
+    if (t < T) {
+        for (int b = b0; b < b1; b += CS_CHUNK) {
+            int v[CS_CHUNK];
+#pragma unroll
+            for (int k = 0; k < CS_CHUNK; ++k) v[k] = (b + k < b1) ? hist_g[(size_t)(b + k) * T + t] : 0;
+#pragma unroll
+            for (int k = 0; k < CS_CHUNK; ++k) total += v[k];
+        }
+    }
+    gsum[rg][tl] = total;
     __syncthreads();
-    for (int base = 0; base < T; base += 1024) {
-        const int t = base + tid;
-        int run = 0;
-        if (t < T) {
-            for (int b = 0; b < nblk; ++b) {
-                const int cnt = hist_g[(size_t)b * T + t];
-                hist_g[(size_t)b * T + t] = run;
-                run += cnt;
+    int run = 0;
+    for (int g = 0; g < rg; ++g) run += gsum[g][tl];
+    if (t < T) {
+        if (rg == 0) tile_counts[t] = gsum[0][tl] + gsum[1][tl] + gsum[2][tl] + gsum[3][tl];
+        for (int b = b0; b < b1; b += CS_CHUNK) {
+            int v[CS_CHUNK];
+#pragma unroll
+            for (int k = 0; k < CS_CHUNK; ++k) v[k] = (b + k < b1) ? hist_g[(size_t)(b + k) * T + t] : 0;
+#pragma unroll
+            for (int k = 0; k < CS_CHUNK; ++k) {
+                if (b + k < b1) hist_g[(size_t)(b + k) * T + t] = run;
+                run += v[k];
             }
         }
-        int s = run;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int n = __shfl_up(s, off);
-            if (lane >= off) s += n;
-        }
-        if (lane == 63) wsum[wid] = s;
-        __syncthreads();
-        int wprefix = 0;
-        for (int w = 0; w < wid; ++w) wprefix += wsum[w];
-        const int carry = carry_s;
-        if (t < T) tile_offsets[t] = carry + wprefix + s - run;
-        __syncthreads();
-        if (tid == 1023) carry_s = carry + wprefix + s;
-        __syncthreads();
     }
-    if (tid == 0) tile_offsets[T] = carry_s;
 }
 
 __global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* __restrict__ rec, int N, int gx, int gy,
                                                                   const int32_t* __restrict__ hist_g,
-                                                                  const int32_t* __restrict__ tile_offsets, int K_cap,
+                                                                  const int32_t* __restrict__ tile_counts,
+                                                                  int32_t* __restrict__ tile_offsets, int K_cap,
                                                                   unsigned long long* __restrict__ keys,
                                                                   int32_t* __restrict__ overflow) {
     extern __shared__ int32_t cursor[];
+    __shared__ int32_t wsum[BIN_BLOCK / 64];
     const int T = gx * gy;
     const int32_t* base_row = hist_g + (size_t)blockIdx.x * T;
-    for (int t = threadIdx.x; t < T; t += BIN_BLOCK) cursor[t] = tile_offsets[t] + base_row[t];
+    {
+        // every block scans the T tile totals itself (a few elements per thread); block 0
+        // publishes the exclusive offsets for the tile sort / blend kernels
+        const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+        const int per = (T + BIN_BLOCK - 1) / BIN_BLOCK;
+        const int t0 = tid * per;
+        int local = 0;
+        for (int k = 0; k < per; ++k)
+            if (t0 + k < T) local += tile_counts[t0 + k];
+        int sc = local;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int n = __shfl_up(sc, off);
+            if (lane >= off) sc += n;
+        }
+        if (lane == 63) wsum[wid] = sc;
+        __syncthreads();
+        int wprefix = 0;
+        for (int w = 0; w < wid; ++w) wprefix += wsum[w];
+        int run = wprefix + sc - local;
+        for (int k = 0; k < per; ++k) {
+            const int t = t0 + k;
+            if (t < T) {
+                cursor[t] = run + base_row[t];
+                if (blockIdx.x == 0) tile_offsets[t] = run;
+                run += tile_counts[t];
+            }
+        }
+        if (blockIdx.x == 0 && tid == BIN_BLOCK - 1) tile_offsets[T] = run;
+    }
     __syncthreads();
     const int i = blockIdx.x * BIN_BLOCK + threadIdx.x;
     if (i >= N) return;
@@ -313,9 +349,12 @@ __global__ void __launch_bounds__(256) fused_blend_bwd_kernel(const float* __res
                                                               int H, int gx, const float* __restrict__ final_T,
                                                               const int32_t* __restrict__ n_contrib,
                                                               const float* __restrict__ d_out,
-                                                              float* __restrict__ d_rec) {
+                                                              float* __restrict__ pair_grad) {
+    // No global atomics: the four waves of the tile combine their per-splat sums in LDS and the
+    // tile writes ONE 48-byte row per (splat, tile) pair at the pair's list position with plain,
+    // coalesced stores.  The per-splat kernel gathers its rows afterwards (deterministic).
     __shared__ RecLDS recs[FB];
-    __shared__ int32_t rec_id[FB];
+    __shared__ float acc[FB][REC];
     __shared__ unsigned char s_mask[FB];
     __shared__ int32_t s_max_last;
     const int tile = blockIdx.x;
@@ -345,6 +384,13 @@ __global__ void __launch_bounds__(256) fused_blend_bwd_kernel(const float* __res
     if (lane == 0) atomicMax(&s_max_last, wave_last);
     __syncthreads();
     const int depth_n = min(total, (int)s_max_last);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // pairs behind the deepest contributor of the tile get a zero row
+    for (int p = depth_n + tid; p < total; p += 256) {
+        float4* o = reinterpret_cast<float4*>(pair_grad + (size_t)(start + p) * REC);
+        o[0] = zero4; o[1] = zero4; o[2] = zero4;
+    }
 
     for (int r0 = 0; r0 < depth_n; r0 += FB) {
         const int pos_t = depth_n - 1 - r0 - tid;     // slot tid <-> list position pos_t
@@ -354,9 +400,10 @@ __global__ void __launch_bounds__(256) fused_blend_bwd_kernel(const float* __res
             const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g * REC);
             const float4 p0 = r4[0], p1 = r4[1], p2 = r4[2];
             recs[tid].p0 = p0; recs[tid].p1 = p1; recs[tid].p2 = p2;
-            rec_id[tid] = g;
             s_mask[tid] = (unsigned char)block_mask(p0.x, p0.y, p2.z, tx * GFL_TILE, ty * GFL_TILE);
         }
+        float4* az = reinterpret_cast<float4*>(&acc[tid][0]);
+        az[0] = zero4; az[1] = zero4; az[2] = zero4;
         __syncthreads();
         const int cnt = min(FB, depth_n - r0);
         for (int c0 = 0; c0 < cnt; c0 += 64) {
@@ -373,38 +420,37 @@ __global__ void __launch_bounds__(256) fused_blend_bwd_kernel(const float* __res
                 float alpha = 0.f, G = 0.f;
                 const bool valid = (pos < last) && splat_alpha2(p0, p1, fx, fy, alpha, G);
                 if (__ballot(valid) == 0ull) continue;
-                float v_u = 0.f, v_v = 0.f, v_a = 0.f, v_b = 0.f, v_c = 0.f, v_o = 0.f;
-                float v_f0 = 0.f, v_f1 = 0.f, v_f2 = 0.f, v_f3 = 0.f;
+                float v[10];
+#pragma unroll
+                for (int k = 0; k < 10; ++k) v[k] = 0.f;
                 if (valid) {
                     const float4 p2 = recs[j].p2;
-                    const float om = 1.f - alpha;
-                    T = T / om;
+                    const float rom = __builtin_amdgcn_rcpf(1.f - alpha);
+                    T = T * rom;
                     const float h = fmaf(g0, p1.z, fmaf(g1, p1.w, fmaf(g2, p2.x, g3 * p2.y)));
-                    const float dalpha = T * h - S / om;
+                    const float dalpha = fmaf(T, h, -(S * rom));
                     const float w = alpha * T;
                     S = fmaf(h, w, S);
-                    v_f0 = w * g0; v_f1 = w * g1; v_f2 = w * g2; v_f3 = w * g3;
+                    v[6] = w * g0; v[7] = w * g1; v[8] = w * g2; v[9] = w * g3;
                     const float dx = p0.x - fx, dy = p0.y - fy;
-                    v_o = G * dalpha;
-                    const float dpow = p1.y * G * dalpha;
-                    v_a = -0.5f * dx * dx * dpow;
-                    v_c = -0.5f * dy * dy * dpow;
-                    v_b = -dx * dy * dpow;
-                    v_u = -(p0.z * dx + p0.w * dy) * dpow;
-                    v_v = -(p1.x * dy + p0.w * dx) * dpow;
+                    v[5] = G * dalpha;
+                    const float dpow = p1.y * v[5];
+                    v[2] = -0.5f * dx * dx * dpow;
+                    v[4] = -0.5f * dy * dy * dpow;
+                    v[3] = -dx * dy * dpow;
+                    v[0] = -(p0.z * dx + p0.w * dy) * dpow;
+                    v[1] = -(p1.x * dy + p0.w * dx) * dpow;
                 }
-                v_u = wave_sum_to_lane63(v_u); v_v = wave_sum_to_lane63(v_v);
-                v_a = wave_sum_to_lane63(v_a); v_b = wave_sum_to_lane63(v_b); v_c = wave_sum_to_lane63(v_c);
-                v_o = wave_sum_to_lane63(v_o);
-                v_f0 = wave_sum_to_lane63(v_f0); v_f1 = wave_sum_to_lane63(v_f1);
-                v_f2 = wave_sum_to_lane63(v_f2); v_f3 = wave_sum_to_lane63(v_f3);
-                if (lane == 63) {
-                    float* d = d_rec + (size_t)rec_id[j] * REC;
-                    atomicAdd(d + 0, v_u); atomicAdd(d + 1, v_v); atomicAdd(d + 2, v_a); atomicAdd(d + 3, v_b);
-                    atomicAdd(d + 4, v_c); atomicAdd(d + 5, v_o); atomicAdd(d + 6, v_f0); atomicAdd(d + 7, v_f1);
-                    atomicAdd(d + 8, v_f2); atomicAdd(d + 9, v_f3);
-                }
+                int comp;
+                const float mine = wave_reduce_scatter10(v, lane, comp);
+                if (comp >= 0) atomicAdd(&acc[j][comp], mine);
             }
+        }
+        __syncthreads();
+        if (pos_t >= 0) {
+            const float4* a4 = reinterpret_cast<const float4*>(&acc[tid][0]);
+            float4* o = reinterpret_cast<float4*>(pair_grad + (size_t)(start + pos_t) * REC);
+            o[0] = a4[0]; o[1] = a4[1]; o[2] = a4[2];
         }
     }
 }
@@ -440,7 +486,9 @@ struct RegCfg {                 // per-splat regularisers (trainer.py:490-530)
 
 __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel(
     float* __restrict__ params, float* __restrict__ adam_m, float* __restrict__ adam_v, const float* __restrict__ intr,
-    const float* __restrict__ pose, const float* __restrict__ rec, const float* __restrict__ d_rec, int N, int W, int H,
+    const float* __restrict__ pose, const float* __restrict__ rec, float* __restrict__ d_rec,
+    const float* __restrict__ pair_grad, const unsigned long long* __restrict__ keys,
+    const int32_t* __restrict__ tile_range, const int32_t* __restrict__ slot_inv, int gx, int gy, int N, int W, int H,
     const float* __restrict__ flow_target, const float* __restrict__ flow_w, const float* __restrict__ still_target,
     const float* __restrict__ still_w, const uint8_t* __restrict__ row_flags, RegCfg rc, AdamCfg ac,
     const int32_t* __restrict__ d_step, float* __restrict__ partial) {
@@ -448,13 +496,94 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
     float e[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) e[k] = 0.f;
+    // gather this splat's rows of pair_grad (one per tile it was binned into), in tile order.
+    // The tile sort left each pair's list position in the splat's slot row; splats covering more
+    // than SLOT_MAX tiles (a handful per frame) are handled by the whole wave below.
+    float4 rp0 = make_float4(0.f, 0.f, 0.f, 0.f), rp2 = rp0;
+    float4 d0 = rp0, d1 = rp0, d2 = rp0;   // du dv dA dB | dC do dr dg | db ddepth
+    float4 d0g = rp0, d1g = rp0, d2g = rp0;
+    bool big = false;
+    if (i < N) {
+        const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)i * REC);
+        rp0 = r4[0]; rp2 = r4[2];
+        {
+            const int rad = __float_as_int(rp2.w);
+            if (rad > 0) {
+                int x0, x1, y0, y1;
+                tile_rect(rp0.x, rp0.y, rad, gx, gy, x0, x1, y0, y1);
+                const int nt = (x1 - x0) * (y1 - y0);
+                if (nt <= SLOT_MAX) {
+                    const int32_t* sl = slot_inv + (size_t)i * SLOT_MAX;
+                    for (int q = 0; q < nt; ++q) {
+                        const int pos = sl[q];
+                        if (pos >= 0) {
+                            const float4* g4 = reinterpret_cast<const float4*>(pair_grad + (size_t)pos * REC);
+                            const float4 q0 = g4[0], q1 = g4[1], q2 = g4[2];
+                            d0.x += q0.x; d0.y += q0.y; d0.z += q0.z; d0.w += q0.w;
+                            d1.x += q1.x; d1.y += q1.y; d1.z += q1.z; d1.w += q1.w;
+                            d2.x += q2.x; d2.y += q2.y;
+                        }
+                    }
+                } else {
+                    big = true;
+                }
+            }
+        }
+    }
+    // ---- wave-cooperative gather for the few splats with more than SLOT_MAX tiles: every lane
+    // bisects the sorted keys of one of the splat's tiles (keys are unique), rows are wave-summed
+    {
+        const int lane = threadIdx.x & 63;
+        unsigned long long todo = __ballot(big);
+        while (todo) {
+            const int src = (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int si = __shfl(i, src);
+            const float su = __shfl(rp0.x, src), sv = __shfl(rp0.y, src), scut = __shfl(rp2.z, src),
+                        sdep = __shfl(rp2.y, src);
+            const int srad = __shfl(__float_as_int(rp2.w), src);
+            int x0, x1, y0, y1;
+            tile_rect(su, sv, srad, gx, gy, x0, x1, y0, y1);
+            const int nx = x1 - x0, nt = nx * (y1 - y0);
+            const unsigned long long key = ((unsigned long long)__float_as_uint(sdep) << 32) | (unsigned long long)(unsigned)si;
+            float a[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) a[k] = 0.f;
+            for (int q = lane; q < nt; q += 64) {
+                const int tx = x0 + q % nx, ty = y0 + q / nx;
+                if (!tile_hit2(su, sv, scut, tx, ty)) continue;
+                const int t = ty * gx + tx;
+                int lo = tile_range[2 * t];
+                const int e1 = tile_range[2 * t + 1];
+                int hi = e1;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (keys[mid] < key) lo = mid + 1; else hi = mid;
+                }
+                if (lo < e1 && keys[lo] == key) {
+                    const float4* g4 = reinterpret_cast<const float4*>(pair_grad + (size_t)lo * REC);
+                    const float4 q0 = g4[0], q1 = g4[1], q2 = g4[2];
+                    a[0] += q0.x; a[1] += q0.y; a[2] += q0.z; a[3] += q0.w; a[4] += q1.x; a[5] += q1.y; a[6] += q1.z;
+                    a[7] += q1.w; a[8] += q2.x; a[9] += q2.y;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 10; ++k) a[k] = wave_sum(a[k]);
+            if (lane == src) {
+                d0g = make_float4(a[0], a[1], a[2], a[3]);
+                d1g = make_float4(a[4], a[5], a[6], a[7]);
+                d2g = make_float4(a[8], a[9], 0.f, 0.f);
+            }
+        }
+    }
     if (i < N) {
         const Cam c = cam_from_pose(intr, pose);
         const Splat s = load_splat(params, i);
-        const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)i * REC);
-        const float4 rp0 = r4[0], rp2 = r4[2];
-        const float4* g4 = reinterpret_cast<const float4*>(d_rec + (size_t)i * REC);
-        const float4 d0 = g4[0], d1 = g4[1], d2 = g4[2];   // du dv dA dB | dC do dr dg | db ddepth
+        if (big) { d0 = d0g; d1 = d1g; d2 = d2g; }
+        {
+            float4* o4 = reinterpret_cast<float4*>(d_rec + (size_t)i * REC);
+            o4[0] = d0; o4[1] = d1; o4[2] = d2;
+        }
         float g[14];
 #pragma unroll
         for (int k = 0; k < 14; ++k) g[k] = 0.f;
@@ -632,6 +761,9 @@ size_t gfl_fit_workspace_bytes(int cap, int K_cap, int W, int H) {
     return up256((size_t)fit_nblk(cap > 0 ? cap : 1) * T * sizeof(int32_t))      // hist / bases
            + up256((size_t)K_cap * sizeof(unsigned long long))                      // keys
            + up256((size_t)reduce_rows(cap > 0 ? cap : 1) * 12 * sizeof(float))    // extr partials
+           + up256(T * sizeof(int32_t))                                             // tile totals
+           + up256((size_t)K_cap * REC * sizeof(float))                             // per-pair gradient rows
+           + up256((size_t)(cap > 0 ? cap : 1) * SLOT_MAX * sizeof(int32_t))        // slot -> list position
            + up256(gfl_loss_workspace_bytes(W, H)) + 256;
 }
 
@@ -639,6 +771,9 @@ struct FitWs {
     int32_t* hist;
     unsigned long long* keys;
     float* partial;
+    int32_t* tile_counts;
+    float* pair_grad;
+    int32_t* slot_inv;
     void* loss_ws;
     size_t loss_ws_bytes;
 };
@@ -653,6 +788,12 @@ static FitWs carve(const gfl_fit_state* st) {
     p += up256((size_t)st->K_cap * sizeof(unsigned long long));
     w.partial = (float*)p;
     p += up256((size_t)reduce_rows(st->cap > 0 ? st->cap : 1) * 12 * sizeof(float));
+    w.tile_counts = (int32_t*)p;
+    p += up256(T * sizeof(int32_t));
+    w.pair_grad = (float*)p;
+    p += up256((size_t)st->K_cap * REC * sizeof(float));
+    w.slot_inv = (int32_t*)p;
+    p += up256((size_t)(st->cap > 0 ? st->cap : 1) * SLOT_MAX * sizeof(int32_t));
     w.loss_ws = p;
     w.loss_ws_bytes = up256(gfl_loss_workspace_bytes(st->W, st->H));
     return w;
@@ -685,21 +826,22 @@ int gfl_fit_forward(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream
     {
         StageScope p(ST_PREPROCESS, s);
         fused_preprocess_fwd_kernel<<<nblk, BIN_BLOCK, lds, s>>>(st->params, st->intr, st->pose, st->N, st->W, st->H,
-                                                                hp->nearest, hp->extent, gx, gy, st->rec, st->d_rec,
+                                                                hp->nearest, hp->extent, gx, gy, st->rec, w.slot_inv,
                                                                 w.hist, st->extr);
     }
     {
         StageScope p(ST_COLSCAN, s);
-        bin_colscan_kernel<<<1, 1024, 0, s>>>(w.hist, nblk, T, st->tile_offsets);
+        bin_colscan_kernel<<<(T + 63) / 64, 256, 0, s>>>(w.hist, nblk, T, w.tile_counts);
     }
     {
         StageScope p(ST_SCATTER, s);
-        fused_scatter_kernel<<<nblk, BIN_BLOCK, lds, s>>>(st->rec, st->N, gx, gy, w.hist, st->tile_offsets, st->K_cap,
-                                                          w.keys, st->overflow);
+        fused_scatter_kernel<<<nblk, BIN_BLOCK, lds, s>>>(st->rec, st->N, gx, gy, w.hist, w.tile_counts, st->tile_offsets,
+                                                          st->K_cap, w.keys, st->overflow);
     }
     {
         StageScope p(ST_TILE_SORT, s);
-        rc = gfl_tile_sort_only(st->tile_offsets, T, st->K_cap, w.keys, st->ids, st->tile_range, stream);
+        rc = gfl_tile_sort_with_slots(st->tile_offsets, st->W, st->H, st->K_cap, w.keys, st->ids, st->tile_range, st->rec,
+                                      w.slot_inv, stream);
     }
     if (rc) return rc;
     {
@@ -729,7 +871,7 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
     {
         StageScope p(ST_BLEND_BWD, s);
         fused_blend_bwd_kernel<<<T, 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx, st->final_T,
-                                                 st->n_contrib, st->d_render, st->d_rec);
+                                                 st->n_contrib, st->d_render, w.pair_grad);
     }
     const int rows = reduce_rows(st->N > 0 ? st->N : 1);
     RegCfg rcfg;
@@ -744,8 +886,8 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
     {
         StageScope p(ST_PRE_BWD_ADAM, s);
         fused_preprocess_bwd_adam_kernel<<<rows, REDUCE_BLOCK, 0, s>>>(
-            st->params, st->adam_m, st->adam_v, st->intr, st->pose, st->rec, st->d_rec, st->N, st->W, st->H,
-            st->flow_target, st->flow_w, st->still_target, st->still_w, st->row_flags, rcfg, ac, st->step, w.partial);
+            st->params, st->adam_m, st->adam_v, st->intr, st->pose, st->rec, st->d_rec, w.pair_grad, w.keys,
+            st->tile_range, w.slot_inv, gx, gy, st->N, st->W, st->H, st->flow_target, st->flow_w, st->still_target, st->still_w, st->row_flags, rcfg, ac, st->step, w.partial);
     }
     {
         StageScope p(ST_CAMERA, s);

@@ -1,0 +1,30 @@
+// Device self-tests of wave-level primitives, exported so the GPU test-suite can pin
+// them independently of the kernels that use them.
+#include "gfl_common.hpp"
+
+namespace gfl {
+
+// one wave: in[64][10] -> out[10] via wave_reduce_scatter10; out2[10] via ten wave_sum calls
+__global__ void __launch_bounds__(64) selftest_reduce10_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                               float* __restrict__ out2) {
+    const int lane = threadIdx.x;
+    float v[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) v[k] = in[lane * 10 + k];
+    int comp;
+    const float mine = wave_reduce_scatter10(v, lane, comp);
+    if (comp >= 0) out[comp] = mine;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const float s = wave_sum(v[k]);
+        if (lane == 0) out2[k] = s;
+    }
+}
+
+}  // namespace gfl
+
+extern "C" int gfl_selftest_reduce10(const float* in, float* out_scatter, float* out_dpp, gfl_stream_t stream) {
+    if (!in || !out_scatter || !out_dpp) return GFL_ERR_INVALID;
+    gfl::selftest_reduce10_kernel<<<1, 64, 0, (hipStream_t)stream>>>(in, out_scatter, out_dpp);
+    return gfl::check_launch();
+}

@@ -110,7 +110,7 @@ class FitEngine:
         self.d_rec = torch.zeros(cap, REC, **f32)
         if old is not None and n:
             self.params[:n] = old[:n]
-        self.K_cap = int(self.K_cap_req) if self.K_cap_req else max(4_000_000, 48 * cap)
+        self.K_cap = int(self.K_cap_req) if self.K_cap_req else max(4_000_000, 16 * cap)
         self.ids = torch.zeros(self.K_cap, dtype=torch.int32, device=self.dev)
         nbytes = self.lib.gfl_fit_workspace_bytes(cap, self.K_cap, self.W, self.H)
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)

@@ -342,7 +342,8 @@ class SimpleGaussian:
             self.scheduler.step()
             self.iterations_done += 1
             if log_interval and iteration % log_interval == 0:
-                st.log.append({k: float(v) for k, v in terms.items()} | {"total": float(loss), "it": iteration})
+                st.log.append({k: float(v.detach()) for k, v in terms.items()}
+                              | {"total": float(loss.detach()), "it": iteration})
 
             # ---- densification (trainer.py:560-571)
             if not camera_only and iteration == 0 and later_frame and mask is not None:

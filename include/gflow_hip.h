@@ -211,6 +211,11 @@ int gfl_fit_iteration(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stre
 /* the per-tile sort of gfl_bin_sort alone (keys already scattered into segments) */
 int gfl_tile_sort_only(const int32_t* tile_offsets, int T, int K_cap, void* keys, int32_t* ids,
                        int32_t* tile_range, gfl_stream_t stream);
+/* same, and additionally fills slot_inv[cap][16] from the render records rec[cap][12]:
+ * slot_inv[g][rect-local tile index] = list position of the pair (g, tile) for splats
+ * whose tile rectangle has at most 16 tiles (the fused backward gathers through it) */
+int gfl_tile_sort_with_slots(const int32_t* tile_offsets, int W, int H, int K_cap, void* keys, int32_t* ids,
+                             int32_t* tile_range, const float* rec, int32_t* slot_inv, gfl_stream_t stream);
 
 /* ---- optional per-stage timing of the fused iteration ---------------------------
  * HIP events are recorded on the launch stream around the stages whose bit is set in
@@ -218,6 +223,10 @@ int gfl_tile_sort_only(const int32_t* tile_offsets, int T, int K_cap, void* keys
  * 6 blend backward, 7 preprocess-backward + Adam, 8 camera/affine Adam.
  * gfl_profile_read synchronises on the recorded events, fills total_ms[9] / counts[9]
  * and clears the records. */
+/* device self-test of the wave64 reduce-scatter used by the blend backward: in[64][10] ->
+ * out_scatter[10] (permlane-swap reduce-scatter) and out_dpp[10] (plain DPP sums) */
+int gfl_selftest_reduce10(const float* in, float* out_scatter, float* out_dpp, gfl_stream_t stream);
+
 #define GFL_PROFILE_STAGES 9
 int gfl_profile_enable(unsigned stage_mask);
 int gfl_profile_read(double* total_ms, int* counts, int n_stages);
