@@ -28,3 +28,11 @@ extern "C" int gfl_selftest_reduce10(const float* in, float* out_scatter, float*
     gfl::selftest_reduce10_kernel<<<1, 64, 0, (hipStream_t)stream>>>(in, out_scatter, out_dpp);
     return gfl::check_launch();
 }
+
+// sizes of the plain structs of the fused ABI, so FFI bindings can check their mirrors
+extern "C" int gfl_abi_sizes(int* sizeof_fit_state, int* sizeof_fit_hyper) {
+    if (!sizeof_fit_state || !sizeof_fit_hyper) return GFL_ERR_INVALID;
+    *sizeof_fit_state = (int)sizeof(gfl_fit_state);
+    *sizeof_fit_hyper = (int)sizeof(gfl_fit_hyper);
+    return GFL_OK;
+}

@@ -1,0 +1,139 @@
+"""Video driver -- the counterpart of gflow/fit_video.py's frame loop, plus clip sharding.
+
+``fit_clip`` keeps the reference's structure (fit_video.py:105-349): first-frame fit with
+``iterations_first``; then for every later frame an optional camera-only fit
+(``iterations_camera``, ``lr_camera_after``) followed by the full fit (``iterations_after``,
+``lr_after``, occlusion-mask densification at iteration 0).  Inputs are in-memory frames (dicts
+as produced by ``gflow_amd.synthetic.make_clip``: image, depth, flow, move_mask, occ_mask, focal,
+pp); the reference's file readers and video writers are out of scope.
+
+Multi-GPU: clips are independent, frames of one clip are not.  One process per GPU,
+clip i goes to rank i mod world, no data-path collective; at the end ONE all-reduce(SUM) of a small
+metrics vector and ONE all-reduce(MAX) of the wall time (RCCL over xGMI on a node, 32-64 bytes:
+pure latency).
+
+    python -m torch.distributed.run --nproc-per-node 8 -m gflow_amd.fit_video --clips 8 --frames 60
+"""
+import argparse
+import json
+import os
+import time
+
+import torch
+
+# defaults = README.md:89-107 / scripts/fit_video.sh
+DEFAULTS = dict(num_points=60000, lr=4e-3, lr_camera=0.0, iterations_first=500, lr_after=1e-3, iterations_after=300,
+                camera_first=True, lr_camera_after=5e-4, iterations_camera=150, densify_interval=150, densify_times=2,
+                densify_interval_after=100, densify_times_after=1, densify_occ_percent=1.0, densify_err_thre=1e-2,
+                densify_err_percent=1.0, lambda_rgb=1.0, lambda_depth=1e-4, lambda_var=10.0, lambda_still=10.0,
+                lambda_flow=0.01, lambda_scale=0.0, background="black")
+
+METRIC_NAMES = ("psnr_sum", "frames", "iterations", "rasterisations", "clips", "splats_final")
+
+
+def shard(n_items, rank, world):
+    """Indices of the clips rank ``rank`` fits: i with i % world == rank."""
+    return [i for i in range(n_items) if i % world == rank]
+
+
+def reduce_metrics(local, wall_seconds, dist=None, device="cpu"):
+    """SUM of the metrics vector and MAX of the wall time over all ranks (identity without dist)."""
+    vec = torch.tensor([float(local.get(k, 0.0)) for k in METRIC_NAMES], dtype=torch.float64, device=device)
+    wall = torch.tensor([float(wall_seconds)], dtype=torch.float64, device=device)
+    if dist is not None and dist.is_initialized():
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+        dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+    out = {k: float(v) for k, v in zip(METRIC_NAMES, vec.tolist())}
+    out["wall_s"] = float(wall.item())
+    return out
+
+
+def fit_clip(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, log=None):
+    """Fit one clip; returns the metrics dict of this clip (PSNR summed over its frames)."""
+    from .trainer import SimpleGaussian
+    c = dict(DEFAULTS)
+    c.update(cfg or {})
+    f0 = frames[0]
+    tr = SimpleGaussian(f0["image"], f0["depth"], num_points=c["num_points"], background=c["background"],
+                        device=device, seed=seed, fused=fused)
+    tr.load_camera(focal=f0["focal"], pp=f0["pp"])
+    tr.init_gaussians_from_image(f0["image"], f0["depth"], num_points=c["num_points"])
+    common = dict(lambda_rgb=c["lambda_rgb"], lambda_depth=c["lambda_depth"], lambda_scale=c["lambda_scale"],
+                  densify_occ_percent=c["densify_occ_percent"], densify_err_thre=c["densify_err_thre"],
+                  densify_err_percent=c["densify_err_percent"], snapshot_interval=snapshot_interval)
+    # first frame (fit_video.py:119-142)
+    tr.train(iterations=c["iterations_first"], lr=c["lr"], lr_camera=c["lr_camera"], lambda_var=c["lambda_var"],
+             densify_interval=c["densify_interval"], densify_times=c["densify_times"], move_mask=f0["move_mask"],
+             **common)
+    psnr_sum = float(tr.psnr())
+    if log:
+        log(f"frame 0: psnr {psnr_sum:.2f} dB, splats {tr.current_pts_num()}")
+    for i, fr in enumerate(frames[1:], start=1):
+        tr.set_gt_image(fr["image"])
+        tr.set_gt_depth(fr["depth"])
+        tr.set_gt_flow(frames[i - 1]["flow"])            # flow from frame i-1 to i (fit_video.py:250)
+        if c["camera_first"]:                            # fit_video.py:256-278
+            tr.train(iterations=c["iterations_camera"], lr_camera=c["lr_camera_after"], lambda_var=0.0,
+                     lambda_still=0.0, lambda_flow=c["lambda_flow"], densify_interval=c["densify_interval"],
+                     densify_times=c["densify_times"], camera_only=True, move_mask=fr["move_mask"], **common)
+        if c["iterations_after"] > 0:                    # fit_video.py:288-315
+            tr.train(iterations=c["iterations_after"], lr=c["lr_after"], lr_camera=0.0, lambda_var=c["lambda_var"],
+                     lambda_still=c["lambda_still"], lambda_flow=c["lambda_flow"],
+                     densify_interval=c["densify_interval_after"], densify_times=c["densify_times_after"],
+                     mask=fr.get("occ_mask"), move_mask=fr["move_mask"], **common)
+        p = float(tr.psnr())
+        psnr_sum += p
+        if log:
+            log(f"frame {i}: psnr {p:.2f} dB, splats {tr.current_pts_num()}")
+    if tr.engine is not None:
+        tr.engine.check_overflow()
+    return dict(psnr_sum=psnr_sum, frames=len(frames), iterations=tr.iterations_done,
+                rasterisations=tr.rasterisations_done, clips=1, splats_final=tr.current_pts_num())
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="fit synthetic clips, one process per GPU")
+    ap.add_argument("--clips", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=4)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=854)
+    ap.add_argument("--num_points", type=int, default=60000)
+    ap.add_argument("--iterations_first", type=int, default=500)
+    ap.add_argument("--iterations_after", type=int, default=300)
+    ap.add_argument("--iterations_camera", type=int, default=150)
+    ap.add_argument("--verbose", action="store_true")
+    args = ap.parse_args(argv)
+    from . import synthetic as S
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+    cfg = dict(num_points=args.num_points, iterations_first=args.iterations_first,
+               iterations_after=args.iterations_after, iterations_camera=args.iterations_camera)
+    local = {k: 0.0 for k in METRIC_NAMES}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for ci in shard(args.clips, rank, world):
+        frames = S.make_clip(args.frames, args.height, args.width, seed=ci)
+        m = fit_clip(frames, dev, cfg, seed=ci, log=(lambda s: print(f"[rank {rank} clip {ci}] {s}")) if args.verbose else None)
+        for k in METRIC_NAMES:
+            local[k] += m[k]
+    torch.cuda.synchronize()
+    out = reduce_metrics(local, time.perf_counter() - t0, dist, dev)
+    if rank == 0:
+        out["frames_per_s"] = out["frames"] / out["wall_s"]
+        out["iterations_per_s"] = out["iterations"] / out["wall_s"]
+        out["psnr_mean_db"] = out["psnr_sum"] / max(out["frames"], 1.0)
+        out["n_gpus"] = world
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -128,6 +128,15 @@ class SimpleGaussian:
         self.iterations_done = 0          # bookkeeping for throughput reports
         self.rasterisations_done = 0
 
+    def set_gt_image(self, gt_image):
+        self.gt_image = gt_image.to(self.device)
+
+    def set_gt_depth(self, gt_depth):
+        self.gt_depth = gt_depth.to(self.device)
+
+    def set_gt_flow(self, gt_flow):
+        self.gt_flow = gt_flow.to(self.device)
+
     # ------------------------------------------------------------------ camera
     def get_extr(self):
         return pose_to_extr(self.pose)

@@ -227,6 +227,9 @@ int gfl_tile_sort_with_slots(const int32_t* tile_offsets, int W, int H, int K_ca
  * out_scatter[10] (permlane-swap reduce-scatter) and out_dpp[10] (plain DPP sums) */
 int gfl_selftest_reduce10(const float* in, float* out_scatter, float* out_dpp, gfl_stream_t stream);
 
+/* sizeof(gfl_fit_state), sizeof(gfl_fit_hyper): lets an FFI binding verify its struct mirrors */
+int gfl_abi_sizes(int* sizeof_fit_state, int* sizeof_fit_hyper);
+
 #define GFL_PROFILE_STAGES 9
 int gfl_profile_enable(unsigned stage_mask);
 int gfl_profile_read(double* total_ms, int* counts, int n_stages);

@@ -1,0 +1,73 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/gflow_hip.h declares,
+the ctypes table mirrors the header, and the product path refuses to run without a device."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "gflow_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gfl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from gflow_amd import _lib
+    _lib.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = header_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/gflow_hip.h but not exported"
+
+
+def test_ctypes_table_covers_the_header():
+    from gflow_amd import _lib
+    assert sorted(_lib.SIGNATURES) == header_symbols()
+    lib = _lib.load()
+    assert lib.gfl_version() >= 100
+    assert lib.gfl_status_string(-2) == b"workspace too small"
+
+
+def test_struct_mirrors_match_the_c_layout():
+    from gflow_amd import _lib, fused
+    lib = _lib.load()
+    a, b = ctypes.c_int(), ctypes.c_int()
+    assert lib.gfl_abi_sizes(ctypes.byref(a), ctypes.byref(b)) == 0
+    assert a.value == ctypes.sizeof(fused.FitState)
+    assert b.value == ctypes.sizeof(fused.FitHyper)
+
+
+def test_size_queries_without_a_gpu():
+    from gflow_amd import _lib
+    lib = _lib.load()
+    assert lib.gfl_reduce_workspace_bytes(60000) == 235 * 12 * 4
+    assert lib.gfl_bin_workspace_bytes(60000, 300000, 854, 480) > 300000 * 8
+    assert lib.gfl_loss_workspace_bytes(854, 480) > 9 * 854 * 480 * 4
+    assert lib.gfl_fit_workspace_bytes(60000, 1000000, 854, 480) > 1000000 * (8 + 48)
+    # invalid arguments are rejected before any launch
+    assert lib.gfl_project_point_fwd(None, None, None, 5, 8, 8, 0.2, 1.3, None, None, None) == -1
+    assert lib.gfl_blend_fwd(None, None, None, None, 3, 0, 5, None, None, 0.0, 8, 8, None, None, None, None) == -1
+
+
+def test_product_path_has_no_cpu_fallback():
+    import gflow_amd.msplat as ms
+    from gflow_amd.trainer import SimpleGaussian
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ms.project_point(torch.zeros(4, 3), torch.zeros(4), torch.zeros(3, 4), 8, 8)
+    with pytest.raises(RuntimeError):
+        SimpleGaussian(torch.zeros(8, 8, 3), torch.zeros(8, 8, 1), num_points=4, device="cpu")
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "gflow_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"

@@ -1,0 +1,104 @@
+"""CPU: host-side pieces of the path -- sampler, geometry, pose helpers, synthetic inputs,
+clip sharding and the end-of-job reduction over a 2-rank gloo group."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import loss_oracle as LO
+
+
+def test_sobel_and_sampler_follow_gradient_magnitude():
+    from gflow_amd.sampling import _sobel, complex_texture_sampling
+    ramp = np.tile(np.arange(8, dtype=np.float32) * 3.0, (6, 1))
+    gx, gy = _sobel(ramp)
+    assert np.allclose(gx[:, 1:-1], 24.0) and np.allclose(gy, 0.0)
+    assert np.allclose(gx[:, 0], 0.0)                         # REFLECT_101 border: zero x-derivative at the edge
+    # a faint ramp (tiny gradient everywhere, so the reference's "min positive" floor is tiny)
+    # plus one strong vertical edge
+    img = (torch.arange(48).float() * 1e-4).reshape(1, 48, 1).repeat(32, 1, 3)
+    img[:, 24:] += 0.9
+    depth = torch.full((32, 48, 1), 2.0)
+    xys, d, sc, rgb, _ = complex_texture_sampling(img, depth, 4000, rng=np.random.default_rng(0))
+    assert xys.shape == (4000, 2) and d.shape == (4000, 1) and rgb.shape == (4000, 3)
+    near_edge = np.abs(xys[:, 0] - 23.5) <= 1.0
+    assert near_edge.mean() > 0.9                              # samples concentrate on the edge
+    assert abs(sc.sum() - 100.0) < 1e-6
+
+
+def test_pix2world_matches_golden(golden_dir):
+    from gflow_amd.geometry import pix2world
+    g = np.load(os.path.join(golden_dir, "pix2world.npz"))
+    uv, d, intr = (torch.from_numpy(g[k]) for k in ("uv", "depth", "intr"))
+    for e, o in (("extr_id", "xyz_id"), ("extr_rt", "xyz_rt")):
+        np.testing.assert_allclose(pix2world(uv, d, intr, torch.from_numpy(g[e])).numpy(), g[o], rtol=1e-5, atol=1e-6)
+
+
+def test_pose_helpers_agree_with_the_oracle():
+    from gflow_amd.trainer import pose_to_extr, rotmat_to_unitquat_xyzw
+    pose = torch.tensor([0.1, -0.2, 0.3, 0.9, 0.5, -0.4, 0.2])
+    e = pose_to_extr(pose)
+    np.testing.assert_allclose(e.numpy(), LO.pose_to_extr(pose).numpy(), atol=1e-7)
+    R = e[:, :3]
+    np.testing.assert_allclose((R @ R.T).numpy(), np.eye(3), atol=1e-6)
+    q = rotmat_to_unitquat_xyzw(R)
+    qn = pose[:4] / pose[:4].norm()
+    assert min((q - qn).abs().max().item(), (q + qn).abs().max().item()) < 1e-6
+    ident = pose_to_extr(torch.tensor([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0]))
+    np.testing.assert_allclose(ident.numpy(), np.eye(4)[:3], atol=0)
+
+
+def test_synthetic_inputs_are_seeded_and_well_formed():
+    from gflow_amd import synthetic as S
+    a, b = S.make_frame(48, 64, seed=3), S.make_frame(48, 64, seed=3)
+    assert torch.equal(a["image"], b["image"]) and torch.equal(a["depth"], b["depth"])
+    assert a["image"].shape == (48, 64, 3) and 0.0 <= a["image"].min() and a["image"].max() <= 1.0
+    assert a["depth"].shape == (48, 64, 1) and 1.0 <= a["depth"].min() and a["depth"].max() <= 5.0
+    assert a["flow"].shape == (48, 64, 2) and a["move_mask"].dtype == torch.bool
+    sp = S.init_splats(a, 500, seed=1)
+    assert sp["xyz"].shape == (500, 3) and sp["rotate"].shape == (500, 4)
+    assert torch.allclose(torch.sigmoid(10 * sp["opacity"]), torch.full((500, 1), 0.99), atol=1e-5)
+    assert (sp["scale"] <= 1e-3 + 1e-9).all()                 # trainer.py:225 clamp
+    assert not torch.equal(S.make_frame(48, 64, seed=4)["image"], a["image"])
+
+
+def test_shard_partitions_clips():
+    from gflow_amd.fit_video import shard
+    for world in (1, 2, 3, 8):
+        parts = [shard(11, r, world) for r in range(world)]
+        assert sorted(sum(parts, [])) == list(range(11))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from gflow_amd.fit_video import METRIC_NAMES, reduce_metrics, shard
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    clips = shard(5, rank, world)
+    local = dict(psnr_sum=30.0 * len(clips), frames=4 * len(clips), iterations=100 * len(clips),
+                 rasterisations=110 * len(clips), clips=len(clips), splats_final=1000 * (rank + 1))
+    out = reduce_metrics(local, wall_seconds=1.0 + rank, dist=dist)
+    dist.destroy_process_group()
+    q.put((rank, out))
+
+
+def test_two_rank_gloo_reduction():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        o = outs[r]
+        assert o["clips"] == 5 and o["frames"] == 20 and o["iterations"] == 500 and o["psnr_sum"] == 150.0
+        assert o["wall_s"] == 2.0                               # MAX over ranks
+        assert o["splats_final"] == 3000
