@@ -27,6 +27,7 @@
 namespace gfl {
 
 constexpr int BIN_BLOCK = 512;
+constexpr int WIDE_TILES = 16;   // splats covering more tiles are binned by a whole wave
 constexpr int ROW = 16;   // floats per params row
 constexpr int REC = 12;   // floats per rec row
 
@@ -92,22 +93,25 @@ __device__ __forceinline__ bool tile_hit2(float u, float v, float cutoff, int tx
 __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
     const float* __restrict__ params, const float* __restrict__ intr, const float* __restrict__ pose, int N, int W, int H,
     float nearest, float extent, int gx, int gy, float* __restrict__ rec, int32_t* __restrict__ slot_inv,
-    int32_t* __restrict__ hist_g, float* __restrict__ extr_out) {
+    int32_t* __restrict__ hist_g, float* __restrict__ extr_out, int32_t* __restrict__ overflow) {
     extern __shared__ int32_t hist[];
     const int T = gx * gy;
     for (int t = threadIdx.x; t < T; t += BIN_BLOCK) hist[t] = 0;
     __syncthreads();
     const Cam c = cam_from_pose(intr, pose);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *overflow = 0;            // set again by the scatter kernel (next launch) if K > K_cap
         extr_out[0] = c.r00; extr_out[1] = c.r01; extr_out[2] = c.r02; extr_out[3] = c.t0;
         extr_out[4] = c.r10; extr_out[5] = c.r11; extr_out[6] = c.r12; extr_out[7] = c.t1;
         extr_out[8] = c.r20; extr_out[9] = c.r21; extr_out[10] = c.r22; extr_out[11] = c.t2;
     }
     const int i = blockIdx.x * BIN_BLOCK + threadIdx.x;
+    float u = 0.f, v = 0.f, cutoff = 0.f;
+    int wx0 = 0, wy0 = 0, wnx = 0, wnt = 0;      // rectangle of a "wide" splat (walked by the wave below)
     if (i < N) {
         const Splat s = load_splat(params, i);
         const Proj p = project_fwd(c, s.x, s.y, s.z, W, H, nearest, extent);
-        float u = 0.f, v = 0.f, depth = 0.f, A = 0.f, B = 0.f, C = 0.f, cutoff = 0.f;
+        float depth = 0.f, A = 0.f, B = 0.f, C = 0.f;
         int rad = 0;
         if (p.vis) {
             u = p.u; v = p.v; depth = p.pz;
@@ -118,13 +122,18 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
                 const int r = ewa_radius(e);
                 int x0, x1, y0, y1;
                 tile_rect(u, v, r, gx, gy, x0, x1, y0, y1);
-                if ((x1 - x0) * (y1 - y0) > 0) {
+                const int nt = (x1 - x0) * (y1 - y0);
+                if (nt > 0) {
                     rad = r;
                     A = e.c / e.det; B = -e.b / e.det; C = e.a / e.det;
                     cutoff = alpha_cutoff(s.o, e.lam);
-                    for (int ty = y0; ty < y1; ++ty)
-                        for (int tx = x0; tx < x1; ++tx)
-                            if (tile_hit2(u, v, cutoff, tx, ty)) atomicAdd(&hist[ty * gx + tx], 1);
+                    if (nt > WIDE_TILES) {
+                        wx0 = x0; wy0 = y0; wnx = x1 - x0; wnt = nt;
+                    } else {
+                        for (int ty = y0; ty < y1; ++ty)
+                            for (int tx = x0; tx < x1; ++tx)
+                                if (tile_hit2(u, v, cutoff, tx, ty)) atomicAdd(&hist[ty * gx + tx], 1);
+                    }
                 }
             }
         }
@@ -136,6 +145,21 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
         const int4 none = make_int4(-1, -1, -1, -1);
 #pragma unroll
         for (int q = 0; q < SLOT_MAX / 4; ++q) iv[q] = none;
+    }
+    {
+        // splats covering many tiles: the whole wave counts their tiles, 64 at a time
+        const int lane = threadIdx.x & 63;
+        unsigned long long todo = __ballot(wnt > 0);
+        while (todo) {
+            const int src = (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const float su = __shfl(u, src), sv = __shfl(v, src), sc = __shfl(cutoff, src);
+            const int sx0 = __shfl(wx0, src), sy0 = __shfl(wy0, src), snx = __shfl(wnx, src), snt = __shfl(wnt, src);
+            for (int q = lane; q < snt; q += 64) {
+                const int tx = sx0 + q % snx, ty = sy0 + q / snx;
+                if (tile_hit2(su, sv, sc, tx, ty)) atomicAdd(&hist[ty * gx + tx], 1);
+            }
+        }
     }
     __syncthreads();
     int32_t* row = hist_g + (size_t)blockIdx.x * T;
@@ -225,22 +249,48 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* _
     }
     __syncthreads();
     const int i = blockIdx.x * BIN_BLOCK + threadIdx.x;
-    if (i >= N) return;
-    const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)i * REC);
-    const float4 p0 = r4[0], p2 = r4[2];
-    const int rad = __float_as_int(p2.w);
-    if (rad <= 0) return;
-    const float u = p0.x, v = p0.y, cutoff = p2.z;
-    int x0, x1, y0, y1;
-    tile_rect(u, v, rad, gx, gy, x0, x1, y0, y1);
-    const unsigned long long key = ((unsigned long long)__float_as_uint(p2.y) << 32) | (unsigned long long)(unsigned)i;
-    for (int ty = y0; ty < y1; ++ty)
-        for (int tx = x0; tx < x1; ++tx) {
-            if (!tile_hit2(u, v, cutoff, tx, ty)) continue;
+    float u = 0.f, v = 0.f, cutoff = 0.f, depth = 0.f;
+    int rad = 0;
+    if (i < N) {
+        const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)i * REC);
+        const float4 p0 = r4[0], p2 = r4[2];
+        rad = __float_as_int(p2.w);
+        u = p0.x; v = p0.y; cutoff = p2.z; depth = p2.y;
+    }
+    int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+    if (rad > 0) tile_rect(u, v, rad, gx, gy, x0, x1, y0, y1);
+    const int nx = x1 - x0, nt = nx * (y1 - y0);
+    // a splat covering many tiles would keep its lane (and so its wave) busy for ~100 trips:
+    // such splats are walked by the whole wave instead, 64 tiles at a time
+    const bool wide = nt > WIDE_TILES;
+    if (nt > 0 && !wide) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned long long)(unsigned)i;
+        for (int ty = y0; ty < y1; ++ty)
+            for (int tx = x0; tx < x1; ++tx) {
+                if (!tile_hit2(u, v, cutoff, tx, ty)) continue;
+                const int pos = atomicAdd(&cursor[ty * gx + tx], 1);
+                // scattered 8-byte stores: write-through (sc1)
+                if (pos < K_cap) __hip_atomic_store(&keys[pos], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *overflow = 1;
+            }
+    }
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(wide);
+    while (todo) {
+        const int src = (int)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        const float su = __shfl(u, src), sv = __shfl(v, src), sc = __shfl(cutoff, src);
+        const int sx0 = __shfl(x0, src), sy0 = __shfl(y0, src), snx = __shfl(nx, src), snt = __shfl(nt, src);
+        const unsigned long long key =
+            ((unsigned long long)__float_as_uint(__shfl(depth, src)) << 32) | (unsigned long long)(unsigned)__shfl(i, src);
+        for (int q = lane; q < snt; q += 64) {
+            const int tx = sx0 + q % snx, ty = sy0 + q / snx;
+            if (!tile_hit2(su, sv, sc, tx, ty)) continue;
             const int pos = atomicAdd(&cursor[ty * gx + tx], 1);
-            if (pos < K_cap) keys[pos] = key;
+            if (pos < K_cap) __hip_atomic_store(&keys[pos], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else *overflow = 1;
         }
+    }
 }
 
 // ------------------------------------------------------------------- blend (C = 4)
@@ -253,13 +303,14 @@ struct RecLDS {
 __device__ __forceinline__ bool splat_alpha2(const float4& p0, const float4& p1, float fx, float fy, float& alpha,
                                              float& G) {
 #pragma clang fp contract(off)
+    // branch-free; the same instruction sequence in the forward and the backward kernel so that
+    // both take the same skip/keep decision for every (pixel, splat)
     const float dx = p0.x - fx, dy = p0.y - fy;
     const float q = __builtin_fmaf(p0.z * dx, dx, (p1.x * dy) * dy);
     const float power = __builtin_fmaf(-0.5f, q, -((p0.w * dx) * dy));
-    if (power > 0.f) return false;
-    G = __expf(power);
+    G = __expf(fminf(power, 0.f));
     alpha = fminf(GFL_ALPHA_MAX, p1.y * G);
-    return alpha >= GFL_ALPHA_MIN;
+    return (power <= 0.f) & (alpha >= GFL_ALPHA_MIN);
 }
 
 // which of the tile's four 8x8 pixel blocks the alpha>=1/255 disc of a splat reaches
@@ -311,24 +362,47 @@ __global__ void __launch_bounds__(256) fused_blend_fwd_kernel(const float* __res
         const int cnt = min(FB, end - base);
         if (__all(done)) continue;      // this wave is finished; keep meeting the barriers
         for (int c0 = 0; c0 < cnt; c0 += 64) {
+            if (__all(done)) break;
             const int slot = c0 + lane;
             const bool hit = slot < cnt && ((s_mask[slot] >> wave) & 1);
             unsigned long long bits = __ballot(hit);
+            // Two hit splats per trip: their records are fetched and their alphas evaluated
+            // together (independent work hides the LDS latency); only the T recurrence is serial.
+            // The body is branch-free: a lane that skips a splat contributes w = 0.
             while (bits) {
-                const int j = c0 + (int)__builtin_ctzll(bits);
+                const int ja = c0 + (int)__builtin_ctzll(bits);
                 bits &= bits - 1;
-                if (done) continue;
-                const float4 p0 = recs[j].p0;
-                const float4 p1 = recs[j].p1;
-                float alpha, G;
-                if (!splat_alpha2(p0, p1, fx, fy, alpha, G)) continue;
-                const float test_T = T * (1.f - alpha);
-                if (test_T < GFL_T_MIN) { done = true; continue; }
-                const float w = alpha * T;
-                const float4 p2 = recs[j].p2;
-                a0 = fmaf(p1.z, w, a0); a1 = fmaf(p1.w, w, a1); a2 = fmaf(p2.x, w, a2); a3 = fmaf(p2.y, w, a3);
-                T = test_T;
-                last = base - start + j + 1;
+                const bool two = bits != 0ull;
+                const int jb = two ? c0 + (int)__builtin_ctzll(bits) : ja;
+                bits &= bits - 1;            // no-op when bits is already 0
+                const float4 pa0 = recs[ja].p0, pa1 = recs[ja].p1, pa2 = recs[ja].p2;
+                const float4 pb0 = recs[jb].p0, pb1 = recs[jb].p1, pb2 = recs[jb].p2;
+                float alpha_a, alpha_b, G;
+                const bool va = splat_alpha2(pa0, pa1, fx, fy, alpha_a, G);
+                const bool vb = splat_alpha2(pb0, pb1, fx, fy, alpha_b, G) && two;
+                {
+                    const float test_T = T * (1.f - alpha_a);
+                    const bool live = va && !done;
+                    const bool stop = live && test_T < GFL_T_MIN;
+                    const bool use = live && !stop;
+                    const float w = use ? alpha_a * T : 0.f;
+                    a0 = fmaf(pa1.z, w, a0); a1 = fmaf(pa1.w, w, a1); a2 = fmaf(pa2.x, w, a2); a3 = fmaf(pa2.y, w, a3);
+                    T = use ? test_T : T;
+                    last = use ? base - start + ja + 1 : last;
+                    done = done || stop;
+                }
+                {
+                    const float test_T = T * (1.f - alpha_b);
+                    const bool live = vb && !done;
+                    const bool stop = live && test_T < GFL_T_MIN;
+                    const bool use = live && !stop;
+                    const float w = use ? alpha_b * T : 0.f;
+                    a0 = fmaf(pb1.z, w, a0); a1 = fmaf(pb1.w, w, a1); a2 = fmaf(pb2.x, w, a2); a3 = fmaf(pb2.y, w, a3);
+                    T = use ? test_T : T;
+                    last = use ? base - start + jb + 1 : last;
+                    done = done || stop;
+                }
+                if (__all(done)) break;
             }
         }
     }
@@ -415,32 +489,30 @@ __global__ void __launch_bounds__(256) fused_blend_bwd_kernel(const float* __res
                 const int j = c0 + (int)__builtin_ctzll(bits);
                 bits &= bits - 1;
                 const int pos = depth_n - 1 - r0 - j;
-                const float4 p0 = recs[j].p0;
-                const float4 p1 = recs[j].p1;
-                float alpha = 0.f, G = 0.f;
-                const bool valid = (pos < last) && splat_alpha2(p0, p1, fx, fy, alpha, G);
+                const float4 p0 = recs[j].p0, p1 = recs[j].p1, p2 = recs[j].p2;
+                float alpha, G;
+                const bool valid = splat_alpha2(p0, p1, fx, fy, alpha, G) && (pos < last);
                 if (__ballot(valid) == 0ull) continue;
+                // branch-free: a lane that does not see this splat uses alpha = 0 (T, S unchanged,
+                // every gradient term exactly 0)
+                const float a_eff = valid ? alpha : 0.f;
+                const float rom = __builtin_amdgcn_rcpf(1.f - a_eff);
+                T = T * rom;
+                const float h = fmaf(g0, p1.z, fmaf(g1, p1.w, fmaf(g2, p2.x, g3 * p2.y)));
+                const float dalpha = valid ? fmaf(T, h, -(S * rom)) : 0.f;
+                const float w = a_eff * T;
+                S = fmaf(h, w, S);
                 float v[10];
-#pragma unroll
-                for (int k = 0; k < 10; ++k) v[k] = 0.f;
-                if (valid) {
-                    const float4 p2 = recs[j].p2;
-                    const float rom = __builtin_amdgcn_rcpf(1.f - alpha);
-                    T = T * rom;
-                    const float h = fmaf(g0, p1.z, fmaf(g1, p1.w, fmaf(g2, p2.x, g3 * p2.y)));
-                    const float dalpha = fmaf(T, h, -(S * rom));
-                    const float w = alpha * T;
-                    S = fmaf(h, w, S);
-                    v[6] = w * g0; v[7] = w * g1; v[8] = w * g2; v[9] = w * g3;
-                    const float dx = p0.x - fx, dy = p0.y - fy;
-                    v[5] = G * dalpha;
-                    const float dpow = p1.y * v[5];
-                    v[2] = -0.5f * dx * dx * dpow;
-                    v[4] = -0.5f * dy * dy * dpow;
-                    v[3] = -dx * dy * dpow;
-                    v[0] = -(p0.z * dx + p0.w * dy) * dpow;
-                    v[1] = -(p1.x * dy + p0.w * dx) * dpow;
-                }
+                v[6] = w * g0; v[7] = w * g1; v[8] = w * g2; v[9] = w * g3;
+                const float dx = p0.x - fx, dy = p0.y - fy;
+                v[5] = G * dalpha;
+                const float dpow = p1.y * v[5];
+                const float mx = -dx * dpow, my = -dy * dpow;
+                v[2] = 0.5f * dx * mx;
+                v[4] = 0.5f * dy * my;
+                v[3] = dx * my;
+                v[0] = fmaf(p0.z, mx, p0.w * my);
+                v[1] = fmaf(p1.x, my, p0.w * mx);
                 int comp;
                 const float mine = wave_reduce_scatter10(v, lane, comp);
                 if (comp >= 0) atomicAdd(&acc[j][comp], mine);
@@ -820,14 +892,12 @@ int gfl_fit_forward(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream
     const FitWs w = carve(st);
     const int nblk = fit_nblk(st->N > 0 ? st->N : 1);
     const size_t lds = (size_t)T * sizeof(int32_t);
-    rc = check(hipMemsetAsync(st->overflow, 0, sizeof(int32_t), s));
-    if (rc) return rc;
     if (lds > 64 * 1024) return GFL_ERR_INVALID;   // tile grid too large for the LDS histogram
     {
         StageScope p(ST_PREPROCESS, s);
         fused_preprocess_fwd_kernel<<<nblk, BIN_BLOCK, lds, s>>>(st->params, st->intr, st->pose, st->N, st->W, st->H,
                                                                 hp->nearest, hp->extent, gx, gy, st->rec, w.slot_inv,
-                                                                w.hist, st->extr);
+                                                                w.hist, st->extr, st->overflow);
     }
     {
         StageScope p(ST_COLSCAN, s);
