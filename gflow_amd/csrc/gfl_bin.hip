@@ -141,8 +141,8 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr a, int n) {
 // Optional inverse map for the fused backward: slot_rec = [cap][12] render records (u, v at 0,1,
 // radius bits at 11), slot_inv = [cap][SLOT_MAX]: for a splat whose tile rectangle has <= SLOT_MAX tiles,
 // slot_inv[g][rect-local tile index] = position of (g, tile) in the sorted lists.
-__device__ __forceinline__ void write_slot(const float* __restrict__ slot_rec, int32_t* __restrict__ slot_inv, int g,
-                                           int tile, int gx, int gy, int pos) {
+__device__ __forceinline__ void write_slot(const float* __restrict__ slot_rec, int32_t* __restrict__ slot_inv,
+                                           int32_t* __restrict__ slot_pool, int g, int tile, int gx, int gy, int pos) {
     const float* r = slot_rec + (size_t)g * 12;
     int x0, x1, y0, y1;
     tile_rect(r[0], r[1], __float_as_int(r[11]), gx, gy, x0, x1, y0, y1);
@@ -152,6 +152,15 @@ __device__ __forceinline__ void write_slot(const float* __restrict__ slot_rec, i
         // scattered 4-byte store: write-through (sc1), no partially dirty L2 lines left behind
         __hip_atomic_store(&slot_inv[(size_t)g * SLOT_MAX + (ty - y0) * nx + (tx - x0)], pos, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+    } else if (slot_pool) {
+        // more tiles than slots: the preprocess kernel reserved a run of the pool and left its
+        // offset in the first slot as -2 - offset
+        const int code = slot_inv[(size_t)g * SLOT_MAX];
+        if (code <= -2) {
+            const int tx = tile % gx, ty = tile / gx;
+            __hip_atomic_store(&slot_pool[-2 - code + (ty - y0) * nx + (tx - x0)], pos, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -167,7 +176,8 @@ __global__ void __launch_bounds__(MODE == 1 ? 1024 : 256) bin_tile_sort_kernel(c
                                                             int32_t* __restrict__ ids,
                                                             int32_t* __restrict__ tile_range,
                                                             const float* __restrict__ slot_rec,
-                                                            int32_t* __restrict__ slot_inv, int gx, int gy) {
+                                                            int32_t* __restrict__ slot_inv,
+                                                            int32_t* __restrict__ slot_pool, int gx, int gy) {
     constexpr bool SMALL = MODE < 2;
     constexpr int LANES = MODE == 1 ? 1024 : 256;
     __shared__ unsigned long long sk[MODE == 2 ? SORT_LDS_KEYS : LANES];
@@ -213,7 +223,7 @@ __global__ void __launch_bounds__(MODE == 1 ? 1024 : 256) bin_tile_sort_kernel(c
             seg[tid] = key;
             const int g = (int32_t)(unsigned)(key & 0xffffffffull);
             ids[start + tid] = g;
-            if (slot_inv) write_slot(slot_rec, slot_inv, g, tile, gx, gy, start + tid);
+            if (slot_inv) write_slot(slot_rec, slot_inv, slot_pool, g, tile, gx, gy, start + tid);
         }
     } else if (n <= SORT_LDS_KEYS) {
         for (int i = threadIdx.x; i < n; i += blockDim.x) sk[i] = seg[i];
@@ -224,7 +234,7 @@ __global__ void __launch_bounds__(MODE == 1 ? 1024 : 256) bin_tile_sort_kernel(c
             seg[i] = k;                                    // sorted keys stay available (fused backward bisects them)
             const int g = (int32_t)(unsigned)(k & 0xffffffffull);
             ids[start + i] = g;
-            if (slot_inv) write_slot(slot_rec, slot_inv, g, tile, gx, gy, start + i);
+            if (slot_inv) write_slot(slot_rec, slot_inv, slot_pool, g, tile, gx, gy, start + i);
         }
     } else {
         // oversized segment: same network directly on global memory (one CU, its
@@ -233,7 +243,7 @@ __global__ void __launch_bounds__(MODE == 1 ? 1024 : 256) bin_tile_sort_kernel(c
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const int g = (int32_t)(unsigned)(seg[i] & 0xffffffffull);
             ids[start + i] = g;
-            if (slot_inv) write_slot(slot_rec, slot_inv, g, tile, gx, gy, start + i);
+            if (slot_inv) write_slot(slot_rec, slot_inv, slot_pool, g, tile, gx, gy, start + i);
         }
     }
 }
@@ -293,9 +303,9 @@ int gfl_bin_sort(const float* uv, const float* depth, const int32_t* radius, con
             bin_scatter_kernel<false><<<(N + 255) / 256, 256, 0, s>>>(uv, depth, radius, cutoff, N, gx, gy, tile_offsets,
                                                                       cursor, K_cap, keys, overflow);
     }
-    bin_tile_sort_kernel<0><<<T, 256, 0, s>>>(tile_offsets, K_cap, keys, ids, tile_range, nullptr, nullptr, gx, gy);
-    bin_tile_sort_kernel<1><<<T, 1024, 0, s>>>(tile_offsets, K_cap, keys, ids, tile_range, nullptr, nullptr, gx, gy);
-    bin_tile_sort_kernel<2><<<T, 256, 0, s>>>(tile_offsets, K_cap, keys, ids, tile_range, nullptr, nullptr, gx, gy);
+    bin_tile_sort_kernel<0><<<T, 256, 0, s>>>(tile_offsets, K_cap, keys, ids, tile_range, nullptr, nullptr, nullptr, gx, gy);
+    bin_tile_sort_kernel<1><<<T, 1024, 0, s>>>(tile_offsets, K_cap, keys, ids, tile_range, nullptr, nullptr, nullptr, gx, gy);
+    bin_tile_sort_kernel<2><<<T, 256, 0, s>>>(tile_offsets, K_cap, keys, ids, tile_range, nullptr, nullptr, nullptr, gx, gy);
     return check_launch();
 }
 
@@ -304,23 +314,24 @@ int gfl_tile_sort_only(const int32_t* tile_offsets, int T, int K_cap, void* keys
     if (T <= 0 || K_cap < 0 || !tile_offsets || !keys || !tile_range || (K_cap > 0 && !ids)) return GFL_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* k64 = (unsigned long long*)keys;
-    bin_tile_sort_kernel<0><<<T, 256, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, nullptr, nullptr, 1, T);
-    bin_tile_sort_kernel<1><<<T, 1024, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, nullptr, nullptr, 1, T);
-    bin_tile_sort_kernel<2><<<T, 256, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, nullptr, nullptr, 1, T);
+    bin_tile_sort_kernel<0><<<T, 256, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, nullptr, nullptr, nullptr, 1, T);
+    bin_tile_sort_kernel<1><<<T, 1024, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, nullptr, nullptr, nullptr, 1, T);
+    bin_tile_sort_kernel<2><<<T, 256, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, nullptr, nullptr, nullptr, 1, T);
     return check_launch();
 }
 
 int gfl_tile_sort_with_slots(const int32_t* tile_offsets, int W, int H, int K_cap, void* keys, int32_t* ids,
-                             int32_t* tile_range, const float* rec, int32_t* slot_inv, gfl_stream_t stream) {
+                             int32_t* tile_range, const float* rec, int32_t* slot_inv, int32_t* slot_pool,
+                             gfl_stream_t stream) {
     if (W <= 0 || H <= 0 || K_cap < 0 || !tile_offsets || !keys || !tile_range || (K_cap > 0 && !ids) || !rec ||
         !slot_inv)
         return GFL_ERR_INVALID;
     const int gx = (W + GFL_TILE - 1) / GFL_TILE, gy = (H + GFL_TILE - 1) / GFL_TILE;
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* k64 = (unsigned long long*)keys;
-    bin_tile_sort_kernel<0><<<gx * gy, 256, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, rec, slot_inv, gx, gy);
-    bin_tile_sort_kernel<1><<<gx * gy, 1024, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, rec, slot_inv, gx, gy);
-    bin_tile_sort_kernel<2><<<gx * gy, 256, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, rec, slot_inv, gx, gy);
+    bin_tile_sort_kernel<0><<<gx * gy, 256, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, rec, slot_inv, slot_pool, gx, gy);
+    bin_tile_sort_kernel<1><<<gx * gy, 1024, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, rec, slot_inv, slot_pool, gx, gy);
+    bin_tile_sort_kernel<2><<<gx * gy, 256, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, rec, slot_inv, slot_pool, gx, gy);
     return check_launch();
 }
 

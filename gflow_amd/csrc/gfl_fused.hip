@@ -93,14 +93,14 @@ __device__ __forceinline__ bool tile_hit2(float u, float v, float cutoff, int tx
 __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
     const float* __restrict__ params, const float* __restrict__ intr, const float* __restrict__ pose, int N, int W, int H,
     float nearest, float extent, int gx, int gy, float* __restrict__ rec, int32_t* __restrict__ slot_inv,
-    int32_t* __restrict__ hist_g, float* __restrict__ extr_out, int32_t* __restrict__ overflow) {
+    int32_t* __restrict__ hist_g, float* __restrict__ extr_out, int32_t* __restrict__ overflow,
+    int32_t* __restrict__ slot_pool, int32_t* __restrict__ pool_counter, int pool_cap) {
     extern __shared__ int32_t hist[];
     const int T = gx * gy;
     for (int t = threadIdx.x; t < T; t += BIN_BLOCK) hist[t] = 0;
     __syncthreads();
     const Cam c = cam_from_pose(intr, pose);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        *overflow = 0;            // set again by the scatter kernel (next launch) if K > K_cap
         extr_out[0] = c.r00; extr_out[1] = c.r01; extr_out[2] = c.r02; extr_out[3] = c.t0;
         extr_out[4] = c.r10; extr_out[5] = c.r11; extr_out[6] = c.r12; extr_out[7] = c.t1;
         extr_out[8] = c.r20; extr_out[9] = c.r21; extr_out[10] = c.r22; extr_out[11] = c.t2;
@@ -108,6 +108,7 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
     const int i = blockIdx.x * BIN_BLOCK + threadIdx.x;
     float u = 0.f, v = 0.f, cutoff = 0.f;
     int wx0 = 0, wy0 = 0, wnx = 0, wnt = 0;      // rectangle of a "wide" splat (walked by the wave below)
+    int woff = -1;                               // its offset in the slot pool (more than SLOT_MAX tiles)
     if (i < N) {
         const Splat s = load_splat(params, i);
         const Proj p = project_fwd(c, s.x, s.y, s.z, W, H, nearest, extent);
@@ -145,6 +146,17 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
         const int4 none = make_int4(-1, -1, -1, -1);
 #pragma unroll
         for (int q = 0; q < SLOT_MAX / 4; ++q) iv[q] = none;
+        if (wnt > SLOT_MAX) {
+            // too many tiles for the slot row: reserve wnt entries of the pool; the row's first
+            // entry carries the pool offset as -2 - offset
+            const int off = atomicAdd(pool_counter, wnt);
+            if (off + wnt <= pool_cap) {
+                woff = off;
+                slot_inv[(size_t)i * SLOT_MAX] = -2 - off;
+            } else {
+                *overflow = 1;
+            }
+        }
     }
     {
         // splats covering many tiles: the whole wave counts their tiles, 64 at a time
@@ -155,9 +167,11 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
             todo &= todo - 1;
             const float su = __shfl(u, src), sv = __shfl(v, src), sc = __shfl(cutoff, src);
             const int sx0 = __shfl(wx0, src), sy0 = __shfl(wy0, src), snx = __shfl(wnx, src), snt = __shfl(wnt, src);
+            const int soff = __shfl(woff, src);
             for (int q = lane; q < snt; q += 64) {
                 const int tx = sx0 + q % snx, ty = sy0 + q / snx;
                 if (tile_hit2(su, sv, sc, tx, ty)) atomicAdd(&hist[ty * gx + tx], 1);
+                if (soff >= 0) slot_pool[soff + q] = -1;
             }
         }
     }
@@ -172,7 +186,9 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
 // measured 64 us for 118 rows in the first version of this kernel).
 constexpr int CS_CHUNK = 16;
 __global__ void __launch_bounds__(256) bin_colscan_kernel(int32_t* __restrict__ hist_g, int nblk, int T,
-                                                         int32_t* __restrict__ tile_counts) {
+                                                         int32_t* __restrict__ tile_counts,
+                                                         int32_t* __restrict__ pool_counter) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *pool_counter = 0;   // preprocess is done with it
     __shared__ int32_t gsum[4][64];
     const int tl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int t = blockIdx.x * 64 + tl;
@@ -294,7 +310,9 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* _
 }
 
 // ------------------------------------------------------------------- blend (C = 4)
-constexpr int FB = 256;   // staged splats per batch
+constexpr int FB = 256;   // staged splats per batch (forward)
+constexpr int FBB = 192;  // backward: 18.6 KB of LDS per workgroup -> 8 workgroups per CU, so that all
+                          // 1620 tiles of a 480p frame are resident at once (no second round)
 
 struct RecLDS {
     float4 p0, p1, p2;    // p2 = (b, depth, cutoff, radius bits)
@@ -327,7 +345,7 @@ __device__ __forceinline__ unsigned block_mask(float u, float v, float cutoff, i
     return m;
 }
 
-__global__ void __launch_bounds__(256) fused_blend_fwd_kernel(const float* __restrict__ rec,
+__global__ void __launch_bounds__(256, 8) fused_blend_fwd_kernel(const float* __restrict__ rec,
                                                               const int32_t* __restrict__ ids,
                                                               const int32_t* __restrict__ tile_range, float bg, int W,
                                                               int H, int gx, float* __restrict__ out,
@@ -417,7 +435,7 @@ __global__ void __launch_bounds__(256) fused_blend_fwd_kernel(const float* __res
     }
 }
 
-__global__ void __launch_bounds__(256) fused_blend_bwd_kernel(const float* __restrict__ rec,
+__global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __restrict__ rec,
                                                               const int32_t* __restrict__ ids,
                                                               const int32_t* __restrict__ tile_range, float bg, int W,
                                                               int H, int gx, const float* __restrict__ final_T,
@@ -427,9 +445,9 @@ __global__ void __launch_bounds__(256) fused_blend_bwd_kernel(const float* __res
     // No global atomics: the four waves of the tile combine their per-splat sums in LDS and the
     // tile writes ONE 48-byte row per (splat, tile) pair at the pair's list position with plain,
     // coalesced stores.  The per-splat kernel gathers its rows afterwards (deterministic).
-    __shared__ RecLDS recs[FB];
-    __shared__ float acc[FB][REC];
-    __shared__ unsigned char s_mask[FB];
+    __shared__ RecLDS recs[FBB];
+    __shared__ float acc[FBB][REC];
+    __shared__ unsigned char s_mask[FBB];
     __shared__ int32_t s_max_last;
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
@@ -466,8 +484,8 @@ __global__ void __launch_bounds__(256) fused_blend_bwd_kernel(const float* __res
         o[0] = zero4; o[1] = zero4; o[2] = zero4;
     }
 
-    for (int r0 = 0; r0 < depth_n; r0 += FB) {
-        const int pos_t = depth_n - 1 - r0 - tid;     // slot tid <-> list position pos_t
+    for (int r0 = 0; r0 < depth_n; r0 += FBB) {
+        const int pos_t = tid < FBB ? depth_n - 1 - r0 - tid : -1;     // slot tid <-> list position pos_t
         __syncthreads();
         if (pos_t >= 0) {
             const int g = ids[start + pos_t];
@@ -476,10 +494,12 @@ __global__ void __launch_bounds__(256) fused_blend_bwd_kernel(const float* __res
             recs[tid].p0 = p0; recs[tid].p1 = p1; recs[tid].p2 = p2;
             s_mask[tid] = (unsigned char)block_mask(p0.x, p0.y, p2.z, tx * GFL_TILE, ty * GFL_TILE);
         }
-        float4* az = reinterpret_cast<float4*>(&acc[tid][0]);
-        az[0] = zero4; az[1] = zero4; az[2] = zero4;
+        if (tid < FBB) {
+            float4* az = reinterpret_cast<float4*>(&acc[tid][0]);
+            az[0] = zero4; az[1] = zero4; az[2] = zero4;
+        }
         __syncthreads();
-        const int cnt = min(FB, depth_n - r0);
+        const int cnt = min(FBB, depth_n - r0);
         for (int c0 = 0; c0 < cnt; c0 += 64) {
             const int slot = c0 + lane;
             const int spos = depth_n - 1 - r0 - slot;
@@ -559,7 +579,7 @@ struct RegCfg {                 // per-splat regularisers (trainer.py:490-530)
 __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel(
     float* __restrict__ params, float* __restrict__ adam_m, float* __restrict__ adam_v, const float* __restrict__ intr,
     const float* __restrict__ pose, const float* __restrict__ rec, float* __restrict__ d_rec,
-    const float* __restrict__ pair_grad, const unsigned long long* __restrict__ keys,
+    const float* __restrict__ pair_grad, const int32_t* __restrict__ slot_pool,
     const int32_t* __restrict__ tile_range, const int32_t* __restrict__ slot_inv, int gx, int gy, int N, int W, int H,
     const float* __restrict__ flow_target, const float* __restrict__ flow_w, const float* __restrict__ still_target,
     const float* __restrict__ still_w, const uint8_t* __restrict__ row_flags, RegCfg rc, AdamCfg ac,
@@ -575,6 +595,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
     float4 d0 = rp0, d1 = rp0, d2 = rp0;   // du dv dA dB | dC do dr dg | db ddepth
     float4 d0g = rp0, d1g = rp0, d2g = rp0;
     bool big = false;
+    int big_nt = 0;
     if (i < N) {
         const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)i * REC);
         rp0 = r4[0]; rp2 = r4[2];
@@ -598,12 +619,13 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
                     }
                 } else {
                     big = true;
+                    big_nt = nt;
                 }
             }
         }
     }
-    // ---- wave-cooperative gather for the few splats with more than SLOT_MAX tiles: every lane
-    // bisects the sorted keys of one of the splat's tiles (keys are unique), rows are wave-summed
+    // ---- wave-cooperative gather for the few splats with more than SLOT_MAX tiles: their list
+    // positions sit in the slot pool (offset encoded in the first slot); rows are wave-summed
     {
         const int lane = threadIdx.x & 63;
         unsigned long long todo = __ballot(big);
@@ -611,28 +633,14 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
             const int src = (int)__builtin_ctzll(todo);
             todo &= todo - 1;
             const int si = __shfl(i, src);
-            const float su = __shfl(rp0.x, src), sv = __shfl(rp0.y, src), scut = __shfl(rp2.z, src),
-                        sdep = __shfl(rp2.y, src);
-            const int srad = __shfl(__float_as_int(rp2.w), src);
-            int x0, x1, y0, y1;
-            tile_rect(su, sv, srad, gx, gy, x0, x1, y0, y1);
-            const int nx = x1 - x0, nt = nx * (y1 - y0);
-            const unsigned long long key = ((unsigned long long)__float_as_uint(sdep) << 32) | (unsigned long long)(unsigned)si;
+            const int nt = __shfl(big_nt, src);
+            const int code = slot_inv[(size_t)si * SLOT_MAX];
             float a[10];
 #pragma unroll
             for (int k = 0; k < 10; ++k) a[k] = 0.f;
-            for (int q = lane; q < nt; q += 64) {
-                const int tx = x0 + q % nx, ty = y0 + q / nx;
-                if (!tile_hit2(su, sv, scut, tx, ty)) continue;
-                const int t = ty * gx + tx;
-                int lo = tile_range[2 * t];
-                const int e1 = tile_range[2 * t + 1];
-                int hi = e1;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (keys[mid] < key) lo = mid + 1; else hi = mid;
-                }
-                if (lo < e1 && keys[lo] == key) {
+            for (int q = lane; q < nt && code <= -2; q += 64) {
+                const int lo = slot_pool[-2 - code + q];
+                if (lo >= 0) {
                     const float4* g4 = reinterpret_cast<const float4*>(pair_grad + (size_t)lo * REC);
                     const float4 q0 = g4[0], q1 = g4[1], q2 = g4[2];
                     a[0] += q0.x; a[1] += q0.y; a[2] += q0.z; a[3] += q0.w; a[4] += q1.x; a[5] += q1.y; a[6] += q1.z;
@@ -836,6 +844,7 @@ size_t gfl_fit_workspace_bytes(int cap, int K_cap, int W, int H) {
            + up256(T * sizeof(int32_t))                                             // tile totals
            + up256((size_t)K_cap * REC * sizeof(float))                             // per-pair gradient rows
            + up256((size_t)(cap > 0 ? cap : 1) * SLOT_MAX * sizeof(int32_t))        // slot -> list position
+           + 256 + up256((size_t)K_cap * sizeof(int32_t))                          // pool counter + slot pool
            + up256(gfl_loss_workspace_bytes(W, H)) + 256;
 }
 
@@ -846,6 +855,8 @@ struct FitWs {
     int32_t* tile_counts;
     float* pair_grad;
     int32_t* slot_inv;
+    int32_t* slot_pool;
+    int32_t* pool_counter;
     void* loss_ws;
     size_t loss_ws_bytes;
 };
@@ -866,6 +877,10 @@ static FitWs carve(const gfl_fit_state* st) {
     p += up256((size_t)st->K_cap * REC * sizeof(float));
     w.slot_inv = (int32_t*)p;
     p += up256((size_t)(st->cap > 0 ? st->cap : 1) * SLOT_MAX * sizeof(int32_t));
+    w.pool_counter = (int32_t*)p;
+    p += 256;
+    w.slot_pool = (int32_t*)p;
+    p += up256((size_t)st->K_cap * sizeof(int32_t));
     w.loss_ws = p;
     w.loss_ws_bytes = up256(gfl_loss_workspace_bytes(st->W, st->H));
     return w;
@@ -897,11 +912,12 @@ int gfl_fit_forward(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream
         StageScope p(ST_PREPROCESS, s);
         fused_preprocess_fwd_kernel<<<nblk, BIN_BLOCK, lds, s>>>(st->params, st->intr, st->pose, st->N, st->W, st->H,
                                                                 hp->nearest, hp->extent, gx, gy, st->rec, w.slot_inv,
-                                                                w.hist, st->extr, st->overflow);
+                                                                w.hist, st->extr, st->overflow, w.slot_pool,
+                                                                w.pool_counter, st->K_cap);
     }
     {
         StageScope p(ST_COLSCAN, s);
-        bin_colscan_kernel<<<(T + 63) / 64, 256, 0, s>>>(w.hist, nblk, T, w.tile_counts);
+        bin_colscan_kernel<<<(T + 63) / 64, 256, 0, s>>>(w.hist, nblk, T, w.tile_counts, w.pool_counter);
     }
     {
         StageScope p(ST_SCATTER, s);
@@ -911,7 +927,7 @@ int gfl_fit_forward(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream
     {
         StageScope p(ST_TILE_SORT, s);
         rc = gfl_tile_sort_with_slots(st->tile_offsets, st->W, st->H, st->K_cap, w.keys, st->ids, st->tile_range, st->rec,
-                                      w.slot_inv, stream);
+                                      w.slot_inv, w.slot_pool, stream);
     }
     if (rc) return rc;
     {
@@ -956,7 +972,7 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
     {
         StageScope p(ST_PRE_BWD_ADAM, s);
         fused_preprocess_bwd_adam_kernel<<<rows, REDUCE_BLOCK, 0, s>>>(
-            st->params, st->adam_m, st->adam_v, st->intr, st->pose, st->rec, st->d_rec, w.pair_grad, w.keys,
+            st->params, st->adam_m, st->adam_v, st->intr, st->pose, st->rec, st->d_rec, w.pair_grad, w.slot_pool,
             st->tile_range, w.slot_inv, gx, gy, st->N, st->W, st->H, st->flow_target, st->flow_w, st->still_target, st->still_w, st->row_flags, rcfg, ac, st->step, w.partial);
     }
     {

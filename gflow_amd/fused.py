@@ -113,7 +113,7 @@ class FitEngine:
         self.K_cap = int(self.K_cap_req) if self.K_cap_req else max(4_000_000, 16 * cap)
         self.ids = torch.zeros(self.K_cap, dtype=torch.int32, device=self.dev)
         nbytes = self.lib.gfl_fit_workspace_bytes(cap, self.K_cap, self.W, self.H)
-        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+        self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.dev)   # the pool counter must start at 0
         self._state = None
 
     def ensure_capacity(self, n):
@@ -212,6 +212,7 @@ class FitEngine:
 
     def check_overflow(self):
         if int(self.overflow.item()):
+            self.overflow.zero_()          # the flag is sticky on the device
             raise RuntimeError(f"FitEngine: more than K_cap={self.K_cap} splat-tile pairs; raise K_cap")
 
     def loss_terms(self):

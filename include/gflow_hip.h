@@ -213,9 +213,11 @@ int gfl_tile_sort_only(const int32_t* tile_offsets, int T, int K_cap, void* keys
                        int32_t* tile_range, gfl_stream_t stream);
 /* same, and additionally fills slot_inv[cap][16] from the render records rec[cap][12]:
  * slot_inv[g][rect-local tile index] = list position of the pair (g, tile) for splats
- * whose tile rectangle has at most 16 tiles (the fused backward gathers through it) */
+ * whose tile rectangle has at most 32 tiles; wider splats use a run of slot_pool whose offset the
+ * fused preprocess left in slot_inv[g][0] as -2 - offset (the fused backward gathers through both) */
 int gfl_tile_sort_with_slots(const int32_t* tile_offsets, int W, int H, int K_cap, void* keys, int32_t* ids,
-                             int32_t* tile_range, const float* rec, int32_t* slot_inv, gfl_stream_t stream);
+                             int32_t* tile_range, const float* rec, int32_t* slot_inv, int32_t* slot_pool,
+                             gfl_stream_t stream);
 
 /* ---- optional per-stage timing of the fused iteration ---------------------------
  * HIP events are recorded on the launch stream around the stages whose bit is set in
