@@ -544,6 +544,16 @@ class SimpleGaussian:
             move_mask = move_mask.to(dev).bool()
 
         # ---- post-update (trainer.py:588-625)
+        if st.uv.shape[0] != self.current_pts_num():
+            # splats were appended after the last render (densification on the final iteration; the
+            # reference would fail on the shape mismatch at trainer.py:596): project them once more
+            with torch.no_grad():
+                if self.fused and self.engine is not None:
+                    self.engine.forward()
+                    st.uv, st.depth, st.last_render = self.engine.uv, self.engine.depth, self.engine.render
+                else:
+                    st.uv, st.depth, st.last_render, _ = self._render_rgbd(want_extras=False)
+                self.rasterisations_done += 1
         uv_d, depth_d = st.uv.clone(), st.depth.clone()
         if not camera_only:
             within = _within(uv_d, W, H)
