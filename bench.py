@@ -131,11 +131,12 @@ def main():
     elapsed = time.perf_counter() - t0
     # ---- the same K steps again with HIP events recorded by the library on the launch stream
     # around every stage: per-kernel durations for the roofline block
-    lib.gfl_profile_enable((1 << len(STAGES)) - 1)
+    from gflow_amd.fused import set_profile
+    set_profile((1 << len(STAGES)) - 1)
     for _ in range(args.steps):
         stepper()
     torch.cuda.synchronize()
-    lib.gfl_profile_enable(0)
+    set_profile(0)
     kern_all = profile_read(lib)
     kern = {k: kern_all[k] for k in ("blend_fwd", "loss", "blend_bwd") if k in kern_all}
 

@@ -42,6 +42,7 @@ SIGNATURES = {
     "gfl_colormap_nonzero": (c_int, [_P, c_int, _P, _P, _P, c_size_t, _P]),
     "gfl_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
     "gfl_loss_fwd_bwd": (c_int, [_P, _P, _P, _P, _P, c_float, c_float, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "gfl_loss_fwd_bwd_partials": (c_int, [_P, _P, _P, _P, _P, c_float, c_float, c_int, c_int, _P, _P, _P, c_size_t, _P, _P, _P, _P, _P]),
     "gfl_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, c_float, c_float, c_float, c_float, _P, c_float, c_int, _P]),
     "gfl_step_increment": (c_int, [_P, _P]),
     "gfl_tile_sort_only": (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),

@@ -16,7 +16,6 @@
 
 namespace gfl {
 
-constexpr int SORT_LDS_KEYS = 4096;
 
 __device__ __forceinline__ bool tile_hit(float u, float v, float cutoff, int tx, int ty) {
     // exact-disc test: distance from the splat centre to the tile's pixel-centre
@@ -164,90 +163,11 @@ __device__ __forceinline__ void write_slot(const float* __restrict__ slot_rec, i
     }
 }
 
-// SMALL = true : tiles with at most 256 keys, 2 KB of LDS -> eight workgroups per CU, one round;
-// SMALL = false: the remaining tiles (LDS network up to 4096 keys, global-memory network beyond).
-// Both are launched over all tiles; a block whose tile belongs to the other variant exits at once.
-// MODE 0: n <= 256 (256 lanes)   MODE 1: 256 < n <= 1024 (1024 lanes)   MODE 2: n > 1024 (generic)
-// In modes 0/1 every lane holds ONE key in a register; a single oversized tile on the generic
-// path costs ~25 us of barrier latency, which is why the one-key-per-lane path goes up to 1024.
-template <int MODE>
-__global__ void __launch_bounds__(MODE == 1 ? 1024 : 256) bin_tile_sort_kernel(const int32_t* __restrict__ offsets, int K_cap,
-                                                            unsigned long long* __restrict__ keys,
-                                                            int32_t* __restrict__ ids,
-                                                            int32_t* __restrict__ tile_range,
-                                                            const float* __restrict__ slot_rec,
-                                                            int32_t* __restrict__ slot_inv,
-                                                            int32_t* __restrict__ slot_pool, int gx, int gy) {
-    constexpr bool SMALL = MODE < 2;
-    constexpr int LANES = MODE == 1 ? 1024 : 256;
-    __shared__ unsigned long long sk[MODE == 2 ? SORT_LDS_KEYS : LANES];
-    const int tile = blockIdx.x;
-    const int start = min(offsets[tile], K_cap);
-    const int end = min(offsets[tile + 1], K_cap);
-    const int n = end - start;
-    const int mode = n <= 256 ? 0 : (n <= 1024 ? 1 : 2);
-    if (mode != MODE) return;
-    if (threadIdx.x == 0) {
-        tile_range[2 * tile] = n > 0 ? start : 0;
-        tile_range[2 * tile + 1] = n > 0 ? end : 0;
-    }
-    if (n <= 0) return;
-    unsigned long long* seg = keys + start;
-    if (SMALL) {
-        // Register path (the common case: ~130 keys per tile): one key per lane, padded with
-        // +inf; compare-exchange partners closer than 64 lanes are reached with wave shuffles
-        // (no barrier, no LDS traffic), only the strides 64 and 128 go through LDS.
-        const int tid = threadIdx.x;
-        unsigned long long key = tid < n ? seg[tid] : ~0ull;
-        int npow = 2;
-        while (npow < n) npow <<= 1;
-        for (int k = 2; k <= npow; k <<= 1) {
-            const bool up = (tid & k) == 0;
-            for (int j = k >> 1; j >= 1; j >>= 1) {
-                unsigned long long other;
-                if (j >= 64) {
-                    __syncthreads();
-                    sk[tid] = key;
-                    __syncthreads();
-                    other = sk[tid ^ j];
-                } else {
-                    other = __shfl_xor(key, j);
-                }
-                const bool lower = (tid & j) == 0;
-                const bool take_min = lower == up;
-                const unsigned long long mn = key < other ? key : other, mx = key < other ? other : key;
-                key = take_min ? mn : mx;
-            }
-        }
-        if (tid < n) {
-            seg[tid] = key;
-            const int g = (int32_t)(unsigned)(key & 0xffffffffull);
-            ids[start + tid] = g;
-            if (slot_inv) write_slot(slot_rec, slot_inv, slot_pool, g, tile, gx, gy, start + tid);
-        }
-    } else if (n <= SORT_LDS_KEYS) {
-        for (int i = threadIdx.x; i < n; i += blockDim.x) sk[i] = seg[i];
-        __syncthreads();
-        if (n > 1) bitonic_sort(sk, n);
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const unsigned long long k = sk[i];
-            seg[i] = k;                                    // sorted keys stay available (fused backward bisects them)
-            const int g = (int32_t)(unsigned)(k & 0xffffffffull);
-            ids[start + i] = g;
-            if (slot_inv) write_slot(slot_rec, slot_inv, slot_pool, g, tile, gx, gy, start + i);
-        }
-    } else {
-        // oversized segment: same network directly on global memory (one CU, its
-        // own L1, barriers between passes order the accesses)
-        bitonic_sort((volatile unsigned long long*)seg, n);
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const int g = (int32_t)(unsigned)(seg[i] & 0xffffffffull);
-            ids[start + i] = g;
-            if (slot_inv) write_slot(slot_rec, slot_inv, slot_pool, g, tile, gx, gy, start + i);
-        }
-    }
-}
+}  // namespace gfl
 
+#include "gfl_tile_sort.hpp"
+
+namespace gfl {
 }  // namespace gfl
 
 using namespace gfl;
@@ -303,9 +223,7 @@ int gfl_bin_sort(const float* uv, const float* depth, const int32_t* radius, con
             bin_scatter_kernel<false><<<(N + 255) / 256, 256, 0, s>>>(uv, depth, radius, cutoff, N, gx, gy, tile_offsets,
                                                                       cursor, K_cap, keys, overflow);
     }
-    bin_tile_sort_kernel<0><<<T, 256, 0, s>>>(tile_offsets, K_cap, keys, ids, tile_range, nullptr, nullptr, nullptr, gx, gy);
-    bin_tile_sort_kernel<1><<<T, 1024, 0, s>>>(tile_offsets, K_cap, keys, ids, tile_range, nullptr, nullptr, nullptr, gx, gy);
-    bin_tile_sort_kernel<2><<<T, 256, 0, s>>>(tile_offsets, K_cap, keys, ids, tile_range, nullptr, nullptr, nullptr, gx, gy);
+    bin_tile_sort_kernel<<<T, 256, 0, s>>>(tile_offsets, K_cap, keys, ids, tile_range, nullptr, nullptr, nullptr, gx, gy);
     return check_launch();
 }
 
@@ -314,9 +232,7 @@ int gfl_tile_sort_only(const int32_t* tile_offsets, int T, int K_cap, void* keys
     if (T <= 0 || K_cap < 0 || !tile_offsets || !keys || !tile_range || (K_cap > 0 && !ids)) return GFL_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* k64 = (unsigned long long*)keys;
-    bin_tile_sort_kernel<0><<<T, 256, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, nullptr, nullptr, nullptr, 1, T);
-    bin_tile_sort_kernel<1><<<T, 1024, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, nullptr, nullptr, nullptr, 1, T);
-    bin_tile_sort_kernel<2><<<T, 256, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, nullptr, nullptr, nullptr, 1, T);
+    bin_tile_sort_kernel<<<T, 256, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, nullptr, nullptr, nullptr, 1, T);
     return check_launch();
 }
 
@@ -329,9 +245,7 @@ int gfl_tile_sort_with_slots(const int32_t* tile_offsets, int W, int H, int K_ca
     const int gx = (W + GFL_TILE - 1) / GFL_TILE, gy = (H + GFL_TILE - 1) / GFL_TILE;
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* k64 = (unsigned long long*)keys;
-    bin_tile_sort_kernel<0><<<gx * gy, 256, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, rec, slot_inv, slot_pool, gx, gy);
-    bin_tile_sort_kernel<1><<<gx * gy, 1024, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, rec, slot_inv, slot_pool, gx, gy);
-    bin_tile_sort_kernel<2><<<gx * gy, 256, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, rec, slot_inv, slot_pool, gx, gy);
+    bin_tile_sort_kernel<<<gx * gy, 256, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, rec, slot_inv, slot_pool, gx, gy);
     return check_launch();
 }
 

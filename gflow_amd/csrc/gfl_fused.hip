@@ -761,33 +761,46 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
 }
 
 // camera + depth affine: fold the extr partials, chain to the pose, Adam, step += 1
-__global__ void __launch_bounds__(256) fused_camera_adam_kernel(const float* __restrict__ partial, int rows,
-                                                                float* __restrict__ pose, float* __restrict__ pose_m,
-                                                                float* __restrict__ pose_v, float* __restrict__ depth_ab,
-                                                                float* __restrict__ ab_m, float* __restrict__ ab_v,
-                                                                const float* __restrict__ sums, AdamCfg ac_cam,
-                                                                AdamCfg ac_ab, int step_camera, int32_t* __restrict__ d_step,
-                                                                float* __restrict__ d_extr_out) {
-    float acc[12];
+// One block of 1024 lanes also folds the loss partial rows (no separate fold launch): every lane
+// is at most a couple of loads deep, the tree has a fixed shape (reproducible).
+__global__ void __launch_bounds__(1024) fused_camera_adam_kernel(
+    const float* __restrict__ partial, int rows, const float* __restrict__ p_ssim, int n_ssim,
+    const float* __restrict__ p_grad, int n_grad, float* __restrict__ pose, float* __restrict__ pose_m,
+    float* __restrict__ pose_v, float* __restrict__ depth_ab, float* __restrict__ ab_m, float* __restrict__ ab_v,
+    float* __restrict__ sums, AdamCfg ac_cam, AdamCfg ac_ab, int step_camera, int32_t* __restrict__ d_step,
+    float* __restrict__ d_extr_out) {
+    constexpr int NV = 17;   // 12 extr + {mse, ssim, depth, d/da, d/db}
+    float acc[NV];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
-    for (int r = threadIdx.x; r < rows; r += 256) {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) acc[k] += partial[(size_t)r * 12 + k];
+    for (int k = 0; k < NV; ++k) acc[k] = 0.f;
+    for (int r = threadIdx.x; r < rows; r += 1024) {
+        const float4* p4 = reinterpret_cast<const float4*>(partial + (size_t)r * 12);
+        const float4 a = p4[0], b = p4[1], c = p4[2];
+        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w; acc[4] += b.x; acc[5] += b.y; acc[6] += b.z;
+        acc[7] += b.w; acc[8] += c.x; acc[9] += c.y; acc[10] += c.z; acc[11] += c.w;
     }
-    __shared__ float red[4][12];
-    __shared__ float ge[12];
+    for (int r = threadIdx.x; r < n_ssim; r += 1024) acc[13] += p_ssim[r];
+    for (int r = threadIdx.x; r < n_grad; r += 1024) {
+        const float4 q = reinterpret_cast<const float4*>(p_grad)[r];
+        acc[12] += q.x; acc[14] += q.y; acc[15] += q.z; acc[16] += q.w;
+    }
+    __shared__ float red[16][NV];
+    __shared__ float ge[NV];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) {
+    for (int k = 0; k < NV; ++k) {
         const float s = wave_sum_to_lane63(acc[k]);
         if (lane == 63) red[wid][k] = s;
     }
     __syncthreads();
-    if (threadIdx.x < 12) {
-        ge[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        d_extr_out[threadIdx.x] = ge[threadIdx.x];
+    if (threadIdx.x < NV) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += red[w][threadIdx.x];
+        ge[threadIdx.x] = t;
+        if (threadIdx.x < 12) d_extr_out[threadIdx.x] = t;
+        else sums[threadIdx.x - 12] = t;       // sums[0..4] as gfl_loss_fwd_bwd documents
     }
+    if (threadIdx.x >= NV && threadIdx.x < NV + 3) sums[threadIdx.x - NV + 5] = 0.f;
     __syncthreads();
     if (threadIdx.x == 0) {
         const int e = *d_step;
@@ -816,7 +829,7 @@ __global__ void __launch_bounds__(256) fused_camera_adam_kernel(const float* __r
             for (int k = 0; k < 7; ++k) pose[k] = adam_update(pose[k], gp[k], pose_m[k], pose_v[k], ac_cam, ss, isb);
             adam_scalars(ac_ab, e, ac_ab.lr, ss, isb);
 #pragma unroll
-            for (int k = 0; k < 2; ++k) depth_ab[k] = adam_update(depth_ab[k], sums[3 + k], ab_m[k], ab_v[k], ac_ab, ss, isb);
+            for (int k = 0; k < 2; ++k) depth_ab[k] = adam_update(depth_ab[k], ge[15 + k], ab_m[k], ab_v[k], ac_ab, ss, isb);
         }
         *d_step = e + 1;
     }
@@ -947,11 +960,13 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
     hipStream_t s = (hipStream_t)stream;
     const int gx = (st->W + GFL_TILE - 1) / GFL_TILE, gy = (st->H + GFL_TILE - 1) / GFL_TILE, T = gx * gy;
     const FitWs w = carve(st);
+    const float *p_ssim = nullptr, *p_grad = nullptr;
+    int n_ssim = 0, n_grad = 0;
     {
         StageScope p(ST_LOSS, s);
-        rc = gfl_loss_fwd_bwd(st->render, st->gt_rgb, st->gt_depth, st->keep, st->depth_ab, hp->lambda_rgb,
-                              hp->lambda_depth, st->W, st->H, st->d_render, st->err_px, st->sums, w.loss_ws,
-                              w.loss_ws_bytes, stream);
+        rc = gfl_loss_fwd_bwd_partials(st->render, st->gt_rgb, st->gt_depth, st->keep, st->depth_ab, hp->lambda_rgb,
+                                       hp->lambda_depth, st->W, st->H, st->d_render, st->err_px, w.loss_ws,
+                                       w.loss_ws_bytes, &p_ssim, &n_ssim, &p_grad, &n_grad, stream);
     }
     if (rc) return rc;
     {
@@ -977,9 +992,9 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
     }
     {
         StageScope p(ST_CAMERA, s);
-        fused_camera_adam_kernel<<<1, 256, 0, s>>>(w.partial, rows, st->pose, st->pose_m, st->pose_v, st->depth_ab,
-                                                   st->depth_ab_m, st->depth_ab_v, st->sums, ac_cam, ac, hp->step_camera,
-                                                   st->step, st->d_extr);
+        fused_camera_adam_kernel<<<1, 1024, 0, s>>>(w.partial, rows, p_ssim, n_ssim, p_grad, n_grad, st->pose, st->pose_m,
+                                                    st->pose_v, st->depth_ab, st->depth_ab_m, st->depth_ab_v, st->sums,
+                                                    ac_cam, ac, hp->step_camera, st->step, st->d_extr);
     }
     return check_launch();
 }

@@ -306,10 +306,11 @@ size_t gfl_loss_workspace_bytes(int W, int H) {
            align_up256(gx * gy * 4 * sizeof(float));
 }
 
-int gfl_loss_fwd_bwd(const float* render, const float* gt_rgb, const float* gt_depth, const uint8_t* keep,
-                     const float* depth_ab, float lambda_rgb, float lambda_depth, int W, int H, float* d_render,
-                     float* err_px, float* sums, void* workspace, size_t workspace_bytes, gfl_stream_t stream) {
-    if (W <= 0 || H <= 0 || !render || !gt_rgb || !d_render || !err_px || !sums || !workspace) return GFL_ERR_INVALID;
+static int loss_launch(const float* render, const float* gt_rgb, const float* gt_depth, const uint8_t* keep,
+                       const float* depth_ab, float lambda_rgb, float lambda_depth, int W, int H, float* d_render,
+                       float* err_px, float* sums, void* workspace, size_t workspace_bytes, gfl_stream_t stream,
+                       const float** p_ssim_out, int* n_ssim, const float** p_grad_out, int* n_grad) {
+    if (W <= 0 || H <= 0 || !render || !gt_rgb || !d_render || !err_px || !workspace) return GFL_ERR_INVALID;
     if (lambda_depth != 0.f && (!gt_depth || !depth_ab)) return GFL_ERR_INVALID;
     if (workspace_bytes < gfl_loss_workspace_bytes(W, H)) return GFL_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -325,8 +326,27 @@ int gfl_loss_fwd_bwd(const float* render, const float* gt_rgb, const float* gt_d
     loss_grad_kernel<<<dim3(gx, gy, 4), 256, 0, s>>>(render, gt_rgb, gt_depth, keep, depth_ab, dmaps, W, H, win,
                                                   lambda_rgb * 2.f / (3.f * hw), lambda_depth / hw, d_render, err_px,
                                                   p_grad);
-    loss_fold_kernel<<<1, 1024, 0, s>>>(p_ssim, gx * gy * 3, p_grad, gx * gy, sums);
+    if (sums) loss_fold_kernel<<<1, 1024, 0, s>>>(p_ssim, gx * gy * 3, p_grad, gx * gy, sums);
+    if (p_ssim_out) { *p_ssim_out = p_ssim; *n_ssim = gx * gy * 3; *p_grad_out = p_grad; *n_grad = gx * gy; }
     return check_launch();
+}
+
+int gfl_loss_fwd_bwd(const float* render, const float* gt_rgb, const float* gt_depth, const uint8_t* keep,
+                     const float* depth_ab, float lambda_rgb, float lambda_depth, int W, int H, float* d_render,
+                     float* err_px, float* sums, void* workspace, size_t workspace_bytes, gfl_stream_t stream) {
+    if (!sums) return GFL_ERR_INVALID;
+    return loss_launch(render, gt_rgb, gt_depth, keep, depth_ab, lambda_rgb, lambda_depth, W, H, d_render, err_px, sums,
+                       workspace, workspace_bytes, stream, nullptr, nullptr, nullptr, nullptr);
+}
+
+int gfl_loss_fwd_bwd_partials(const float* render, const float* gt_rgb, const float* gt_depth, const uint8_t* keep,
+                              const float* depth_ab, float lambda_rgb, float lambda_depth, int W, int H,
+                              float* d_render, float* err_px, void* workspace, size_t workspace_bytes,
+                              const float** p_ssim, int* n_ssim, const float** p_grad, int* n_grad,
+                              gfl_stream_t stream) {
+    if (!p_ssim || !n_ssim || !p_grad || !n_grad) return GFL_ERR_INVALID;
+    return loss_launch(render, gt_rgb, gt_depth, keep, depth_ab, lambda_rgb, lambda_depth, W, H, d_render, err_px,
+                       nullptr, workspace, workspace_bytes, stream, p_ssim, n_ssim, p_grad, n_grad);
 }
 
 }  // extern "C"

@@ -56,6 +56,15 @@ def _declare(lib):
     lib._fit_declared = True
 
 
+PROFILE = {"mask": 0}
+
+
+def set_profile(mask):
+    """Enable the library's per-stage HIP-event timing (bit i = stage i, include/gflow_hip.h)."""
+    PROFILE["mask"] = int(mask)
+    L.check(L.load().gfl_profile_enable(int(mask)), "profile")
+
+
 class FitEngine:
     def __init__(self, W, H, capacity, device, K_cap=None, bg=0.0):
         self.lib = L.load()
@@ -95,6 +104,8 @@ class FitEngine:
         self.flow_target = self.flow_w = self.still_target = self.still_w = self.row_flags = None
         self.cap = 0
         self.K_cap_req = K_cap
+        self._graph = self._graph_key = None
+        self._launched = False
         self._alloc(int(capacity))
 
     # ------------------------------------------------------------------ storage
@@ -193,9 +204,27 @@ class FitEngine:
         L.check(self.lib.gfl_fit_backward_step(ctypes.byref(self.state()), ctypes.byref(self.hp), L.stream()),
                 "fit backward/step")
 
-    def iteration(self):
+    def iteration(self, use_graph=False):
+        """One full iteration.  ``use_graph=True`` replays a hipGraph of the ~12 launches (captured
+        lazily, re-captured whenever a pointer, a size or a hyper-parameter changed); it is ignored
+        while the library's stage profiler is recording events."""
+        if use_graph and not PROFILE["mask"] and self._launched:
+            key = bytes(self.state()) + bytes(self.hp)
+            if self._graph is None or self._graph_key != key:
+                g = torch.cuda.CUDAGraph()
+                side = torch.cuda.Stream(device=self.dev)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    with torch.cuda.graph(g, stream=side):
+                        L.check(self.lib.gfl_fit_iteration(ctypes.byref(self.state()), ctypes.byref(self.hp),
+                                                           L.stream()), "fit iteration (capture)")
+                torch.cuda.current_stream().wait_stream(side)
+                self._graph, self._graph_key = g, key
+            self._graph.replay()
+            return
         L.check(self.lib.gfl_fit_iteration(ctypes.byref(self.state()), ctypes.byref(self.hp), L.stream()),
                 "fit iteration")
+        self._launched = True          # every kernel is loaded now: capture is safe from here on
 
     # ------------------------------------------------------------------ outputs
     @property

@@ -81,6 +81,7 @@ class SimpleGaussian:
         (gflow_amd/fused.py); ``fused=False`` composes the msplat-compatible autograd operators
         the way the reference does (slower, same results)."""
         self.fused = bool(fused)
+        self.use_graph = True          # replay the fused iteration as a hipGraph when nothing else happens in it
         self.engine = None
         self.device = torch.device(device if device is not None else "cuda")
         if self.device.type != "cuda":
@@ -476,15 +477,18 @@ class SimpleGaussian:
                     mm = (grey > 0.0) | move_mask
                 st.move_mask = mm
                 eng.keep.copy_((~mm).to(torch.uint8))
-            eng.forward()
+            if snap or tentative:
+                eng.forward()
+                if snap:
+                    with torch.no_grad():
+                        extras = extras_from_engine()
+                    st.frames.append(render_mod.render2img(eng.render[:3]))
+                    st.frames_depth.append(render_mod.render2img(extras[0]))
+                    st.frames_center.append(render_mod.render2img(extras[1]))
+                eng.backward_step()
+            else:
+                eng.iteration(use_graph=self.use_graph)      # one call (or one hipGraph replay)
             self.rasterisations_done += 1
-            if snap:
-                with torch.no_grad():
-                    extras = extras_from_engine()
-                st.frames.append(render_mod.render2img(eng.render[:3]))
-                st.frames_depth.append(render_mod.render2img(extras[0]))
-                st.frames_center.append(render_mod.render2img(extras[1]))
-            eng.backward_step()
             self.iterations_done += 1
             if log_interval and iteration % log_interval == 0:
                 l_rgb, l_depth = eng.loss_terms()

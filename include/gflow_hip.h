@@ -135,6 +135,14 @@ int gfl_colormap_nonzero(const float* value, int N, const float* lut, float* out
  *          (un-normalised sums; the d/d terms already carry lambda_depth / (H*W)).
  * workspace: gfl_loss_workspace_bytes(W,H). */
 size_t gfl_loss_workspace_bytes(int W, int H);
+/* same kernels, but the scalar sums are left as per-block partial rows inside `workspace`
+ * (p_ssim[n_ssim] floats: SSIM-map sums; p_grad[n_grad][4] floats: mse, depth term, d/d depth_a,
+ * d/d depth_b) for a consumer that folds them itself (the fused iteration's camera kernel) */
+int gfl_loss_fwd_bwd_partials(const float* render, const float* gt_rgb, const float* gt_depth, const uint8_t* keep,
+                              const float* depth_ab, float lambda_rgb, float lambda_depth, int W, int H,
+                              float* d_render, float* err_px, void* workspace, size_t workspace_bytes,
+                              const float** p_ssim, int* n_ssim, const float** p_grad, int* n_grad,
+                              gfl_stream_t stream);
 int gfl_loss_fwd_bwd(const float* render, const float* gt_rgb, const float* gt_depth, const uint8_t* keep,
                      const float* depth_ab, float lambda_rgb, float lambda_depth, int W, int H,
                      float* d_render, float* err_px, float* sums, void* workspace, size_t workspace_bytes,

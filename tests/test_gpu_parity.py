@@ -142,6 +142,23 @@ def test_sort_matches_oracle_exactly(scene):
     assert torch.equal(ids_g.cpu(), ids_c)
 
 
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 300, 512, 513, 700, 1024, 1500, 2048, 3000, 4096, 4097])
+def test_sort_every_register_tier(n):
+    """Tile lists of every size class of the register sort (1, 2, 4, 8, 16 keys per lane) and the
+    global-memory fallback, with depth ties."""
+    ms = _ms()
+    W, H = 32, 32
+    g = torch.Generator().manual_seed(n)
+    uv = 8 + 16 * torch.rand(n, 2, generator=g)
+    depth = 1 + torch.rand(n, 1, generator=g)
+    depth[::7] = depth[0].clone()                           # ties -> id order
+    radius = torch.full((n, 1), 40, dtype=torch.int32)
+    tiles = torch.full((n, 1), 4, dtype=torch.int32)
+    ids_c, tr_c = MO.sort_gaussian(uv, depth, W, H, radius, tiles)
+    ids_g, tr_g = ms.sort_gaussian(uv.to(DEV), depth.to(DEV), W, H, radius.to(DEV), tiles.to(DEV))
+    assert torch.equal(tr_g.cpu(), tr_c) and torch.equal(ids_g.cpu(), ids_c)
+
+
 def test_sort_large_tile_uses_global_fallback():
     ms = _ms()
     # 6000 splats all covering the same 2x2 tiles: segments longer than the LDS capacity
