@@ -63,6 +63,17 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// XCD-aware block order.  The dispatcher is observed to place workgroup b on XCD b % 8
+// (MI355X_MICROARCH.md, "Workgroup dispatch"); each XCD has its own 4 MB L2.  Kernels whose
+// neighbouring blocks share data (stencil halos, splat records of adjacent tiles) therefore walk
+// their work in this order: XCD x owns one contiguous range of logical block ids.  Speed only --
+// the map is a bijection on [0, nb) whatever the real placement is.
+__device__ __forceinline__ int xcd_logical_block(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7;
+    const int x = b & 7, i = b >> 3;
+    return x * q + min(x, r) + i;
+}
+
 // Reduce-scatter of ten per-lane values over the wave (blend backward: du dv dA dB dC do df0..3).
 // gfx950's v_permlane32_swap / v_permlane16_swap exchange half-waves / rows between two
 // registers, so "swap + add" halves the number of live values while summing lane pairs:

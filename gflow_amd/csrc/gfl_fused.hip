@@ -353,6 +353,8 @@ __global__ void __launch_bounds__(256, 8) fused_blend_fwd_kernel(const float* __
                                                               int32_t* __restrict__ n_contrib) {
     __shared__ RecLDS recs[FB];
     __shared__ unsigned char s_mask[FB];
+    // plain block order: an XCD-contiguous tile order (xcd_logical_block) was measured 10-15 % slower,
+    // bands of the image carry unequal splat counts and the XCD with the densest band finishes last
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -449,6 +451,8 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
     __shared__ float acc[FBB][REC];
     __shared__ unsigned char s_mask[FBB];
     __shared__ int32_t s_max_last;
+    // plain block order: an XCD-contiguous tile order (xcd_logical_block) was measured 10-15 % slower,
+    // bands of the image carry unequal splat counts and the XCD with the densest band finishes last
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;

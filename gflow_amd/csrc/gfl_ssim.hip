@@ -63,17 +63,20 @@ __device__ __forceinline__ float ld_gt(const float* __restrict__ gt_rgb, const u
     return (keep && !keep[pix]) ? 0.f : v;
 }
 
-// grid (gx, gy, 3); dmaps[3 channels][3 maps][H][W]; partial[block] = sum of S
+// grid gx*gy*3 blocks in XCD order, the three channel blocks of a tile adjacent (they share the
+// HWC ground-truth lines); dmaps[3 channels][3 maps][H][W]; partial[block] = sum of S
 __global__ void __launch_bounds__(256) ssim_stats_kernel(const float* __restrict__ render,
                                                          const float* __restrict__ gt_rgb,
-                                                         const uint8_t* __restrict__ keep, int W, int H, Win win,
-                                                         float scale /* dL/dS per element */,
+                                                         const uint8_t* __restrict__ keep, int W, int H, int gx,
+                                                         int gy, Win win, float scale /* dL/dS per element */,
                                                          float* __restrict__ dmaps, float* __restrict__ partial) {
     __shared__ float sx[SI][SI + 1];
     __shared__ float sy[SI][SI + 1];
     __shared__ float hz[5][SI][ST + 1];
-    const int c = blockIdx.z;
-    const int x0 = blockIdx.x * ST - SR, y0 = blockIdx.y * ST - SR;
+    const int lb = xcd_logical_block(blockIdx.x, gx * gy * 3);
+    const int c = lb % 3, tile = lb / 3;
+    const int bx = tile % gx, by = tile / gx;
+    const int x0 = bx * ST - SR, y0 = by * ST - SR;
     const int tid = threadIdx.x;
     for (int i = tid; i < SI * SI; i += 256) {
         const int r = i / SI, q = i - r * SI;
@@ -97,7 +100,7 @@ __global__ void __launch_bounds__(256) ssim_stats_kernel(const float* __restrict
     }
     __syncthreads();
     const int lx = tid & 15, ly = tid >> 4;
-    const int px = blockIdx.x * ST + lx, py = blockIdx.y * ST + ly;
+    const int px = bx * ST + lx, py = by * ST + ly;
     float sval = 0.f;
     if (px < W && py < H) {
         float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
@@ -126,7 +129,7 @@ __global__ void __launch_bounds__(256) ssim_stats_kernel(const float* __restrict
         base[2 * plane + pix] = scale * d_e12;
     }
     float v[1] = {sval};
-    const int bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int bid = c * gx * gy + tile;
     // block_reduce_store indexes by blockIdx.x only -> reduce by hand here
     __shared__ float red[4];
     const float s = wave_sum_to_lane63(v[0]);
@@ -135,20 +138,24 @@ __global__ void __launch_bounds__(256) ssim_stats_kernel(const float* __restrict
     if (tid == 0) partial[bid] = red[0] + red[1] + red[2] + red[3];
 }
 
-// grid (gx, gy, 4): z < 3 -> gradient of one rgb plane; z == 3 -> depth plane + per-pixel mse.
+// grid gx*gy*4 blocks in XCD order, the four blocks of a tile adjacent: 0..2 -> gradient of one
+// rgb plane; 3 -> depth plane + per-pixel mse.
 // partial rows: [block][4] = {sum mse_px, sum depth term, d/d depth_a, d/d depth_b}
 __global__ void __launch_bounds__(256) loss_grad_kernel(
     const float* __restrict__ render, const float* __restrict__ gt_rgb, const float* __restrict__ gt_depth,
     const uint8_t* __restrict__ keep, const float* __restrict__ depth_ab, const float* __restrict__ dmaps, int W, int H,
-    Win win, float mse_scale /* lambda_rgb * 2/(3HW) */, float depth_scale /* lambda_depth/(HW) */,
+    int gx, int gy, Win win, float mse_scale /* lambda_rgb * 2/(3HW) */, float depth_scale /* lambda_depth/(HW) */,
     float* __restrict__ d_render, float* __restrict__ err_px, float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float sm[3][SI][SP];
     __shared__ __attribute__((aligned(16))) float hz[3][SI][HP];
     const int tid = threadIdx.x;
     const size_t plane = (size_t)H * W;
-    if (blockIdx.z == 3) {
+    const int lb = xcd_logical_block(blockIdx.x, gx * gy * 4);
+    const int ch = lb & 3, tile = lb >> 2;
+    const int bx = tile % gx, by = tile / gx;
+    if (ch == 3) {
         const int lx = tid & 15, ly = tid >> 4;
-        const int px = blockIdx.x * ST + lx, py = blockIdx.y * ST + ly;
+        const int px = bx * ST + lx, py = by * ST + ly;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (px < W && py < H) {
             const size_t pix = (size_t)py * W + px;
@@ -185,11 +192,10 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(
             if ((tid & 63) == 63) red[tid >> 6][q] = s;
         }
         __syncthreads();
-        if (tid < 4) partial[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        if (tid < 4) partial[(size_t)tile * 4 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
         return;
     }
-    const int ch = blockIdx.z;
-    const int x0 = blockIdx.x * ST - SR, y0 = blockIdx.y * ST - SR;
+    const int x0 = bx * ST - SR, y0 = by * ST - SR;
     const float* base = dmaps + (size_t)ch * 3 * plane;
     for (int i = tid; i < SI * SP; i += 256) {
         const int r = i / SP, q = i - r * SP;
@@ -220,7 +226,7 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(
     // column pass: item = (pair of rows, column): 128 lanes
     if (tid < 128) {
         const int r0 = (tid >> 4) * 2, col = tid & 15;
-        const int px = blockIdx.x * ST + col;
+        const int px = bx * ST + col;
         float g[3][2];
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
@@ -237,7 +243,7 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(
         }
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
-            const int py = blockIdx.y * ST + r0 + o;
+            const int py = by * ST + r0 + o;
             if (px < W && py < H) {
                 const size_t pix = (size_t)py * W + px;
                 float out = 0.f;
@@ -321,11 +327,11 @@ static int loss_launch(const float* render, const float* gt_rgb, const float* gt
     static const Win win = make_window();
     const float hw = (float)W * (float)H;
     // L = lambda_rgb * (mean mse + 1 - mean S)  ->  dL/dS = -lambda_rgb / (3HW)
-    ssim_stats_kernel<<<dim3(gx, gy, 3), 256, 0, s>>>(render, gt_rgb, keep, W, H, win, -lambda_rgb / (3.f * hw), dmaps,
-                                                   p_ssim);
-    loss_grad_kernel<<<dim3(gx, gy, 4), 256, 0, s>>>(render, gt_rgb, gt_depth, keep, depth_ab, dmaps, W, H, win,
-                                                  lambda_rgb * 2.f / (3.f * hw), lambda_depth / hw, d_render, err_px,
-                                                  p_grad);
+    ssim_stats_kernel<<<gx * gy * 3, 256, 0, s>>>(render, gt_rgb, keep, W, H, gx, gy, win, -lambda_rgb / (3.f * hw),
+                                               dmaps, p_ssim);
+    loss_grad_kernel<<<gx * gy * 4, 256, 0, s>>>(render, gt_rgb, gt_depth, keep, depth_ab, dmaps, W, H, gx, gy, win,
+                                              lambda_rgb * 2.f / (3.f * hw), lambda_depth / hw, d_render, err_px,
+                                              p_grad);
     if (sums) loss_fold_kernel<<<1, 1024, 0, s>>>(p_ssim, gx * gy * 3, p_grad, gx * gy, sums);
     if (p_ssim_out) { *p_ssim_out = p_ssim; *n_ssim = gx * gy * 3; *p_grad_out = p_grad; *n_grad = gx * gy; }
     return check_launch();

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Profile the default bench workload on the GPU box:
+#   pass 1  rocprofv3 --kernel-trace --stats      -> per-kernel durations
+#   pass 2  rocprofv3 --pmc FETCH_SIZE            -> HBM read bytes per launch   (own pass)
+#   pass 3  rocprofv3 --pmc WRITE_SIZE            -> HBM write bytes per launch  (own pass)
+# then tools/summarise_profile.py folds the three into gpurun_out/<tag>_summary.json.
+#   gpurun --timeout 900 -- 'bash tools/profile_round.sh r01b'
+# Copy the summary + kernel stats into profiles/ afterwards (gpurun_out/ is scratch).
+set -u
+TAG=${1:-prof}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+BENCH="python $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-stage-pass"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o r -- $BENCH > "$OUT/bench_trace.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o r -- $BENCH > "$OUT/bench_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o r -- $BENCH > "$OUT/bench_write.log" 2>&1
+cd "$ROOT"
+python tools/summarise_profile.py "$OUT" > "$OUT/../${TAG}_summary.json"
+cat "$OUT/../${TAG}_summary.json"
