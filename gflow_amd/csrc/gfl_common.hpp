@@ -87,10 +87,10 @@ __device__ __forceinline__ int xcd_logical_block(int b, int nb) {
 // elements of its result (verified on hardware), so the swaps are issued as inline asm; the
 // leading s_nop covers the VALU-write -> permlane-read hazard that hipcc does not pad inside asm.
 __device__ __forceinline__ void permlane32_swap(float& a, float& b) {
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 __device__ __forceinline__ void permlane16_swap(float& a, float& b) {
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
 __device__ __forceinline__ float wave_reduce_scatter10(const float (&v)[10], int lane, int& comp) {

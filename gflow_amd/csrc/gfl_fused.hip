@@ -23,6 +23,9 @@
 //                 order is independent of the LDS-atomic arrival order.
 #include "gfl_math.hpp"
 #include "gfl_profile.hpp"
+#include "gfl_sched.hpp"
+
+#include <stdlib.h>
 
 namespace gfl {
 
@@ -223,15 +226,23 @@ __global__ void __launch_bounds__(256) bin_colscan_kernel(int32_t* __restrict__ 
     }
 }
 
+static_assert(SCHED_BLOCK == BIN_BLOCK, "the tile scheduler runs as one extra block of the scatter launch");
+
 __global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* __restrict__ rec, int N, int gx, int gy,
                                                                   const int32_t* __restrict__ hist_g,
                                                                   const int32_t* __restrict__ tile_counts,
                                                                   int32_t* __restrict__ tile_offsets, int K_cap,
                                                                   unsigned long long* __restrict__ keys,
-                                                                  int32_t* __restrict__ overflow) {
+                                                                  int32_t* __restrict__ overflow,
+                                                                  Sched sched) {
     extern __shared__ int32_t cursor[];
     __shared__ int32_t wsum[BIN_BLOCK / 64];
     const int T = gx * gy;
+    if (blockIdx.x == gridDim.x - 1) {
+        // one extra workgroup (the launch leaves CUs idle) builds the blend kernels' tile queues
+        schedule_tiles(tile_counts, T, sched, cursor, wsum);
+        return;
+    }
     const int32_t* base_row = hist_g + (size_t)blockIdx.x * T;
     {
         // every block scans the T tile totals itself (a few elements per thread); block 0
@@ -310,6 +321,7 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* _
 }
 
 // ------------------------------------------------------------------- blend (C = 4)
+constexpr int BLEND_WG_PER_CU = 8;
 constexpr int FB = 256;   // staged splats per batch (forward)
 constexpr int FBB = 192;  // backward: 18.6 KB of LDS per workgroup -> 8 workgroups per CU, so that all
                           // 1620 tiles of a 480p frame are resident at once (no second round)
@@ -350,19 +362,27 @@ __global__ void __launch_bounds__(256, 8) fused_blend_fwd_kernel(const float* __
                                                               const int32_t* __restrict__ tile_range, float bg, int W,
                                                               int H, int gx, float* __restrict__ out,
                                                               float* __restrict__ final_T,
-                                                              int32_t* __restrict__ n_contrib) {
+                                                              int32_t* __restrict__ n_contrib, TileQueue queue,
+                                                              float* __restrict__ ckpt) {
     __shared__ RecLDS recs[FB];
     __shared__ unsigned char s_mask[FB];
-    // plain block order: an XCD-contiguous tile order (xcd_logical_block) was measured 10-15 % slower,
-    // bands of the image carry unequal splat counts and the XCD with the densest band finishes last
-    const int tile = blockIdx.x;
-    const int tx = tile % gx, ty = tile / gx;
+    __shared__ int32_t s_ticket;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (bool first = true;; first = false) {
+    const TileItem item = next_item(queue, &s_ticket, first, false);
+    const int tile = item.tile;
+    if (tile < 0) break;
+    const int tx = tile % gx, ty = tile / gx;
     const int px = tx * GFL_TILE + (wave & 1) * 8 + (lane & 7);
     const int py = ty * GFL_TILE + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
     const float fx = (float)px, fy = (float)py;
     const int start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
+    // the queue's heavy tile: leave the per-pixel state at the split position for the backward pass
+    const bool heavy = first && blockIdx.x < (unsigned)queue.nq;
+    const int split = heavy ? heavy_split(end - start) : 0;
+    float* ck = ckpt + (size_t)item.queue * 5 * 256 + tid;
+    bool ck_open = split > 0;
 
     float T = 1.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int last = 0;
@@ -383,6 +403,10 @@ __global__ void __launch_bounds__(256, 8) fused_blend_fwd_kernel(const float* __
         if (__all(done)) continue;      // this wave is finished; keep meeting the barriers
         for (int c0 = 0; c0 < cnt; c0 += 64) {
             if (__all(done)) break;
+            if (ck_open && base - start + c0 == split) {
+                ck[0] = T; ck[256] = a0; ck[512] = a1; ck[768] = a2; ck[1024] = a3;
+                ck_open = false;
+            }
             const int slot = c0 + lane;
             const bool hit = slot < cnt && ((s_mask[slot] >> wave) & 1);
             unsigned long long bits = __ballot(hit);
@@ -435,7 +459,39 @@ __global__ void __launch_bounds__(256, 8) fused_blend_fwd_kernel(const float* __
         final_T[pix] = T;
         n_contrib[pix] = last;
     }
+    // the wave stopped before the split position: every pixel's state is frozen, final = checkpoint
+    if (ck_open) { ck[0] = T; ck[256] = a0; ck[512] = a1; ck[768] = a2; ck[1024] = a3; }
+  }
 }
+
+// gradient terms of one (pixel, splat) pair; branch-free: a lane that does not see the splat uses
+// alpha = 0 (T, S unchanged, every term exactly 0).  v = du dv dA dB dC do df0..3
+__device__ __forceinline__ void blend_bwd_terms(const float4& p0, const float4& p1, const float4& p2, float fx, float fy,
+                                                bool valid, float alpha, float G, float g0, float g1, float g2, float g3,
+                                                float& T, float& S, float (&v)[10]) {
+    const float a_eff = valid ? alpha : 0.f;
+    const float rom = __builtin_amdgcn_rcpf(1.f - a_eff);
+    T = T * rom;
+    const float h = fmaf(g0, p1.z, fmaf(g1, p1.w, fmaf(g2, p2.x, g3 * p2.y)));
+    const float dalpha = valid ? fmaf(T, h, -(S * rom)) : 0.f;
+    const float w = a_eff * T;
+    S = fmaf(h, w, S);
+    v[6] = w * g0; v[7] = w * g1; v[8] = w * g2; v[9] = w * g3;
+    const float dx = p0.x - fx, dy = p0.y - fy;
+    v[5] = G * dalpha;
+    const float dpow = p1.y * v[5];
+    const float mx = -dx * dpow, my = -dy * dpow;
+    v[2] = 0.5f * dx * mx;
+    v[4] = 0.5f * dy * my;
+    v[3] = dx * my;
+    v[0] = fmaf(p0.z, mx, p0.w * my);
+    v[1] = fmaf(p1.x, my, p0.w * mx);
+}
+
+#ifdef GFL_TRACE
+// analysis build only (make TRACE=1): per-tile timeline of the backward blend
+__device__ long long g_bwd_trace[16384 * 8];
+#endif
 
 __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __restrict__ rec,
                                                               const int32_t* __restrict__ ids,
@@ -443,7 +499,10 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
                                                               int H, int gx, const float* __restrict__ final_T,
                                                               const int32_t* __restrict__ n_contrib,
                                                               const float* __restrict__ d_out,
-                                                              float* __restrict__ pair_grad) {
+                                                              float* __restrict__ pair_grad, TileQueue queue,
+                                                              int32_t* __restrict__ tile_work,
+                                                              const float* __restrict__ ckpt,
+                                                              const float* __restrict__ render) {
     // No global atomics: the four waves of the tile combine their per-splat sums in LDS and the
     // tile writes ONE 48-byte row per (splat, tile) pair at the pair's list position with plain,
     // coalesced stores.  The per-splat kernel gathers its rows afterwards (deterministic).
@@ -451,28 +510,47 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
     __shared__ float acc[FBB][REC];
     __shared__ unsigned char s_mask[FBB];
     __shared__ int32_t s_max_last;
-    // plain block order: an XCD-contiguous tile order (xcd_logical_block) was measured 10-15 % slower,
-    // bands of the image carry unequal splat counts and the XCD with the densest band finishes last
-    const int tile = blockIdx.x;
-    const int tx = tile % gx, ty = tile / gx;
+    __shared__ int32_t s_units;
+    __shared__ int32_t s_ticket;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (bool first = true;; first = false) {
+    const TileItem item = next_item(queue, &s_ticket, first, true);
+    const int tile = item.tile;
+    if (tile < 0) break;
+    const int tx = tile % gx, ty = tile / gx;
     const int px = tx * GFL_TILE + (wave & 1) * 8 + (lane & 7);
     const int py = ty * GFL_TILE + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
     const float fx = (float)px, fy = (float)py;
     const int start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
     const int total = end - start;
+    const int split = item.part ? heavy_split(total) : 0;
+    if (item.part == 2 && split == 0) continue;      // short heavy tile: the far "half" did all of it
+    const bool near_half = item.part == 2;
+    int units = 0;
+#ifdef GFL_TRACE
+    const long long trace_t0 = wall_clock64();
+#endif
 
     float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, T = 1.f, S = 0.f;
     int last = 0;
     if (inside) {
         const size_t pix = (size_t)py * W + px, plane = (size_t)H * W;
-        T = final_T[pix];
         last = n_contrib[pix];
         g0 = d_out[pix]; g1 = d_out[plane + pix]; g2 = d_out[2 * plane + pix]; g3 = d_out[3 * plane + pix];
-        S = T * bg * (g0 + g1 + g2 + g3);
+        if (!near_half) {
+            T = final_T[pix];
+            S = T * bg * (g0 + g1 + g2 + g3);
+        } else {
+            // state after list position split - 1, from the forward checkpoint: T as it was there
+            // and S = sum_c g_c * (everything blended behind it) = sum_c g_c * (out_c - C_c)
+            const float* ck = ckpt + (size_t)item.queue * 5 * 256 + tid;
+            T = ck[0];
+            S = g0 * (render[pix] - ck[256]) + g1 * (render[plane + pix] - ck[512]) +
+                g2 * (render[2 * plane + pix] - ck[768]) + g3 * (render[3 * plane + pix] - ck[1024]);
+        }
     }
-    if (tid == 0) s_max_last = 0;
+    if (tid == 0) { s_max_last = 0; s_units = 0; }
     __syncthreads();
     int wave_last = last;
 #pragma unroll
@@ -482,16 +560,21 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
     const int depth_n = min(total, (int)s_max_last);
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // pairs behind the deepest contributor of the tile get a zero row
-    for (int p = depth_n + tid; p < total; p += 256) {
-        float4* o = reinterpret_cast<float4*>(pair_grad + (size_t)(start + p) * REC);
-        o[0] = zero4; o[1] = zero4; o[2] = zero4;
-    }
+    // this item walks list positions hi-1 down to lo
+    const int lo = (split && !near_half) ? split : 0;
+    const int hi = near_half ? min(split, depth_n) : depth_n;
 
-    for (int r0 = 0; r0 < depth_n; r0 += FBB) {
-        const int pos_t = tid < FBB ? depth_n - 1 - r0 - tid : -1;     // slot tid <-> list position pos_t
+    // pairs behind the deepest contributor of the tile get a zero row
+    if (!near_half)
+        for (int p = depth_n + tid; p < total; p += 256) {
+            float4* o = reinterpret_cast<float4*>(pair_grad + (size_t)(start + p) * REC);
+            o[0] = zero4; o[1] = zero4; o[2] = zero4;
+        }
+
+    for (int r0 = 0; r0 < hi - lo; r0 += FBB) {
+        const int pos_t = tid < FBB ? hi - 1 - r0 - tid : -1;          // slot tid <-> list position pos_t
         __syncthreads();
-        if (pos_t >= 0) {
+        if (pos_t >= lo) {
             const int g = ids[start + pos_t];
             const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g * REC);
             const float4 p0 = r4[0], p1 = r4[1], p2 = r4[2];
@@ -503,52 +586,55 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
             az[0] = zero4; az[1] = zero4; az[2] = zero4;
         }
         __syncthreads();
-        const int cnt = min(FBB, depth_n - r0);
+        const int cnt = min(FBB, hi - lo - r0);
         for (int c0 = 0; c0 < cnt; c0 += 64) {
             const int slot = c0 + lane;
-            const int spos = depth_n - 1 - r0 - slot;
+            const int spos = hi - 1 - r0 - slot;
             const bool hit = slot < cnt && spos < wave_last && ((s_mask[slot] >> wave) & 1);
             unsigned long long bits = __ballot(hit);
             while (bits) {
                 const int j = c0 + (int)__builtin_ctzll(bits);
                 bits &= bits - 1;
-                const int pos = depth_n - 1 - r0 - j;
+                const int pos = hi - 1 - r0 - j;
                 const float4 p0 = recs[j].p0, p1 = recs[j].p1, p2 = recs[j].p2;
                 float alpha, G;
                 const bool valid = splat_alpha2(p0, p1, fx, fy, alpha, G) && (pos < last);
                 if (__ballot(valid) == 0ull) continue;
-                // branch-free: a lane that does not see this splat uses alpha = 0 (T, S unchanged,
-                // every gradient term exactly 0)
-                const float a_eff = valid ? alpha : 0.f;
-                const float rom = __builtin_amdgcn_rcpf(1.f - a_eff);
-                T = T * rom;
-                const float h = fmaf(g0, p1.z, fmaf(g1, p1.w, fmaf(g2, p2.x, g3 * p2.y)));
-                const float dalpha = valid ? fmaf(T, h, -(S * rom)) : 0.f;
-                const float w = a_eff * T;
-                S = fmaf(h, w, S);
+                ++units;                     // wave-uniform: work feedback for the tile scheduler
+                // (an interleaved two-splat version of this body was measured slower, twice)
                 float v[10];
-                v[6] = w * g0; v[7] = w * g1; v[8] = w * g2; v[9] = w * g3;
-                const float dx = p0.x - fx, dy = p0.y - fy;
-                v[5] = G * dalpha;
-                const float dpow = p1.y * v[5];
-                const float mx = -dx * dpow, my = -dy * dpow;
-                v[2] = 0.5f * dx * mx;
-                v[4] = 0.5f * dy * my;
-                v[3] = dx * my;
-                v[0] = fmaf(p0.z, mx, p0.w * my);
-                v[1] = fmaf(p1.x, my, p0.w * mx);
+                blend_bwd_terms(p0, p1, p2, fx, fy, valid, alpha, G, g0, g1, g2, g3, T, S, v);
                 int comp;
                 const float mine = wave_reduce_scatter10(v, lane, comp);
                 if (comp >= 0) atomicAdd(&acc[j][comp], mine);
             }
         }
         __syncthreads();
-        if (pos_t >= 0) {
+        if (pos_t >= lo) {
             const float4* a4 = reinterpret_cast<const float4*>(&acc[tid][0]);
             float4* o = reinterpret_cast<float4*>(pair_grad + (size_t)(start + pos_t) * REC);
             o[0] = a4[0]; o[1] = a4[1]; o[2] = a4[2];
         }
     }
+    // work feedback for the next iteration's schedule (gfl_sched.hpp)
+    if (lane == 0) atomicAdd(&s_units, units);
+    __syncthreads();
+    if (tid == 0) atomicAdd(&tile_work[tile], s_units + 2);
+#ifdef GFL_TRACE
+    if (lane == 0 && tile < 8192) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        long long* tr = g_bwd_trace + (size_t)(tile + (near_half ? 8192 : 0)) * 8;
+        if (wave == 0) {
+            tr[0] = trace_t0; tr[1] = wall_clock64();
+            tr[2] = ((long long)total << 32) | (unsigned)depth_n;
+            tr[3] = ((long long)(xcc & 15) << 32) | hw;
+        }
+        tr[4 + wave] = (unsigned)units;
+    }
+#endif
+  }
 }
 
 // ------------------------------------------------- preprocess backward + Adam (A13)
@@ -852,6 +938,27 @@ size_t gfl_loss_workspace_bytes(int W, int H);
 
 static inline int fit_nblk(int N) { return (N + BIN_BLOCK - 1) / BIN_BLOCK; }
 
+// one tile queue per CU (the dispatcher places workgroup b on CU b % CUs, tools/placement_probe.hip)
+static int blend_queues() {
+    static int nq = 0;
+    if (!nq) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        nq = cus < SCHED_MAX_QUEUES ? cus : SCHED_MAX_QUEUES;
+    }
+    return nq;
+}
+
+// workgroups of a blend launch: up to 8 per queue (all resident), fewer for small tile grids
+static int blend_grid(int T) {
+    const int nq = blend_queues();
+    int per = (T + nq - 1) / nq + 1;
+    if (per > BLEND_WG_PER_CU) per = BLEND_WG_PER_CU;
+    return nq * per;
+}
+
 size_t gfl_fit_workspace_bytes(int cap, int K_cap, int W, int H) {
     if (cap < 0 || K_cap < 0 || W <= 0 || H <= 0) return 0;
     const size_t T = (size_t)((W + GFL_TILE - 1) / GFL_TILE) * ((H + GFL_TILE - 1) / GFL_TILE);
@@ -861,7 +968,11 @@ size_t gfl_fit_workspace_bytes(int cap, int K_cap, int W, int H) {
            + up256(T * sizeof(int32_t))                                             // tile totals
            + up256((size_t)K_cap * REC * sizeof(float))                             // per-pair gradient rows
            + up256((size_t)(cap > 0 ? cap : 1) * SLOT_MAX * sizeof(int32_t))        // slot -> list position
-           + 256 + up256((size_t)K_cap * sizeof(int32_t))                          // pool counter + slot pool
+           + 256 + up256((size_t)K_cap * sizeof(int32_t))                          // counters + slot pool
+           + 2 * up256(T * sizeof(int32_t))                                         // scheduler: work, order
+           + up256((T + SCHED_MAX_QUEUES) * sizeof(int32_t))                        // queue items
+           + up256(2 * SCHED_MAX_QUEUES * sizeof(int32_t))                          // pull counters
+           + up256((size_t)SCHED_MAX_QUEUES * 5 * 256 * sizeof(float))                  // heavy-tile checkpoints
            + up256(gfl_loss_workspace_bytes(W, H)) + 256;
 }
 
@@ -874,6 +985,8 @@ struct FitWs {
     int32_t* slot_inv;
     int32_t* slot_pool;
     int32_t* pool_counter;
+    Sched sched;             // tile queues of the blend kernels; sched.work persists between calls
+    float* ckpt;             // [queue][T a0 a1 a2 a3][256 pixels] forward state at the heavy tile's split
     void* loss_ws;
     size_t loss_ws_bytes;
 };
@@ -898,6 +1011,17 @@ static FitWs carve(const gfl_fit_state* st) {
     p += 256;
     w.slot_pool = (int32_t*)p;
     p += up256((size_t)st->K_cap * sizeof(int32_t));
+    w.sched.work = (int32_t*)p;
+    p += up256(T * sizeof(int32_t));
+    w.sched.order = (int32_t*)p;
+    p += up256(T * sizeof(int32_t));
+    w.sched.seq = (int32_t*)p;
+    p += up256((T + SCHED_MAX_QUEUES) * sizeof(int32_t));
+    w.sched.counters = (int32_t*)p;
+    p += up256(2 * SCHED_MAX_QUEUES * sizeof(int32_t));
+    w.ckpt = (float*)p;
+    p += up256((size_t)SCHED_MAX_QUEUES * 5 * 256 * sizeof(float));
+    w.sched.nq = blend_queues();
     w.loss_ws = p;
     w.loss_ws_bytes = up256(gfl_loss_workspace_bytes(st->W, st->H));
     return w;
@@ -938,8 +1062,8 @@ int gfl_fit_forward(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream
     }
     {
         StageScope p(ST_SCATTER, s);
-        fused_scatter_kernel<<<nblk, BIN_BLOCK, lds, s>>>(st->rec, st->N, gx, gy, w.hist, w.tile_counts, st->tile_offsets,
-                                                          st->K_cap, w.keys, st->overflow);
+        fused_scatter_kernel<<<nblk + 1, BIN_BLOCK, lds, s>>>(st->rec, st->N, gx, gy, w.hist, w.tile_counts,
+                                                              st->tile_offsets, st->K_cap, w.keys, st->overflow, w.sched);
     }
     {
         StageScope p(ST_TILE_SORT, s);
@@ -949,8 +1073,9 @@ int gfl_fit_forward(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream
     if (rc) return rc;
     {
         StageScope p(ST_BLEND_FWD, s);
-        fused_blend_fwd_kernel<<<T, 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx, st->render,
-                                                 st->final_T, st->n_contrib);
+        const TileQueue q = {w.sched.seq, w.sched.counters, w.sched.nq, sched_rounds(T, w.sched.nq)};
+        fused_blend_fwd_kernel<<<blend_grid(T), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx,
+                                                             st->render, st->final_T, st->n_contrib, q, w.ckpt);
     }
     return check_launch();
 }
@@ -975,8 +1100,10 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
     if (rc) return rc;
     {
         StageScope p(ST_BLEND_BWD, s);
-        fused_blend_bwd_kernel<<<T, 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx, st->final_T,
-                                                 st->n_contrib, st->d_render, w.pair_grad);
+        const TileQueue q = {w.sched.seq, w.sched.counters + w.sched.nq, w.sched.nq, sched_rounds(T, w.sched.nq)};
+        fused_blend_bwd_kernel<<<blend_grid(T), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx,
+                                                             st->final_T, st->n_contrib, st->d_render, w.pair_grad, q,
+                                                             w.sched.work, w.ckpt, st->render);
     }
     const int rows = reduce_rows(st->N > 0 ? st->N : 1);
     RegCfg rcfg;
@@ -1008,5 +1135,11 @@ int gfl_fit_iteration(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stre
     if (rc) return rc;
     return gfl_fit_backward_step(st, hp, stream);
 }
+
+#ifdef GFL_TRACE
+int gfl_debug_read_bwd_trace(long long* out, int n_tiles) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gfl::g_bwd_trace), (size_t)n_tiles * 8 * sizeof(long long));
+}
+#endif
 
 }  // extern "C"

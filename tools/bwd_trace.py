@@ -1,0 +1,51 @@
+"""Per-tile timeline of the backward blend (needs a library built with `make TRACE=1`).
+    gpurun -- python tools/bwd_trace.py
+"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import bench
+from gflow_amd import _lib
+from gflow_amd import synthetic as S
+from gflow_amd.trainer import SimpleGaussian
+
+dev = torch.device("cuda", 0)
+lib = _lib.load()
+frame = S.make_frame(bench.H, bench.W, seed=0)
+raw = S.init_splats(frame, bench.N_SPLATS, seed=0, grown=True)
+tr = SimpleGaussian(frame["image"], frame["depth"], num_points=bench.N_SPLATS, device=dev, seed=0)
+tr.load_camera(focal=frame["focal"], pp=frame["pp"])
+for k in ("xyz", "scale", "rotate", "opacity", "rgb"):
+    tr._attributes[k] = raw[k].to(dev)
+stepper = tr.make_stepper(iterations=500, lr=4e-3, lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0,
+                          move_mask=frame["move_mask"], densify_interval=0, snapshot_interval=0)
+for _ in range(200):
+    stepper()
+torch.cuda.synchronize()
+T = tr.engine.T
+NT = 16384
+buf = (ctypes.c_longlong * (NT * 8))()
+fn = lib.gfl_debug_read_bwd_trace
+fn.restype = ctypes.c_int
+fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+assert fn(buf, NT) == 0
+a = np.frombuffer(buf, dtype=np.int64).reshape(NT, 8)
+a = a[a[:, 1] > 0]          # rows 8192+ are the near halves of split heavy tiles
+np.save(os.path.join(ROOT, "gpurun_out", "bwd_trace.npy"), a)
+t0, t1 = a[:, 0], a[:, 1]
+base = t0.min()
+dur = (t1 - t0) / 100.0          # wall_clock64 ticks at 100 MHz -> us
+total, depth_n = a[:, 2] >> 32, a[:, 2] & 0xffffffff
+units = a[:, 4:8] & 0xffffffff
+probes = units
+print("kernel span us", (t1.max() - base) / 100.0)
+print("tile dur us: mean %.1f max %.1f" % (dur.mean(), dur.max()))
+print("start offsets us: max", ((t0 - base) / 100.0).max())
+order = np.argsort(-dur)[:15]
+for i in order:
+    print("tile %4d total %4d depth_n %4d units %s probes %s start %.1f dur %.1f" %
+          (i, total[i], depth_n[i], units[i], probes[i], (t0[i] - base) / 100.0, dur[i]))
+print("sum units", units.sum(), "sum probes", probes.sum(), "max wave units", units.max())
+print("corr(dur, max wave units)", np.corrcoef(dur, units.max(1))[0, 1], "corr(dur, total)", np.corrcoef(dur, total)[0, 1])
