@@ -256,3 +256,41 @@ def test_fused_fullsize_matches_operator_path():
     api4 = torch.cat([og["rgb"], og["depth_map"]])
     close_frac(eng.render, api4, 2e-5, 2e-6, bad_frac=1e-4, hard=2e-2, what="480p/60k fused vs operator path")
     assert 60000 < eng.K < 4_000_000
+
+
+def test_fused_fullsize_gradients_match_operator_path():
+    """480p / 60k splats: more tiles than queues (seven scheduling rounds), ~250 heavy tiles split
+    in two in the backward pass, and -- second iteration -- the schedule built from the first
+    iteration's measured work.  With lr = 0 the parameters stay put, so after two iterations
+    Adam's first moment is (0.1 + 0.09) * g."""
+    from gflow_amd import losses
+    from gflow_amd import synthetic as S
+    import gflow_amd.render as R
+    from gflow_amd.fused import COLS
+    H, W, N = 480, 854, 60000
+    frame = S.make_frame(H, W, seed=0)
+    raw = S.init_splats(frame, N, seed=0, grown=True)
+    keys = ("xyz", "scale", "rotate", "opacity", "rgb")
+    s = dict(W=W, H=H, intr=raw["intr"])
+    lam = dict(lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0)
+    eng = _engine({k: raw[k] for k in keys}, s, frame["image"], frame["depth"], lr=0.0, lr_camera=0.0, **lam)
+    eng.iteration()
+    m1 = eng.adam_m[:N].clone()
+    eng.iteration()
+    eng.check_overflow()
+    m2 = eng.adam_m[:N].clone()
+    # operator path: autograd through the five msplat operators and the loss kernels
+    leaf = {k: raw[k].to(DEV).clone().requires_grad_(True) for k in keys}
+    act = FO.activate(leaf)
+    og = R.render_multiple([*act, raw["intr"].to(DEV), raw["extr"].to(DEV), 0.0, W, H], ["rgb", "depth_map"])
+    render4 = torch.cat([og["rgb"], og["depth_map"]])
+    ab = torch.tensor([1.0, 0.0], device=DEV)
+    loss, _, _, _ = losses.image_loss(render4, frame["image"].to(DEV), frame["depth"].to(DEV), ab, 1.0, 0.1, None)
+    loss = loss + lam["lambda_var"] * losses.var_loss(act[1])
+    loss.backward()
+    for k, (a, b) in COLS.items():
+        ref = leaf[k].grad.reshape(N, b - a)
+        for name, got in (("first", m1[:, a:b] / 0.1), ("second", m2[:, a:b] / 0.19)):
+            rel = ((got - ref).norm() / ref.norm()).item()
+            assert rel < 1e-3, f"d_{k} ({name} iteration): relative L2 error {rel:.2e}"
+            close_frac(got.cpu(), ref.cpu(), 5e-3, 5e-4 * ref.abs().max().item(), bad_frac=1e-3, what=f"d_{k} {name}")
