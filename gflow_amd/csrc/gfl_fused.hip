@@ -57,9 +57,7 @@ struct Splat {           // activated parameters of one splat
     float o, c[3];
 };
 
-__device__ __forceinline__ Splat load_splat(const float* __restrict__ params, int i) {
-    const float4* row = reinterpret_cast<const float4*>(params + (size_t)i * ROW);
-    const float4 a = row[0], b = row[1], c = row[2], d = row[3];
+__device__ __forceinline__ Splat splat_from_row(const float4& a, const float4& b, const float4& c, const float4& d) {
     Splat s;
     s.x = a.x; s.y = a.y; s.z = a.z;
     s.raw_s[0] = a.w; s.raw_s[1] = b.x; s.raw_s[2] = b.y;
@@ -73,6 +71,11 @@ __device__ __forceinline__ Splat load_splat(const float* __restrict__ params, in
     s.o = sigmoidf_(10.0f * c.z);                                                 // trainer.py:58-59,67
     s.c[0] = sigmoidf_(c.w); s.c[1] = sigmoidf_(d.x); s.c[2] = sigmoidf_(d.y);    // trainer.py:68
     return s;
+}
+
+__device__ __forceinline__ Splat load_splat(const float* __restrict__ params, int i) {
+    const float4* row = reinterpret_cast<const float4*>(params + (size_t)i * ROW);
+    return splat_from_row(row[0], row[1], row[2], row[3]);
 }
 
 // squared radius of the disc outside which alpha < 1/255 for every pixel, with a
@@ -686,7 +689,15 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
     float4 d0g = rp0, d1g = rp0, d2g = rp0;
     bool big = false;
     int big_nt = 0;
+    // the parameter row and both Adam moments are requested before the gather so that their
+    // latency overlaps it (the launch has about one wave per SIMD: nothing else would hide it)
+    float4 prow_v[4], mrow_v[4], vrow_v[4];
     if (i < N) {
+        const float4* prow = reinterpret_cast<const float4*>(params + (size_t)i * ROW);
+        const float4* mrow = reinterpret_cast<const float4*>(adam_m + (size_t)i * ROW);
+        const float4* vrow = reinterpret_cast<const float4*>(adam_v + (size_t)i * ROW);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { prow_v[q] = prow[q]; mrow_v[q] = mrow[q]; vrow_v[q] = vrow[q]; }
         const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)i * REC);
         rp0 = r4[0]; rp2 = r4[2];
         {
@@ -696,15 +707,32 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
                 tile_rect(rp0.x, rp0.y, rad, gx, gy, x0, x1, y0, y1);
                 const int nt = (x1 - x0) * (y1 - y0);
                 if (nt <= SLOT_MAX) {
-                    const int32_t* sl = slot_inv + (size_t)i * SLOT_MAX;
-                    for (int q = 0; q < nt; ++q) {
-                        const int pos = sl[q];
-                        if (pos >= 0) {
-                            const float4* g4 = reinterpret_cast<const float4*>(pair_grad + (size_t)pos * REC);
-                            const float4 q0 = g4[0], q1 = g4[1], q2 = g4[2];
-                            d0.x += q0.x; d0.y += q0.y; d0.z += q0.z; d0.w += q0.w;
-                            d1.x += q1.x; d1.y += q1.y; d1.z += q1.z; d1.w += q1.w;
-                            d2.x += q2.x; d2.y += q2.y;
+                    // The launch has about one wave per SIMD, so nothing hides a dependent load:
+                    // the whole slot row is fetched first (up to eight 16-byte loads in flight),
+                    // then the gradient rows four at a time (twelve loads in flight), summed in
+                    // tile order.  One slot and one row per trip took 2 x nt round trips to L2.
+                    const int4* sl4 = reinterpret_cast<const int4*>(slot_inv + (size_t)i * SLOT_MAX);
+                    int4 s4[SLOT_MAX / 4];
+#pragma unroll
+                    for (int k = 0; k < SLOT_MAX / 4; ++k) s4[k] = (4 * k < nt) ? sl4[k] : make_int4(-1, -1, -1, -1);
+#pragma unroll
+                    for (int k = 0; k < SLOT_MAX / 4; ++k) {
+                        if (4 * k >= nt) break;
+                        const int pos[4] = {s4[k].x, s4[k].y, s4[k].z, s4[k].w};
+                        float4 r0[4], r1[4], r2[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const bool ok = 4 * k + j < nt && pos[j] >= 0;
+                            const float4* g4 = reinterpret_cast<const float4*>(pair_grad + (size_t)(ok ? pos[j] : 0) * REC);
+                            r0[j] = g4[0]; r1[j] = g4[1]; r2[j] = g4[2];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (4 * k + j < nt && pos[j] >= 0) {
+                                d0.x += r0[j].x; d0.y += r0[j].y; d0.z += r0[j].z; d0.w += r0[j].w;
+                                d1.x += r1[j].x; d1.y += r1[j].y; d1.z += r1[j].z; d1.w += r1[j].w;
+                                d2.x += r2[j].x; d2.y += r2[j].y;
+                            }
                         }
                     }
                 } else {
@@ -748,7 +776,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
     }
     if (i < N) {
         const Cam c = cam_from_pose(intr, pose);
-        const Splat s = load_splat(params, i);
+        const Splat s = splat_from_row(prow_v[0], prow_v[1], prow_v[2], prow_v[3]);
         if (big) { d0 = d0g; d1 = d1g; d2 = d2g; }
         {
             float4* o4 = reinterpret_cast<float4*>(d_rec + (size_t)i * REC);
@@ -833,7 +861,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
         float pv[16], mv[16], vv[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 a = prow[q], b = mrow[q], d = vrow[q];
+            const float4 a = prow_v[q], b = mrow_v[q], d = vrow_v[q];
             pv[4 * q] = a.x; pv[4 * q + 1] = a.y; pv[4 * q + 2] = a.z; pv[4 * q + 3] = a.w;
             mv[4 * q] = b.x; mv[4 * q + 1] = b.y; mv[4 * q + 2] = b.z; mv[4 * q + 3] = b.w;
             vv[4 * q] = d.x; vv[4 * q + 1] = d.y; vv[4 * q + 2] = d.z; vv[4 * q + 3] = d.w;
