@@ -249,4 +249,10 @@ int gfl_tile_sort_with_slots(const int32_t* tile_offsets, int W, int H, int K_ca
     return check_launch();
 }
 
+#ifdef GFL_TRACE
+int gfl_debug_read_sort_trace(long long* out, int n_tiles) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gfl::g_sort_trace), (size_t)n_tiles * 4 * sizeof(long long));
+}
+#endif
+
 }  // extern "C"

@@ -1,16 +1,63 @@
 // Per-tile sort of the 64-bit (depth bits << 32 | splat id) keys -- included by gfl_bin.hip.
 //
-// One workgroup of 256 lanes per tile, keys in REGISTERS: a lane holds E = 1, 2, 4, 8 or 16
-// consecutive keys (E chosen per tile from its length, up to 4096 keys), padded with +inf.
+// One workgroup of 256 lanes per tile, keys in REGISTERS: a lane holds E = 1, 2 or 4
+// consecutive keys (E chosen per tile from its length, up to 1024 keys), padded with +inf.
 // Bitonic network; a compare-exchange partner is
 //   - in the same lane            when the stride is below E        (register swap),
-//   - in the same wave            when it is below 64 E             (wave shuffle, no barrier),
+//   - in the same wave            when it is below 64 E             (DPP / permlane swap, no LDS),
 //   - in another wave otherwise   (three steps per sort)            (2 KB LDS exchange buffer).
 // A first version sorted in LDS with a barrier per pass: a single 300-key tile then cost ~25 us
 // of barrier latency and set the duration of the whole launch.
 #pragma once
 
 namespace gfl {
+
+#ifdef GFL_TRACE
+__device__ long long g_sort_trace[16384 * 4];   // analysis build: start / keys loaded / sorted / done
+#define SORT_TRACE(slot) if (threadIdx.x == 0 && blockIdx.x < 16384) g_sort_trace[blockIdx.x * 4 + (slot)] = wall_clock64()
+#else
+#define SORT_TRACE(slot)
+#endif
+
+// Value of lane (lane ^ D) for a wave-uniform D in {1, 2, 4, 8, 16, 32}, on the VALU only: DPP
+// quad permutes / row shifts / row rotate inside a 16-lane row, v_permlane16_swap / v_permlane32_swap
+// (gfx950) across rows.  __shfl_xor goes through ds_bpermute (address VGPR + an LDS-pipe round trip
+// per 32 bits); with ~40 dependent exchange steps per tile the sort network cost 14 of the
+// launch's 24 us that way.
+template <int D>
+__device__ __forceinline__ unsigned xor_lane_u32(unsigned v, int lane) {
+    const int x = (int)v;
+    if constexpr (D == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    else if constexpr (D == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else if constexpr (D == 4) {
+        int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);               // row_shl:4 -> banks 0, 2
+        t = __builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);                   // row_shr:4 -> banks 1, 3
+        return (unsigned)t;
+    } else if constexpr (D == 8) return (unsigned)__builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, true);   // row_ror:8
+    else if constexpr (D == 16) {
+        float a = __builtin_bit_cast(float, v), b = a;
+        permlane16_swap(a, b);               // a = rows {0,0,2,2} of v, b = rows {1,1,3,3}
+        return __builtin_bit_cast(unsigned, (lane & 16) ? a : b);
+    } else {
+        float a = __builtin_bit_cast(float, v), b = a;
+        permlane32_swap(a, b);               // a = {lo, lo}, b = {hi, hi}
+        return __builtin_bit_cast(unsigned, (lane & 32) ? a : b);
+    }
+}
+
+// one compare-exchange step of the network with the partner D lanes away, all E keys of the lane
+template <int E, int D>
+__device__ __forceinline__ void exchange_in_wave(unsigned long long (&key)[E], int k, int tid) {
+    const bool lower = (tid & D) == 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const unsigned lo = xor_lane_u32<D>((unsigned)key[e], tid), hi = xor_lane_u32<D>((unsigned)(key[e] >> 32), tid);
+        const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+        const bool up = ((tid * E + e) & k) == 0;
+        const bool take_min = lower == up;
+        key[e] = ((key[e] < other) == take_min) ? key[e] : other;     // keys are unique (or equal padding)
+    }
+}
 
 template <int E>
 __device__ __forceinline__ void sort_tile_regs(unsigned long long* __restrict__ seg, int n, int npow,
@@ -21,6 +68,10 @@ __device__ __forceinline__ void sort_tile_regs(unsigned long long* __restrict__ 
         const int idx = tid * E + e;
         key[e] = idx < n ? seg[idx] : ~0ull;
     }
+#ifdef GFL_TRACE
+    if (key[0] == 1ull) return;      // (forces the loads to complete before the time stamp)
+    SORT_TRACE(1);
+#endif
     for (int k = 2; k <= npow; k <<= 1) {
         for (int j = k >> 1; j >= 1; j >>= 1) {
             if (j < E) {
@@ -41,23 +92,27 @@ __device__ __forceinline__ void sort_tile_regs(unsigned long long* __restrict__ 
                 }
             } else {
                 const int tj = j / E;                  // lane distance of the partner
-                const bool lower = (tid & tj) == 0;
+                if (tj >= 64) {
+                    const bool lower = (tid & tj) == 0;
 #pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    unsigned long long other;
-                    if (tj >= 64) {
+                    for (int e = 0; e < E; ++e) {
                         __syncthreads();
                         sk[tid] = key[e];
                         __syncthreads();
-                        other = sk[tid ^ tj];
-                    } else {
-                        other = __shfl_xor(key[e], tj);
+                        const unsigned long long other = sk[tid ^ tj];
+                        const bool up = ((tid * E + e) & k) == 0;
+                        const bool take_min = lower == up;
+                        key[e] = ((key[e] < other) == take_min) ? key[e] : other;
                     }
-                    const bool up = ((tid * E + e) & k) == 0;
-                    const bool take_min = lower == up;
-                    const unsigned long long mn = key[e] < other ? key[e] : other;
-                    const unsigned long long mx = key[e] < other ? other : key[e];
-                    key[e] = take_min ? mn : mx;
+                } else {
+                    switch (tj) {
+                        case 1: exchange_in_wave<E, 1>(key, k, tid); break;
+                        case 2: exchange_in_wave<E, 2>(key, k, tid); break;
+                        case 4: exchange_in_wave<E, 4>(key, k, tid); break;
+                        case 8: exchange_in_wave<E, 8>(key, k, tid); break;
+                        case 16: exchange_in_wave<E, 16>(key, k, tid); break;
+                        default: exchange_in_wave<E, 32>(key, k, tid); break;
+                    }
                 }
             }
         }
@@ -72,6 +127,7 @@ __device__ __forceinline__ void sort_tile_and_emit(unsigned long long* __restric
                                                    int gx, int gy) {
     unsigned long long key[E];
     sort_tile_regs<E>(seg, n, npow, sk, key);
+    SORT_TRACE(2);
     const int tid = threadIdx.x;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -85,15 +141,24 @@ __device__ __forceinline__ void sort_tile_and_emit(unsigned long long* __restric
     }
 }
 
-__global__ void __launch_bounds__(256) bin_tile_sort_kernel(const int32_t* __restrict__ offsets, int K_cap,
-                                                            unsigned long long* __restrict__ keys,
-                                                            int32_t* __restrict__ ids,
-                                                            int32_t* __restrict__ tile_range,
-                                                            const float* __restrict__ slot_rec,
-                                                            int32_t* __restrict__ slot_inv,
-                                                            int32_t* __restrict__ slot_pool, int gx, int gy) {
-    __shared__ unsigned long long sk[256];
+// Register budget: 64 VGPRs, so that 8 workgroups fit a CU and all 1620 tiles of a 480p frame are
+// resident at once.  With the 8- and 16-keys-per-lane variants in the same kernel the compiler
+// needed 95 VGPRs: 5 workgroups per CU, a second round for a fifth of the tiles.  Lists longer
+// than 1024 (none in the benchmark scenes) are sorted in LDS instead (up to 2048), in global memory
+// beyond that -- slower per tile, but they do not tax every other tile.
+constexpr int SORT_LDS_KEYS = 2048;
+
+
+__global__ void __launch_bounds__(256, 8) bin_tile_sort_kernel(const int32_t* __restrict__ offsets, int K_cap,
+                                                               unsigned long long* __restrict__ keys,
+                                                               int32_t* __restrict__ ids,
+                                                               int32_t* __restrict__ tile_range,
+                                                               const float* __restrict__ slot_rec,
+                                                               int32_t* __restrict__ slot_inv,
+                                                               int32_t* __restrict__ slot_pool, int gx, int gy) {
+    __shared__ unsigned long long sk[SORT_LDS_KEYS];    // exchange buffer (256) / the keys of a long list
     const int tile = blockIdx.x;
+    SORT_TRACE(0);
     const int start = min(offsets[tile], K_cap);
     const int end = min(offsets[tile + 1], K_cap);
     const int n = end - start;
@@ -107,18 +172,25 @@ __global__ void __launch_bounds__(256) bin_tile_sort_kernel(const int32_t* __res
     while (npow < n) npow <<= 1;
     if (n <= 256) {
         sort_tile_and_emit<1>(seg, n, npow, sk, start, tile, ids, slot_rec, slot_inv, slot_pool, gx, gy);
+        SORT_TRACE(3);
     } else if (n <= 512) {
         sort_tile_and_emit<2>(seg, n, npow, sk, start, tile, ids, slot_rec, slot_inv, slot_pool, gx, gy);
+        SORT_TRACE(3);
     } else if (n <= 1024) {
         sort_tile_and_emit<4>(seg, n, npow, sk, start, tile, ids, slot_rec, slot_inv, slot_pool, gx, gy);
-    } else if (n <= 2048) {
-        sort_tile_and_emit<8>(seg, n, npow, sk, start, tile, ids, slot_rec, slot_inv, slot_pool, gx, gy);
-    } else if (n <= 4096) {
-        sort_tile_and_emit<16>(seg, n, npow, sk, start, tile, ids, slot_rec, slot_inv, slot_pool, gx, gy);
+        SORT_TRACE(3);
     } else {
-        // oversized segment: the all-ascending network directly on global memory (one CU, its
-        // own L1; the barriers between passes order the accesses)
-        bitonic_sort((volatile unsigned long long*)seg, n);
+        if (n <= SORT_LDS_KEYS) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) sk[i] = seg[i];
+            __syncthreads();
+            bitonic_sort((volatile unsigned long long*)sk, n);
+            for (int i = threadIdx.x; i < n; i += blockDim.x) seg[i] = sk[i];
+        } else {
+            // the all-ascending network directly on global memory (one CU, its own L1; the
+            // barriers between passes order the accesses)
+            bitonic_sort((volatile unsigned long long*)seg, n);
+        }
+        __syncthreads();
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const int g = (int32_t)(unsigned)(seg[i] & 0xffffffffull);
             ids[start + i] = g;
