@@ -65,14 +65,23 @@ __device__ __forceinline__ float ld_gt(const float* __restrict__ gt_rgb, const u
 
 // grid gx*gy*3 blocks in XCD order, the three channel blocks of a tile adjacent (they share the
 // HWC ground-truth lines); dmaps[3 channels][3 maps][H][W]; partial[block] = sum of S
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 __global__ void __launch_bounds__(256) ssim_stats_kernel(const float* __restrict__ render,
                                                          const float* __restrict__ gt_rgb,
                                                          const uint8_t* __restrict__ keep, int W, int H, int gx,
                                                          int gy, Win win, float scale /* dL/dS per element */,
                                                          float* __restrict__ dmaps, float* __restrict__ partial) {
-    __shared__ float sx[SI][SI + 1];
-    __shared__ float sy[SI][SI + 1];
-    __shared__ float hz[5][SI][ST + 1];
+    // The kernel is bound by VALU issue (62 % busy, rocprofv3 PMC), so the five maps are staged
+    // as (x, y), (x^2, y^2), xy with the products formed ONCE per staged pixel, and both filter
+    // passes run on packed pairs: two v_pk_fma_f32 + one v_fma_f32 per tap instead of five FMAs and
+    // three multiplies.
+    __shared__ v2f s_xy[SI][SI + 1];
+    __shared__ v2f s_qq[SI][SI + 1];
+    __shared__ float s_x_y[SI][SI + 1];
+    __shared__ v2f h_mu[SI][ST + 1];
+    __shared__ v2f h_ee[SI][ST + 1];
+    __shared__ float h_xy[SI][ST + 1];
     const int lb = xcd_logical_block(blockIdx.x, gx * gy * 3);
     const int c = lb % 3, tile = lb / 3;
     const int bx = tile % gx, by = tile / gx;
@@ -80,39 +89,43 @@ __global__ void __launch_bounds__(256) ssim_stats_kernel(const float* __restrict
     const int tid = threadIdx.x;
     for (int i = tid; i < SI * SI; i += 256) {
         const int r = i / SI, q = i - r * SI;
-        sx[r][q] = ld_render(render, keep, c, x0 + q, y0 + r, W, H);
-        sy[r][q] = ld_gt(gt_rgb, keep, c, x0 + q, y0 + r, W, H);
+        const float xv = ld_render(render, keep, c, x0 + q, y0 + r, W, H);
+        const float yv = ld_gt(gt_rgb, keep, c, x0 + q, y0 + r, W, H);
+        s_xy[r][q] = (v2f){xv, yv};
+        s_qq[r][q] = (v2f){xv * xv, yv * yv};
+        s_x_y[r][q] = xv * yv;
     }
     __syncthreads();
     for (int i = tid; i < SI * ST; i += 256) {
         const int r = i / ST, q = i - r * ST;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+        v2f a_mu = {0.f, 0.f}, a_ee = {0.f, 0.f};
+        float a_xy = 0.f;
 #pragma unroll
         for (int k = 0; k < SW; ++k) {
-            const float xv = sx[r][q + k], yv = sy[r][q + k], w = win.w[k];
-            a0 = fmaf(w, xv, a0);
-            a1 = fmaf(w, yv, a1);
-            a2 = fmaf(w, xv * xv, a2);
-            a3 = fmaf(w, yv * yv, a3);
-            a4 = fmaf(w, xv * yv, a4);
+            const float w = win.w[k];
+            const v2f w2 = {w, w};
+            a_mu = __builtin_elementwise_fma(w2, s_xy[r][q + k], a_mu);
+            a_ee = __builtin_elementwise_fma(w2, s_qq[r][q + k], a_ee);
+            a_xy = fmaf(w, s_x_y[r][q + k], a_xy);
         }
-        hz[0][r][q] = a0; hz[1][r][q] = a1; hz[2][r][q] = a2; hz[3][r][q] = a3; hz[4][r][q] = a4;
+        h_mu[r][q] = a_mu; h_ee[r][q] = a_ee; h_xy[r][q] = a_xy;
     }
     __syncthreads();
     const int lx = tid & 15, ly = tid >> 4;
     const int px = bx * ST + lx, py = by * ST + ly;
     float sval = 0.f;
     if (px < W && py < H) {
-        float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+        v2f mu = {0.f, 0.f}, ee = {0.f, 0.f};
+        float e12 = 0.f;
 #pragma unroll
         for (int k = 0; k < SW; ++k) {
             const float w = win.w[k];
-            mu1 = fmaf(w, hz[0][ly + k][lx], mu1);
-            mu2 = fmaf(w, hz[1][ly + k][lx], mu2);
-            e11 = fmaf(w, hz[2][ly + k][lx], e11);
-            e22 = fmaf(w, hz[3][ly + k][lx], e22);
-            e12 = fmaf(w, hz[4][ly + k][lx], e12);
+            const v2f w2 = {w, w};
+            mu = __builtin_elementwise_fma(w2, h_mu[ly + k][lx], mu);
+            ee = __builtin_elementwise_fma(w2, h_ee[ly + k][lx], ee);
+            e12 = fmaf(w, h_xy[ly + k][lx], e12);
         }
+        const float mu1 = mu.x, mu2 = mu.y, e11 = ee.x, e22 = ee.y;
         const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
         const float s1 = e11 - mu1s, s2 = e22 - mu2s, s12 = e12 - mu12;
         const float A1 = 2.f * mu12 + SSIM_C1, A2 = 2.f * s12 + SSIM_C2;
@@ -197,6 +210,24 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(
     }
     const int x0 = bx * ST - SR, y0 = by * ST - SR;
     const float* base = dmaps + (size_t)ch * 3 * plane;
+    // the column-pass lanes fetch their own pixels' x, y now: issued last, the two loads would sit
+    // at the end of the workgroup's life with nothing left to overlap them
+    float own_x[2] = {0.f, 0.f}, own_y[2] = {0.f, 0.f};
+    bool own_keep[2] = {false, false};
+    if (tid < 128) {
+        const int r0 = (tid >> 4) * 2, col = tid & 15;
+        const int px = bx * ST + col;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int py = by * ST + r0 + o;
+            if (px < W && py < H) {
+                const size_t pix = (size_t)py * W + px;
+                own_keep[o] = !(keep && !keep[pix]);
+                own_x[o] = render[ch * plane + pix];
+                own_y[o] = gt_rgb[pix * 3 + ch];
+            }
+        }
+    }
     for (int i = tid; i < SI * SP; i += 256) {
         const int r = i / SP, q = i - r * SP;
         const int x = x0 + q, y = y0 + r;
@@ -247,8 +278,8 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(
             if (px < W && py < H) {
                 const size_t pix = (size_t)py * W + px;
                 float out = 0.f;
-                if (!(keep && !keep[pix])) {
-                    const float x = render[ch * plane + pix], y = gt_rgb[pix * 3 + ch];
+                if (own_keep[o]) {
+                    const float x = own_x[o], y = own_y[o];
                     out = g[0][o] + 2.f * x * g[1][o] + y * g[2][o] + mse_scale * (x - y);
                 }
                 d_render[ch * plane + pix] = out;
