@@ -640,6 +640,44 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
   }
 }
 
+// ------------------------------------------------- moving-splat footprint (camera-only stage)
+// GFlow renders the tentative moving splats on their own and masks every pixel whose grey value
+// is > 0 (trainer.py:426-451).  With a black background that is exactly the set of pixels some
+// moving splat reaches with alpha >= 1/255 in a tile it was binned into: the first such splat in
+// depth order always blends (T = 1), and every colour is a sigmoid, hence > 0.  So no second sort
+// and composite: one wave per flagged splat marks its pixels, in any order.
+__global__ void __launch_bounds__(256) keep_init_kernel(const uint8_t* __restrict__ move_mask, int P, int all_masked,
+                                                        uint8_t* __restrict__ keep) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P) keep[i] = (all_masked || (move_mask && move_mask[i])) ? 0 : 1;
+}
+
+__global__ void __launch_bounds__(256) footprint_kernel(const float* __restrict__ rec,
+                                                        const uint8_t* __restrict__ foot_flags, int N, int W, int H,
+                                                        int gx, int gy, uint8_t* __restrict__ keep) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= N || !foot_flags[i]) return;
+    const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)i * REC);
+    const float4 p0 = r4[0], p1 = r4[1], p2 = r4[2];
+    const int rad = __float_as_int(p2.w);
+    if (rad <= 0 || p2.z < 0.f) return;                   // culled, or never reaches alpha >= 1/255
+    int tx0, tx1, ty0, ty1;
+    tile_rect(p0.x, p0.y, rad, gx, gy, tx0, tx1, ty0, ty1);
+    // pixels of the binned tiles, clipped to the box around the alpha >= 1/255 disc
+    const float r = sqrtf(p2.z) + 1.f;
+    const int bx0 = max(tx0 * GFL_TILE, (int)floorf(p0.x - r)), bx1 = min(min(tx1 * GFL_TILE, W), (int)ceilf(p0.x + r) + 1);
+    const int by0 = max(ty0 * GFL_TILE, (int)floorf(p0.y - r)), by1 = min(min(ty1 * GFL_TILE, H), (int)ceilf(p0.y + r) + 1);
+    const int bw = bx1 - bx0, bh = by1 - by0;
+    if (bw <= 0 || bh <= 0) return;
+    for (int q = lane; q < bw * bh; q += 64) {
+        const int py = by0 + q / bw, px = bx0 + q % bw;
+        if (!tile_hit2(p0.x, p0.y, p2.z, px / GFL_TILE, py / GFL_TILE)) continue;   // the pair was not binned
+        float alpha, G;
+        if (splat_alpha2(p0, p1, (float)px, (float)py, alpha, G)) keep[(size_t)py * W + px] = 0;
+    }
+}
+
 // ------------------------------------------------- preprocess backward + Adam (A13)
 struct AdamCfg {
     float lr, b1, b2, eps, lr_end_factor;
@@ -1104,6 +1142,14 @@ int gfl_fit_forward(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream
         const TileQueue q = {w.sched.seq, w.sched.counters, w.sched.nq, sched_rounds(T, w.sched.nq)};
         fused_blend_fwd_kernel<<<blend_grid(T), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx,
                                                              st->render, st->final_T, st->n_contrib, q, w.ckpt);
+        if (st->foot_flags) {
+            if (!st->keep) return GFL_ERR_INVALID;
+            const int P = st->W * st->H;
+            keep_init_kernel<<<(P + 255) / 256, 256, 0, s>>>(st->move_mask, P, hp->bg > 0.f ? 1 : 0, st->keep);
+            if (!(hp->bg > 0.f) && st->N > 0)
+                footprint_kernel<<<(st->N + 3) / 4, 256, 0, s>>>(st->rec, st->foot_flags, st->N, st->W, st->H, gx, gy,
+                                                               st->keep);
+        }
     }
     return check_launch();
 }

@@ -28,7 +28,7 @@ class FitState(ctypes.Structure):          # mirrors gfl_fit_state
                 ("pose", _P), ("pose_m", _P), ("pose_v", _P),
                 ("depth_ab", _P), ("depth_ab_m", _P), ("depth_ab_v", _P),
                 ("intr", _P), ("extr", _P), ("d_extr", _P), ("step", _P),
-                ("gt_rgb", _P), ("gt_depth", _P), ("keep", _P),
+                ("gt_rgb", _P), ("gt_depth", _P), ("keep", _P), ("move_mask", _P), ("foot_flags", _P),
                 ("render", _P), ("final_T", _P), ("n_contrib", _P),
                 ("d_render", _P), ("err_px", _P), ("sums", _P),
                 ("tile_offsets", _P), ("ids", _P), ("tile_range", _P), ("overflow", _P),
@@ -101,6 +101,7 @@ class FitEngine:
         self.tile_range = torch.zeros(self.T, 2, **i32)
         self.overflow = torch.zeros(1, **i32)
         self.gt_rgb = self.gt_depth = self.keep = None
+        self.move_mask = self.foot_flags = None
         self.flow_target = self.flow_w = self.still_target = self.still_w = self.row_flags = None
         self.cap = 0
         self.K_cap_req = K_cap
@@ -159,6 +160,17 @@ class FitEngine:
         self.gt_rgb = gt_image.to(self.dev).float().contiguous()
         self.gt_depth = None if gt_depth is None else gt_depth.to(self.dev).float().reshape(self.H, self.W).contiguous()
         self.keep = None if keep is None else keep.to(self.dev).reshape(self.H, self.W).to(torch.uint8).contiguous()
+        self.move_mask = self.foot_flags = None
+        self._state = None
+
+    def set_footprint_mask(self, move_mask, moving_rows):
+        """Camera-only stage (trainer.py:426-451): from now on every forward rebuilds
+        ``keep = ~(move_mask | footprint of the splats flagged in moving_rows)``."""
+        self.move_mask = move_mask.to(self.dev).reshape(self.H, self.W).to(torch.uint8).contiguous()
+        flags = torch.zeros(self.cap, dtype=torch.uint8, device=self.dev)
+        flags[:moving_rows.shape[0]] = moving_rows.to(self.dev).to(torch.uint8)
+        self.foot_flags = flags
+        self.keep = torch.empty(self.H, self.W, dtype=torch.uint8, device=self.dev)
         self._state = None
 
     def set_regularisers(self, flow_target=None, flow_w=None, still_target=None, still_w=None, row_flags=None):
@@ -186,7 +198,8 @@ class FitEngine:
                             ("pose_v", self.pose_v), ("depth_ab", self.depth_ab), ("depth_ab_m", self.ab_m),
                             ("depth_ab_v", self.ab_v), ("intr", self.intr), ("extr", self.extr),
                             ("d_extr", self.d_extr), ("step", self.step), ("gt_rgb", self.gt_rgb),
-                            ("gt_depth", self.gt_depth), ("keep", self.keep), ("render", self.render),
+                            ("gt_depth", self.gt_depth), ("keep", self.keep), ("move_mask", self.move_mask),
+                            ("foot_flags", self.foot_flags), ("render", self.render),
                             ("final_T", self.final_T), ("n_contrib", self.n_contrib), ("d_render", self.d_render),
                             ("err_px", self.err_px), ("sums", self.sums), ("tile_offsets", self.tile_offsets),
                             ("ids", self.ids), ("tile_range", self.tile_range), ("overflow", self.overflow),

@@ -451,6 +451,11 @@ class SimpleGaussian:
         st.iteration = 0
         st.move_mask, st.camera_only = move_mask, camera_only
         tentative = hasattr(self, "still_mask_tentative") and camera_only
+        if tentative:
+            # the footprint of the tentative moving splats joins the move mask in every iteration
+            # (trainer.py:426-451): the library rebuilds ``keep`` inside its forward
+            eng.set_footprint_mask(move_mask if move_mask is not None else torch.zeros(H, W, dtype=torch.bool),
+                                   ~self.still_mask_tentative)
 
         def extras_from_engine():
             """depth_map_color and center snapshots from the engine's records (render.py:76-106)."""
@@ -468,23 +473,14 @@ class SimpleGaussian:
             iteration = st.iteration
             snap = bool(snapshot_interval) and iteration % snapshot_interval == 0
             if tentative:
-                # moving-splat footprint joins the move mask (trainer.py:427-451)
-                with torch.no_grad():
-                    grp = self._input_group(sel=~self.still_mask_tentative, detach=True)
-                    mrgb = render_mod.render_multiple(grp, ["rgb"])["rgb"]
-                    self.rasterisations_done += 1
-                    grey = 0.299 * mrgb[0] + 0.587 * mrgb[1] + 0.114 * mrgb[2]
-                    mm = (grey > 0.0) | move_mask
-                st.move_mask = mm
-                eng.keep.copy_((~mm).to(torch.uint8))
-            if snap or tentative:
+                self.rasterisations_done += 1                # the reference's extra render of the moving set
+            if snap:
                 eng.forward()
-                if snap:
-                    with torch.no_grad():
-                        extras = extras_from_engine()
-                    st.frames.append(render_mod.render2img(eng.render[:3]))
-                    st.frames_depth.append(render_mod.render2img(extras[0]))
-                    st.frames_center.append(render_mod.render2img(extras[1]))
+                with torch.no_grad():
+                    extras = extras_from_engine()
+                st.frames.append(render_mod.render2img(eng.render[:3]))
+                st.frames_depth.append(render_mod.render2img(extras[0]))
+                st.frames_center.append(render_mod.render2img(extras[1]))
                 eng.backward_step()
             else:
                 eng.iteration(use_graph=self.use_graph)      # one call (or one hipGraph replay)

@@ -191,7 +191,13 @@ typedef struct gfl_fit_state {
     int32_t* step;                              /* device step counter (Adam t-1, LinearLR epoch) */
     const float* gt_rgb;                        /* [H][W][3] */
     const float* gt_depth;                      /* [H][W] or NULL */
-    const uint8_t* keep;                        /* [H][W] or NULL (0 = masked-out pixel) */
+    uint8_t* keep;                              /* [H][W] or NULL (0 = masked-out pixel); an OUTPUT of
+                                                 * gfl_fit_forward when foot_flags is set */
+    const uint8_t* move_mask;                   /* [H][W] or NULL: the frame's move mask (camera-only stage) */
+    const uint8_t* foot_flags;                  /* [cap] or NULL.  Non-NULL: every forward rebuilds
+                                                 * keep = !(move_mask | footprint of the flagged splats), the
+                                                 * mask GFlow gets from an extra render of the tentative moving
+                                                 * splats with "grey > 0" (trainer.py:426-451) */
     float *render, *final_T;                    /* [4][H][W], [H][W] */
     int32_t* n_contrib;                         /* [H][W] */
     float *d_render, *err_px, *sums;            /* [4][H][W], [H][W], [8] as gfl_loss_fwd_bwd */

@@ -294,3 +294,33 @@ def test_fused_fullsize_gradients_match_operator_path():
             rel = ((got - ref).norm() / ref.norm()).item()
             assert rel < 1e-3, f"d_{k} ({name} iteration): relative L2 error {rel:.2e}"
             close_frac(got.cpu(), ref.cpu(), 5e-3, 5e-4 * ref.abs().max().item(), bad_frac=1e-3, what=f"d_{k} {name}")
+
+
+def test_footprint_mask_matches_the_extra_render(setup):
+    """Camera-only stage: keep = ~(move_mask | (grey of a render of the moving splats alone > 0)),
+    trainer.py:426-451.  The library marks the alpha >= 1/255 footprints instead of rendering."""
+    import gflow_amd.render as R
+    s, raw, img, dep = setup
+    n = raw["xyz"].shape[0]
+    g = torch.Generator().manual_seed(3)
+    moving = torch.rand(n - 100, generator=g) < 0.02           # shorter than N, like still_mask_tentative
+    move_mask = torch.zeros(s["H"], s["W"], dtype=torch.bool)
+    move_mask[10:30, 40:90] = True
+    eng = _engine(raw, s, img, dep, pose=POSE)
+    eng.set_footprint_mask(move_mask, moving)
+    eng.forward()
+    keep = eng.keep.bool().cpu()
+    act = [a.to(DEV) for a in FO.activate(raw)]
+    sel = torch.zeros(n, dtype=torch.bool)
+    sel[:moving.shape[0]] = moving
+    extr = LO.pose_to_extr(POSE).to(DEV)
+    og = R.render_multiple([*[a[sel.to(DEV)] for a in act], s["intr"].to(DEV), extr, 0.0, s["W"], s["H"]], ["rgb"])
+    grey = 0.299 * og["rgb"][0] + 0.587 * og["rgb"][1] + 0.114 * og["rgb"][2]
+    ref_keep = ~((grey > 0).cpu() | move_mask)
+    mismatch = (keep != ref_keep).float().mean().item()
+    assert mismatch <= 2e-4, f"footprint mask differs on {mismatch:.2e} of the pixels"
+    assert 0.05 < (~ref_keep).float().mean().item() < 0.95          # the case is not degenerate
+    # a non-black background lights every pixel of the extra render: everything is masked
+    eng.hp.bg = 0.5
+    eng.forward()
+    assert int(eng.keep.sum().item()) == 0
