@@ -1,7 +1,7 @@
 // Per-tile sort of the 64-bit (depth bits << 32 | splat id) keys -- included by gfl_bin.hip.
 //
-// One workgroup of 256 lanes per tile, keys in REGISTERS: a lane holds E = 1, 2 or 4
-// consecutive keys (E chosen per tile from its length, up to 1024 keys), padded with +inf.
+// One workgroup of 256 lanes per tile, keys in REGISTERS: a lane holds E = 1, 2, 4 or 8
+// consecutive keys (E chosen per tile from its length, up to 2048 keys), padded with +inf.
 // Bitonic network; a compare-exchange partner is
 //   - in the same lane            when the stride is below E        (register swap),
 //   - in the same wave            when it is below 64 E             (DPP / permlane swap, no LDS),
@@ -142,13 +142,10 @@ __device__ __forceinline__ void sort_tile_and_emit(unsigned long long* __restric
 }
 
 // Register budget: 64 VGPRs, so that 8 workgroups fit a CU and all 1620 tiles of a 480p frame are
-// resident at once.  With the 8- and 16-keys-per-lane variants in the same kernel the compiler
-// needed 95 VGPRs: 5 workgroups per CU, a second round for a fifth of the tiles.  Lists longer
-// than 1024 (none in the benchmark scenes) are sorted in LDS instead (up to 2048), in global memory
-// beyond that -- slower per tile, but they do not tax every other tile.
-constexpr int SORT_LDS_KEYS = 2048;
-
-
+// resident at once.  With a 16-keys-per-lane variant in the same kernel the compiler needed 95
+// VGPRs (5 workgroups per CU); up to 8 keys per lane (2048 keys: real fits reach ~1200 where
+// densification piles new splats into one tile) it needs 50.  Longer lists are sorted in global
+// memory.
 __global__ void __launch_bounds__(256, 8) bin_tile_sort_kernel(const int32_t* __restrict__ offsets, int K_cap,
                                                                unsigned long long* __restrict__ keys,
                                                                int32_t* __restrict__ ids,
@@ -156,7 +153,7 @@ __global__ void __launch_bounds__(256, 8) bin_tile_sort_kernel(const int32_t* __
                                                                const float* __restrict__ slot_rec,
                                                                int32_t* __restrict__ slot_inv,
                                                                int32_t* __restrict__ slot_pool, int gx, int gy) {
-    __shared__ unsigned long long sk[SORT_LDS_KEYS];    // exchange buffer (256) / the keys of a long list
+    __shared__ unsigned long long sk[256];               // cross-wave exchange buffer
     const int tile = blockIdx.x;
     SORT_TRACE(0);
     const int start = min(offsets[tile], K_cap);
@@ -179,17 +176,13 @@ __global__ void __launch_bounds__(256, 8) bin_tile_sort_kernel(const int32_t* __
     } else if (n <= 1024) {
         sort_tile_and_emit<4>(seg, n, npow, sk, start, tile, ids, slot_rec, slot_inv, slot_pool, gx, gy);
         SORT_TRACE(3);
+    } else if (n <= 2048) {
+        sort_tile_and_emit<8>(seg, n, npow, sk, start, tile, ids, slot_rec, slot_inv, slot_pool, gx, gy);
+        SORT_TRACE(3);
     } else {
-        if (n <= SORT_LDS_KEYS) {
-            for (int i = threadIdx.x; i < n; i += blockDim.x) sk[i] = seg[i];
-            __syncthreads();
-            bitonic_sort((volatile unsigned long long*)sk, n);
-            for (int i = threadIdx.x; i < n; i += blockDim.x) seg[i] = sk[i];
-        } else {
-            // the all-ascending network directly on global memory (one CU, its own L1; the
-            // barriers between passes order the accesses)
-            bitonic_sort((volatile unsigned long long*)seg, n);
-        }
+        // the all-ascending network directly on global memory (one CU, its own L1; the
+        // barriers between passes order the accesses): slow, for lists no scene here produces
+        bitonic_sort((volatile unsigned long long*)seg, n);
         __syncthreads();
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const int g = (int32_t)(unsigned)(seg[i] & 0xffffffffull);

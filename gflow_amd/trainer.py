@@ -604,8 +604,11 @@ class SimpleGaussian:
         densify_num = int(self.num_points * mask_ratio * percent)
         num_before = self.current_pts_num()
         if densify_num > 0 and float(err.sum()) > 0:
-            flat = err.flatten()
-            idx = torch.multinomial(flat / flat.sum(), densify_num, replacement=True, generator=self.gen)
+            # densify_num independent draws from the error map (the reference's multinomial with
+            # replacement) by inverse-CDF lookup: torch.multinomial over 4e5 categories took ~25 ms
+            cdf = torch.cumsum(err.flatten().double(), 0)
+            u = torch.rand(densify_num, generator=self.gen, device=dev, dtype=torch.float64) * cdf[-1]
+            idx = torch.searchsorted(cdf, u, right=True).clamp_(max=cdf.numel() - 1)
             ys, xs = idx // W, idx % W
             xys = torch.stack([xs, ys], dim=1).float()
             depths = self.gt_depth[ys, xs].reshape(-1, 1).float()
