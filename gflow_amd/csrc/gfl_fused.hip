@@ -383,9 +383,10 @@ __global__ void __launch_bounds__(256, 8) fused_blend_fwd_kernel(const float* __
     const int start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
     // the queue's heavy tile: leave the per-pixel state at the split position for the backward pass
     const bool heavy = first && blockIdx.x < (unsigned)queue.nq;
-    const int split = heavy ? heavy_split(end - start) : 0;
-    float* ck = ckpt + (size_t)item.queue * 5 * 256 + tid;
-    bool ck_open = split > 0;
+    const int parts = heavy ? heavy_parts(end - start) : 1;
+    const int seg = heavy_seg(end - start, parts);
+    float* ck = ckpt + (size_t)item.queue * (HEAVY_PARTS - 1) * 5 * 256 + tid;
+    int ck_next = 1;                                 // next boundary to checkpoint: position ck_next * seg
 
     float T = 1.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int last = 0;
@@ -406,9 +407,10 @@ __global__ void __launch_bounds__(256, 8) fused_blend_fwd_kernel(const float* __
         if (__all(done)) continue;      // this wave is finished; keep meeting the barriers
         for (int c0 = 0; c0 < cnt; c0 += 64) {
             if (__all(done)) break;
-            if (ck_open && base - start + c0 == split) {
-                ck[0] = T; ck[256] = a0; ck[512] = a1; ck[768] = a2; ck[1024] = a3;
-                ck_open = false;
+            if (ck_next < parts && base - start + c0 == ck_next * seg) {
+                float* c5 = ck + (size_t)(ck_next - 1) * 5 * 256;
+                c5[0] = T; c5[256] = a0; c5[512] = a1; c5[768] = a2; c5[1024] = a3;
+                ++ck_next;
             }
             const int slot = c0 + lane;
             const bool hit = slot < cnt && ((s_mask[slot] >> wave) & 1);
@@ -463,7 +465,10 @@ __global__ void __launch_bounds__(256, 8) fused_blend_fwd_kernel(const float* __
         n_contrib[pix] = last;
     }
     // the wave stopped before the split position: every pixel's state is frozen, final = checkpoint
-    if (ck_open) { ck[0] = T; ck[256] = a0; ck[512] = a1; ck[768] = a2; ck[1024] = a3; }
+    for (; ck_next < parts; ++ck_next) {
+        float* c5 = ck + (size_t)(ck_next - 1) * 5 * 256;
+        c5[0] = T; c5[256] = a0; c5[512] = a1; c5[768] = a2; c5[1024] = a3;
+    }
   }
 }
 
@@ -527,9 +532,10 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
     const float fx = (float)px, fy = (float)py;
     const int start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
     const int total = end - start;
-    const int split = item.part ? heavy_split(total) : 0;
-    if (item.part == 2 && split == 0) continue;      // short heavy tile: the far "half" did all of it
-    const bool near_half = item.part == 2;
+    const int parts = item.part >= 0 ? heavy_parts(total) : 1;
+    if (item.part >= parts) continue;                // this tile has fewer segments
+    const int seg = heavy_seg(total, parts);
+    const bool last_part = item.part < 0 || item.part == parts - 1;      // the farthest segment (or the whole tile)
     int units = 0;
 #ifdef GFL_TRACE
     const long long trace_t0 = wall_clock64();
@@ -541,13 +547,13 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
         const size_t pix = (size_t)py * W + px, plane = (size_t)H * W;
         last = n_contrib[pix];
         g0 = d_out[pix]; g1 = d_out[plane + pix]; g2 = d_out[2 * plane + pix]; g3 = d_out[3 * plane + pix];
-        if (!near_half) {
+        if (last_part) {
             T = final_T[pix];
             S = T * bg * (g0 + g1 + g2 + g3);
         } else {
-            // state after list position split - 1, from the forward checkpoint: T as it was there
-            // and S = sum_c g_c * (everything blended behind it) = sum_c g_c * (out_c - C_c)
-            const float* ck = ckpt + (size_t)item.queue * 5 * 256 + tid;
+            // state in front of this segment's far boundary, from the forward checkpoint: T as it
+            // was there and S = sum_c g_c * (everything blended behind it) = sum_c g_c * (out_c - C_c)
+            const float* ck = ckpt + ((size_t)item.queue * (HEAVY_PARTS - 1) + item.part) * 5 * 256 + tid;
             T = ck[0];
             S = g0 * (render[pix] - ck[256]) + g1 * (render[plane + pix] - ck[512]) +
                 g2 * (render[2 * plane + pix] - ck[768]) + g3 * (render[3 * plane + pix] - ck[1024]);
@@ -564,11 +570,11 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // this item walks list positions hi-1 down to lo
-    const int lo = (split && !near_half) ? split : 0;
-    const int hi = near_half ? min(split, depth_n) : depth_n;
+    const int lo = item.part > 0 ? item.part * seg : 0;
+    const int hi = last_part ? depth_n : min((item.part + 1) * seg, depth_n);
 
     // pairs behind the deepest contributor of the tile get a zero row
-    if (!near_half)
+    if (last_part)
         for (int p = depth_n + tid; p < total; p += 256) {
             float4* o = reinterpret_cast<float4*>(pair_grad + (size_t)(start + p) * REC);
             o[0] = zero4; o[1] = zero4; o[2] = zero4;
@@ -624,11 +630,11 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
     __syncthreads();
     if (tid == 0) atomicAdd(&tile_work[tile], s_units + 2);
 #ifdef GFL_TRACE
-    if (lane == 0 && tile < 8192) {
+    if (lane == 0 && tile < 2048) {
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        long long* tr = g_bwd_trace + (size_t)(tile + (near_half ? 8192 : 0)) * 8;
+        long long* tr = g_bwd_trace + (size_t)(tile + (last_part ? 0 : 2048 * (1 + item.part))) * 8;
         if (wave == 0) {
             tr[0] = trace_t0; tr[1] = wall_clock64();
             tr[2] = ((long long)total << 32) | (unsigned)depth_n;
@@ -1012,7 +1018,7 @@ static int blend_queues() {
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             cus = 256;
-        nq = cus < SCHED_MAX_QUEUES ? cus : SCHED_MAX_QUEUES;
+        nq = cus < 64 ? 64 : (cus < SCHED_MAX_QUEUES ? cus : SCHED_MAX_QUEUES);
     }
     return nq;
 }
@@ -1035,10 +1041,10 @@ size_t gfl_fit_workspace_bytes(int cap, int K_cap, int W, int H) {
            + up256((size_t)K_cap * REC * sizeof(float))                             // per-pair gradient rows
            + up256((size_t)(cap > 0 ? cap : 1) * SLOT_MAX * sizeof(int32_t))        // slot -> list position
            + 256 + up256((size_t)K_cap * sizeof(int32_t))                          // counters + slot pool
-           + 2 * up256(T * sizeof(int32_t))                                         // scheduler: work, order
-           + up256((T + SCHED_MAX_QUEUES) * sizeof(int32_t))                        // queue items
-           + up256(2 * SCHED_MAX_QUEUES * sizeof(int32_t))                          // pull counters
-           + up256((size_t)SCHED_MAX_QUEUES * 5 * 256 * sizeof(float))                  // heavy-tile checkpoints
+           + up256(T * sizeof(int32_t))                                             // scheduler: work feedback
+           + up256((size_t)SCHED_MAX_QUEUES * sched_queue_capacity((int)T, 64) * sizeof(int32_t))   // queue items
+           + 2 * up256(2 * SCHED_MAX_QUEUES * sizeof(int32_t))                      // queue lengths, pull counters
+           + up256((size_t)SCHED_MAX_QUEUES * (HEAVY_PARTS - 1) * 5 * 256 * sizeof(float))                  // heavy-tile checkpoints
            + up256(gfl_loss_workspace_bytes(W, H)) + 256;
 }
 
@@ -1052,7 +1058,7 @@ struct FitWs {
     int32_t* slot_pool;
     int32_t* pool_counter;
     Sched sched;             // tile queues of the blend kernels; sched.work persists between calls
-    float* ckpt;             // [queue][T a0 a1 a2 a3][256 pixels] forward state at the heavy tile's split
+    float* ckpt;             // [queue][boundary][T a0 a1 a2 a3][256 pixels] forward state at the heavy tile's segment boundaries
     void* loss_ws;
     size_t loss_ws_bytes;
 };
@@ -1079,15 +1085,16 @@ static FitWs carve(const gfl_fit_state* st) {
     p += up256((size_t)st->K_cap * sizeof(int32_t));
     w.sched.work = (int32_t*)p;
     p += up256(T * sizeof(int32_t));
-    w.sched.order = (int32_t*)p;
-    p += up256(T * sizeof(int32_t));
-    w.sched.seq = (int32_t*)p;
-    p += up256((T + SCHED_MAX_QUEUES) * sizeof(int32_t));
+    w.sched.list = (int32_t*)p;
+    p += up256((size_t)SCHED_MAX_QUEUES * sched_queue_capacity((int)T, 64) * sizeof(int32_t));
+    w.sched.count = (int32_t*)p;
+    p += up256(2 * SCHED_MAX_QUEUES * sizeof(int32_t));
     w.sched.counters = (int32_t*)p;
     p += up256(2 * SCHED_MAX_QUEUES * sizeof(int32_t));
     w.ckpt = (float*)p;
-    p += up256((size_t)SCHED_MAX_QUEUES * 5 * 256 * sizeof(float));
+    p += up256((size_t)SCHED_MAX_QUEUES * (HEAVY_PARTS - 1) * 5 * 256 * sizeof(float));
     w.sched.nq = blend_queues();
+    w.sched.cap_q = sched_queue_capacity((int)T, w.sched.nq);
     w.loss_ws = p;
     w.loss_ws_bytes = up256(gfl_loss_workspace_bytes(st->W, st->H));
     return w;
@@ -1139,7 +1146,7 @@ int gfl_fit_forward(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream
     if (rc) return rc;
     {
         StageScope p(ST_BLEND_FWD, s);
-        const TileQueue q = {w.sched.seq, w.sched.counters, w.sched.nq, sched_rounds(T, w.sched.nq)};
+        const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters, w.sched.nq, w.sched.cap_q};
         fused_blend_fwd_kernel<<<blend_grid(T), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx,
                                                              st->render, st->final_T, st->n_contrib, q, w.ckpt);
         if (st->foot_flags) {
@@ -1174,7 +1181,7 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
     if (rc) return rc;
     {
         StageScope p(ST_BLEND_BWD, s);
-        const TileQueue q = {w.sched.seq, w.sched.counters + w.sched.nq, w.sched.nq, sched_rounds(T, w.sched.nq)};
+        const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters + w.sched.nq, w.sched.nq, w.sched.cap_q};
         fused_blend_bwd_kernel<<<blend_grid(T), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx,
                                                              st->final_T, st->n_contrib, st->d_render, w.pair_grad, q,
                                                              w.sched.work, w.ckpt, st->render);

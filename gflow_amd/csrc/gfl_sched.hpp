@@ -13,10 +13,11 @@
 // per CU:
 //   weight    the units the backward blend counted on that tile in the PREVIOUS iteration (the
 //             scene moves slowly); the list length where there is no history yet;
-//   rounds    tiles in order of descending weight, NQ at a time; in every round the queue with
-//             the smallest load so far gets the heaviest tile of the round (rank matching: one
-//             256-way ranking per round instead of the 1620 sequential steps of greedy LPT;
-//             simulated on measured weights: busiest queue 1.06x the mean, LPT 1.03x, plain 1.4x);
+//   rounds    tiles in order of descending weight; in every round the queues whose load is
+//             within twice the next tile's weight of the smallest load take one tile each, the
+//             least loaded queue the heaviest (greedy LPT in batches: one ranking of the queues
+//             per round instead of 1620 sequential steps; a queue that already holds a 1000-unit
+//             tile sits out until the others have caught up);
 //   round 0   the NQ heaviest tiles.  Their waves raise their instruction priority, and in the
 //             backward pass each of them is split in two halves of its list that two workgroups
 //             of the CU walk side by side (the forward pass leaves a per-pixel checkpoint at the
@@ -32,17 +33,18 @@ namespace gfl {
 constexpr int SCHED_BLOCK = 512;          // threads of the scheduling workgroup (= BIN_BLOCK)
 constexpr int SCHED_BINS = 2 * SCHED_BLOCK;
 constexpr int SCHED_MAX_QUEUES = 512;
-constexpr int SCHED_MAX_WEIGHT = 1 << 20;
+constexpr int SCHED_MAX_WEIGHT = 65535;   // weights and tile ids are kept as 16-bit values in LDS
 
 struct Sched {
     int32_t* work;       // [T]        feedback: units of the last backward blend per tile (0: none)
-    int32_t* order;      // [T]        scratch: tiles by descending weight
-    int32_t* seq;        // [rounds nq] item r of queue c at seq[r * nq + c]: tile | priority << 28, or -1
+    int32_t* list;       // [nq][cap_q] items of queue c: tile | priority << 28
+    int32_t* count;      // [nq]       items in each queue
     int32_t* counters;   // [2 nq]     pull counters, forward then backward
     int nq;              // queues (= CUs)
+    int cap_q;           // capacity of one queue
 };
 
-__host__ __device__ inline int sched_rounds(int T, int nq) { return (T + nq - 1) / nq; }
+__host__ __device__ inline int sched_queue_capacity(int T, int nq) { return 2 * ((T + nq - 1) / nq) + 8; }
 
 // exclusive scan of one int per thread over the workgroup; `total` = sum over all threads
 __device__ __forceinline__ int sched_block_scan(int v, int32_t* wsum, int& total) {
@@ -67,12 +69,14 @@ __device__ __forceinline__ int sched_block_scan(int v, int32_t* wsum, int& total
     return wprefix + sc - v;
 }
 
-// w: LDS scratch of T ints; wsum: LDS scratch of SCHED_BLOCK / 64 ints.  Whole workgroup.
-__device__ void schedule_tiles(const int32_t* __restrict__ tile_counts, int T, const Sched sc, int32_t* w,
+// lds: scratch of T ints (used as two 16-bit arrays); wsum: LDS scratch of SCHED_BLOCK / 64 ints.
+// Whole workgroup.
+__device__ void schedule_tiles(const int32_t* __restrict__ tile_counts, int T, const Sched sc, int32_t* lds,
                                int32_t* wsum) {
     __shared__ int32_t bins[SCHED_BINS];
-    __shared__ int32_t chunk[SCHED_MAX_QUEUES];
-    __shared__ int32_t s_max, s_lo, s_hi;
+    __shared__ int32_t s_max, s_lo;
+    unsigned short* w16 = reinterpret_cast<unsigned short*>(lds);      // weight of tile t
+    unsigned short* ord16 = w16 + T;                                     // tiles by descending weight
     const int tid = threadIdx.x;
     const int NQ = sc.nq;
     // ---- 1. weights
@@ -83,9 +87,10 @@ __device__ void schedule_tiles(const int32_t* __restrict__ tile_counts, int T, c
     int local = 0, lmax = 1;
     for (int t = tid; t < T; t += SCHED_BLOCK) {
         int x = sc.work[t];
-        if (x <= 0 || x > SCHED_MAX_WEIGHT) x = min(max(tile_counts[t], 1), SCHED_MAX_WEIGHT);
+        if (x <= 0) x = max(tile_counts[t], 1);
+        x = min(x, SCHED_MAX_WEIGHT);
         sc.work[t] = 0;                  // the backward blend adds this iteration's units
-        w[t] = x;
+        w16[t] = (unsigned short)x;
         local += x;
         lmax = max(lmax, x);
     }
@@ -93,12 +98,12 @@ __device__ void schedule_tiles(const int32_t* __restrict__ tile_counts, int T, c
     for (int off = 32; off >= 1; off >>= 1) lmax = max(lmax, __shfl_xor(lmax, off));
     if ((tid & 63) == 0) atomicMax(&s_max, lmax);
     int W_total;
-    sched_block_scan(local, wsum, W_total);          // (contains the barriers that publish s_max, w)
+    sched_block_scan(local, wsum, W_total);          // (contains the barriers that publish s_max, w16)
     int shift = 0;
     while ((s_max >> shift) >= SCHED_BINS) ++shift;
     // ---- 2. tiles by descending weight (counting sort on the quantised weight; order within a
     //         bin is whatever the LDS atomics produce)
-    for (int t = tid; t < T; t += SCHED_BLOCK) atomicAdd(&bins[SCHED_BINS - 1 - (w[t] >> shift)], 1);
+    for (int t = tid; t < T; t += SCHED_BLOCK) atomicAdd(&bins[SCHED_BINS - 1 - (w16[t] >> shift)], 1);
     __syncthreads();
     {
         const int a = bins[2 * tid], b = bins[2 * tid + 1];
@@ -109,100 +114,96 @@ __device__ void schedule_tiles(const int32_t* __restrict__ tile_counts, int T, c
     }
     __syncthreads();
     for (int t = tid; t < T; t += SCHED_BLOCK) {
-        const int pos = atomicAdd(&bins[SCHED_BINS - 1 - (w[t] >> shift)], 1);
-        sc.order[pos] = t;
+        const int pos = atomicAdd(&bins[SCHED_BINS - 1 - (w16[t] >> shift)], 1);
+        ord16[pos] = (unsigned short)t;
     }
-    __threadfence_block();
     __syncthreads();
-    // ---- 3. rounds of rank matching; thread c < NQ owns queue c.  The ranking is a counting
-    //         sort of the queue loads quantised to SCHED_BINS levels between the smallest and
-    //         the largest load (an exact 256-way ranking by comparison took 5 us per round).
+    // ---- 3. greedy LPT in batches; thread c < NQ owns queue c
     const int target = (W_total + NQ - 1) / NQ;
-    const int rounds = sched_rounds(T, NQ);
-    int my_load = 0;
-    // the round's tiles go through LDS (chunk), fetched from `order` one round ahead: a dependent
-    // global load per round would cost more than the ranking
-    int nxt = (tid < NQ && tid < T) ? sc.order[tid] : -1;
-    for (int r = 0; r < rounds; ++r) {
-        const int cur = nxt;
-        {
-            const int p = (r + 1) * NQ + tid;
-            nxt = (r + 1 < rounds && tid < NQ && p < T) ? sc.order[p] : -1;
-        }
-        int rank = tid;                              // round 0: all loads are zero
-        __syncthreads();
-        if (tid < NQ) chunk[tid] = cur;
-        if (r > 0) {
-            if (tid == 0) { s_lo = 0x7fffffff; s_hi = 0; }
+    int my_load = 0, my_cnt = 0;
+    int32_t* my_list = sc.list + (size_t)min(tid, NQ - 1) * sc.cap_q;
+    int next = 0;
+    bool force = false;
+    while (next < T) {                               // (uniform)
+        const int avail = T - next;
+        const int w_next = w16[ord16[next]];
+        int rank = tid, m = NQ;                      // first round: all loads are zero
+        if (next > 0) {
+            __syncthreads();
+            if (tid == 0) s_lo = 0x7fffffff;
             bins[2 * tid] = 0;
             bins[2 * tid + 1] = 0;
             __syncthreads();
             {
                 // (256 LDS atomics on one word cost ~4 us: reduce in the wave first)
-                int mn = tid < NQ ? my_load : 0x7fffffff, mx = tid < NQ ? my_load : 0;
+                int mn = (tid < NQ && my_cnt < sc.cap_q) ? my_load : 0x7fffffff;
 #pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) {
-                    mn = min(mn, __shfl_xor(mn, off));
-                    mx = max(mx, __shfl_xor(mx, off));
-                }
-                if ((tid & 63) == 0) { atomicMin(&s_lo, mn); atomicMax(&s_hi, mx); }
+                for (int off = 32; off >= 1; off >>= 1) mn = min(mn, __shfl_xor(mn, off));
+                if ((tid & 63) == 0) atomicMin(&s_lo, mn);
             }
             __syncthreads();
             const int lo = s_lo;
-            const float q = (float)(SCHED_BINS - 1) / (float)(s_hi - lo + 1);
-            const int bin = tid < NQ ? (int)((float)(my_load - lo) * q) : 0;
-            if (tid < NQ) atomicAdd(&bins[bin], 1);
+            const int span = force ? 0x3fffffff : 2 * w_next;
+            const bool elig = tid < NQ && my_cnt < sc.cap_q && my_load - lo <= span;
+            // rank of the eligible queues by load: counting sort over [lo, lo + span]
+            const int bin = elig ? (int)(((long long)(my_load - lo) * (SCHED_BINS - 1)) / (span + 1)) : 0;
+            if (elig) atomicAdd(&bins[bin], 1);
             __syncthreads();
             {
                 const int x = bins[2 * tid], y = bins[2 * tid + 1];
-                int tot;
-                const int excl = sched_block_scan(x + y, wsum, tot);
+                const int excl = sched_block_scan(x + y, wsum, m);
                 bins[2 * tid] = excl;
                 bins[2 * tid + 1] = excl + x;
             }
             __syncthreads();
-            if (tid < NQ) rank = atomicAdd(&bins[bin], 1);
-        } else {
-            __syncthreads();
+            rank = elig ? atomicAdd(&bins[bin], 1) : 0x3fffffff;
+        } else if (tid >= NQ) {
+            rank = 0x3fffffff;
         }
-        if (tid < NQ) {
-            int item = -1;
-            const int tile = rank < NQ ? chunk[rank] : -1;
-            if (tile >= 0) {
-                const int wt = w[tile];
-                my_load += wt;
-                const int prio = r > 0 ? 0 : (wt * 5 >= target * 2 ? 3 : (wt * 4 >= target ? 2 : 1));
-                item = tile | (prio << 28);
-            }
-            sc.seq[r * NQ + tid] = item;
+        if (rank < avail && rank < m) {
+            const int tile = ord16[next + rank];
+            const int wt = w16[tile];
+            const int prio = next > 0 ? 0 : (wt * 5 >= target * 2 ? 3 : (wt * 4 >= target ? 2 : 1));
+            my_list[my_cnt++] = tile | (prio << 28);
+            my_load += wt;
         }
+        force = (m == 0);                            // every queue in reach is full: open the round to all
+        next += min(m, avail);
     }
+    if (tid < NQ) sc.count[tid] = my_cnt;
 }
 
 // ---- consumer side
 struct TileQueue {
-    const int32_t* seq;
+    const int32_t* list;
+    const int32_t* count;
     int32_t* counter;    // [nq] for this launch
     int nq;
-    int rounds;
+    int cap_q;
 };
 
-// Item of a queue.  part: 0 = the whole tile; 1 / 2 = far / near half of the queue's heaviest tile
-// (backward launch only).
+// Item of a queue.  part: -1 = the whole tile; 0 .. HEAVY_PARTS-1 = that segment of the queue's
+// first (heaviest) tile, nearest first (backward launch only).
 struct TileItem {
     int tile;     // -1: the queue is empty
     int part;
     int queue;
 };
 
-// list position where a heavy tile is split (a multiple of 64, 0 = not split)
-__device__ __forceinline__ int heavy_split(int total) { return total > 128 ? ((total >> 1) + 63) & ~63 : 0; }
+// The heaviest tile of a queue is walked in up to HEAVY_PARTS segments of its list by as many
+// workgroups of the CU (backward); the forward pass leaves a checkpoint at every segment boundary.
+// heavy_parts: number of segments; heavy_seg: their length, a multiple of 64 (the last is shorter).
+constexpr int HEAVY_PARTS = 4;
+__device__ __forceinline__ int heavy_parts(int total) {
+    return total <= 128 ? 1 : min(HEAVY_PARTS, max(2, (total + 319) / 320));
+}
+__device__ __forceinline__ int heavy_seg(int total, int parts) { return ((total + parts - 1) / parts + 63) & ~63; }
 
 // next item of this workgroup's queue.  Whole workgroup.  `split`: backward launch.
 __device__ __forceinline__ TileItem next_item(const TileQueue& q, int32_t* s_ticket, bool first, bool split) {
     TileItem it;
     it.queue = blockIdx.x % q.nq;
-    it.part = 0;
+    it.part = -1;
     it.tile = -1;
     int idx = blockIdx.x / q.nq;                     // first pull: the slot number, no atomic
     if (!first) {
@@ -211,13 +212,12 @@ __device__ __forceinline__ TileItem next_item(const TileQueue& q, int32_t* s_tic
         __syncthreads();
         idx = *s_ticket;
     }
-    // backward: the round-0 tile is two items
-    const int r = split ? max(idx - 1, 0) : idx;
-    if (r >= q.rounds) return it;
-    const int item = q.seq[r * q.nq + it.queue];
-    if (item < 0) return it;                         // (only the last round has holes)
+    // backward: the first tile of the queue is HEAVY_PARTS items
+    const int k = split ? max(idx - (HEAVY_PARTS - 1), 0) : idx;
+    if (k >= q.count[it.queue]) return it;
+    const int item = q.list[(size_t)it.queue * q.cap_q + k];
     it.tile = item & 0x0fffffff;
-    if (split && idx < 2) it.part = idx + 1;
+    if (split && idx < HEAVY_PARTS) it.part = idx;
     const int prio = item >> 28;
     if (prio == 3) __builtin_amdgcn_s_setprio(3);
     else if (prio == 2) __builtin_amdgcn_s_setprio(2);

@@ -13,16 +13,29 @@ from gflow_amd.trainer import SimpleGaussian
 
 dev = torch.device("cuda", 0)
 lib = _lib.load()
-frame = S.make_frame(bench.H, bench.W, seed=0)
-raw = S.init_splats(frame, bench.N_SPLATS, seed=0, grown=True)
-tr = SimpleGaussian(frame["image"], frame["depth"], num_points=bench.N_SPLATS, device=dev, seed=0)
-tr.load_camera(focal=frame["focal"], pp=frame["pp"])
-for k in ("xyz", "scale", "rotate", "opacity", "rgb"):
-    tr._attributes[k] = raw[k].to(dev)
-stepper = tr.make_stepper(iterations=500, lr=4e-3, lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0,
-                          move_mask=frame["move_mask"], densify_interval=0, snapshot_interval=0)
-for _ in range(200):
-    stepper()
+REAL = "--fit" in sys.argv      # a real first-frame fit (image-driven init, densification) instead of the bench scene
+if REAL:
+    from gflow_amd.fit_video import DEFAULTS as c
+    frame = S.make_clip(1, bench.H, bench.W, seed=0)[0]
+    tr = SimpleGaussian(frame["image"], frame["depth"], num_points=bench.N_SPLATS, device=dev, seed=0)
+    tr.load_camera(focal=frame["focal"], pp=frame["pp"])
+    tr.init_gaussians_from_image(frame["image"], frame["depth"], num_points=bench.N_SPLATS)
+    tr.train(iterations=c["iterations_first"], lr=c["lr"], lr_camera=c["lr_camera"], lambda_var=c["lambda_var"],
+             lambda_rgb=c["lambda_rgb"], lambda_depth=c["lambda_depth"], densify_interval=c["densify_interval"],
+             densify_times=c["densify_times"], move_mask=frame["move_mask"])
+    for _ in range(5):
+        tr.engine.iteration()
+else:
+    frame = S.make_frame(bench.H, bench.W, seed=0)
+    raw = S.init_splats(frame, bench.N_SPLATS, seed=0, grown=True)
+    tr = SimpleGaussian(frame["image"], frame["depth"], num_points=bench.N_SPLATS, device=dev, seed=0)
+    tr.load_camera(focal=frame["focal"], pp=frame["pp"])
+    for k in ("xyz", "scale", "rotate", "opacity", "rgb"):
+        tr._attributes[k] = raw[k].to(dev)
+    stepper = tr.make_stepper(iterations=500, lr=4e-3, lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0,
+                              move_mask=frame["move_mask"], densify_interval=0, snapshot_interval=0)
+    for _ in range(200):
+        stepper()
 torch.cuda.synchronize()
 T = tr.engine.T
 NT = 16384
@@ -32,7 +45,7 @@ fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert fn(buf, NT) == 0
 a = np.frombuffer(buf, dtype=np.int64).reshape(NT, 8)
-a = a[a[:, 1] > 0]          # rows 8192+ are the near halves of split heavy tiles
+a = a[a[:, 0] > a[:, 1].max() - 30000]     # last launch only; rows 8192+ are the near halves of split tiles
 np.save(os.path.join(ROOT, "gpurun_out", "bwd_trace.npy"), a)
 t0, t1 = a[:, 0], a[:, 1]
 base = t0.min()
@@ -49,3 +62,23 @@ for i in order:
           (i, total[i], depth_n[i], units[i], probes[i], (t0[i] - base) / 100.0, dur[i]))
 print("sum units", units.sum(), "sum probes", probes.sum(), "max wave units", units.max())
 print("corr(dur, max wave units)", np.corrcoef(dur, units.max(1))[0, 1], "corr(dur, total)", np.corrcoef(dur, total)[0, 1])
+# ---- per-CU view
+import collections
+hw = a[:, 3] & 0xffffffff
+xcc = a[:, 3] >> 32
+cu = (xcc << 8) | (((hw >> 13) & 7) << 4) | ((hw >> 8) & 15)
+groups = collections.defaultdict(list)
+for i, c_ in enumerate(cu):
+    groups[c_].append(i)
+rows = []
+for c_, ts in groups.items():
+    rows.append((max((t1[ts] - base) / 100.0), int(units[ts].sum()), len(ts), sorted(units[ts].sum(1).tolist(), reverse=True)[:4],
+                 int(units[ts].max())))
+rows.sort(reverse=True)
+for r in rows[:6]:
+    print("CU end %.1f  units %d  items %d  top items %s  max wave %d" % r)
+for r in rows[-2:]:
+    print("CU end %.1f  units %d  items %d  top items %s  max wave %d" % r)
+U = np.array([r[1] for r in rows]); E = np.array([r[0] for r in rows])
+print("CU units mean %.0f max %d min %d ; end mean %.1f min %.1f max %.1f ; corr(end, units) %.2f" %
+      (U.mean(), U.max(), U.min(), E.mean(), E.min(), E.max(), np.corrcoef(E, U)[0, 1]))
