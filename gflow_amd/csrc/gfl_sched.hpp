@@ -18,10 +18,11 @@
 //             least loaded queue the heaviest (greedy LPT in batches: one ranking of the queues
 //             per round instead of 1620 sequential steps; a queue that already holds a 1000-unit
 //             tile sits out until the others have caught up);
-//   round 0   the NQ heaviest tiles.  Their waves raise their instruction priority, and in the
-//             backward pass each of them is split in two halves of its list that two workgroups
-//             of the CU walk side by side (the forward pass leaves a per-pixel checkpoint at the
-//             split position).
+//   first     the first tile of every queue is one of the NQ heaviest.  Its waves raise their
+//             instruction priority, and in the backward pass it is walked as up to four segments
+//             of its list by as many workgroups of the CU side by side (the forward pass leaves
+//             a per-pixel checkpoint (T, C) at every segment boundary; a segment starts from
+//             T and S = sum_c g_c (out_c - C_c)).
 // The 8 workgroups resident on a CU pull from that CU's queue (first pull = slot number, later
 // pulls through a per-queue counter that only those 8 contend for).
 // The schedule decides WHERE a tile is processed, never what is computed: results do not depend on
