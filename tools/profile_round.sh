@@ -12,7 +12,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-stage-pass"
+BENCH="python $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-stage-pass --no-clip"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o r -- $BENCH > "$OUT/bench_trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o r -- $BENCH > "$OUT/bench_fetch.log" 2>&1

@@ -69,7 +69,7 @@ def main():
         stage_bytes[STAGE_OF[k]] += rd + wr
     print(json.dumps({
         "tag": os.path.basename(os.path.normpath(root)),
-        "command": "python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-stage-pass",
+        "command": "python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-stage-pass --no-clip",
         "method": "rocprofv3 --kernel-trace --stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE (three separate runs); "
                   "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B), both counters in KB",
         "kernels": kernels,
