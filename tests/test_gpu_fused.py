@@ -324,3 +324,36 @@ def test_footprint_mask_matches_the_extra_render(setup):
     eng.hp.bg = 0.5
     eng.forward()
     assert int(eng.keep.sum().item()) == 0
+
+
+def test_fused_gradients_with_four_segment_heavy_tiles():
+    """20 000 splats on 96x96 pixels: ~1100 entries per tile, so every tile is a "heaviest tile of
+    its queue" (36 tiles < 256 queues) and the backward walks it in four checkpointed segments."""
+    from gflow_amd import losses
+    import gflow_amd.render as R
+    from gflow_amd.fused import COLS
+    s = random_scene(20000, 96, 96, seed=5, sigma_px=2.0, tilt=False)
+    raw = _raw_from_scene(s)
+    n = raw["xyz"].shape[0]
+    img, dep = _targets(s["H"], s["W"], 9)
+    eng = _engine(raw, s, img, dep, lr=0.0, lr_camera=0.0, lambda_rgb=1.0, lambda_depth=0.1, lambda_var=0.0)
+    eng.iteration()
+    eng.check_overflow()
+    lens = (eng.tile_range[:, 1] - eng.tile_range[:, 0])
+    assert int(lens.max()) > 960, f"scene too sparse for four segments (longest list {int(lens.max())})"
+    m1 = eng.adam_m[:n].clone()
+    keys = ("xyz", "scale", "rotate", "opacity", "rgb")
+    leaf = {k: raw[k].to(DEV).clone().requires_grad_(True) for k in keys}
+    act = FO.activate(leaf)
+    extr = LO.pose_to_extr(eng.pose.cpu()).to(DEV)
+    og = R.render_multiple([*act, s["intr"].to(DEV), extr, 0.0, s["W"], s["H"]], ["rgb", "depth_map"])
+    close_frac(eng.render, torch.cat([og["rgb"], og["depth_map"]]).detach(), 2e-5, 2e-6, bad_frac=1e-4, hard=2e-2,
+               what="dense scene, fused vs operator path")
+    ab = torch.tensor([1.0, 0.0], device=DEV)
+    loss, _, _, _ = losses.image_loss(torch.cat([og["rgb"], og["depth_map"]]), img.to(DEV), dep.to(DEV), ab, 1.0, 0.1, None)
+    loss.backward()
+    for k, (a, b) in COLS.items():
+        ref = leaf[k].grad.reshape(n, b - a)
+        got = m1[:, a:b] / 0.1
+        rel = ((got - ref).norm() / ref.norm()).item()
+        assert rel < 2e-3, f"d_{k}: relative L2 error {rel:.2e}"
