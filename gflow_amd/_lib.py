@@ -39,6 +39,8 @@ SIGNATURES = {
     "gfl_blend_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_float, c_int, c_int, _P, _P, _P, _P]),
     "gfl_blend_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_float, c_int, c_int, _P, _P, _P, c_int,
                               _P, _P, _P, _P, c_int, _P]),
+    "gfl_sh_fwd": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
+    "gfl_sh_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
     "gfl_colormap_nonzero": (c_int, [_P, c_int, _P, _P, _P, c_size_t, _P]),
     "gfl_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
     "gfl_loss_fwd_bwd": (c_int, [_P, _P, _P, _P, _P, c_float, c_float, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),

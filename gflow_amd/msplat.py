@@ -6,6 +6,8 @@ each a ``torch.autograd.Function`` over the C ABI of libgflow_hip.so.  Use as
 
     import gflow_amd.msplat as msplat
 
+``compute_sh`` is provided as an optional sixth operator.
+
 Gradients provided (the ones the reference consumes):
 project_point -> xyz, extr; compute_cov3d -> scale, rotate;
 ewa_project -> xyz, cov3d, extr; alpha_blending -> uv, conic, opacity, feature.
@@ -244,3 +246,43 @@ def alpha_blending(uv, conic, opacity, feature, gaussian_ids_sorted, tile_range,
     ids = gaussian_ids_sorted.to(torch.int32).contiguous()
     tr = tile_range.to(torch.int32).contiguous()
     return _Blend.apply(uv, conic, opacity, feature, ids, tr, float(bg), W, H)
+
+
+# --------------------------------------------------------------------- compute_sh
+class _ComputeSh(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, shs, dirs, vis):
+        lib = L.load()
+        n, k = shs.shape[0], shs.shape[1]
+        out = torch.empty((n, 3), dtype=torch.float32, device=shs.device)
+        L.check(lib.gfl_sh_fwd(L.ptr(shs), L.ptr(dirs), L.ptr(vis), n, k, L.ptr(out), L.stream()), "compute_sh")
+        ctx.save_for_backward(shs, dirs, vis)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = L.load()
+        shs, dirs, vis = ctx.saved_tensors
+        n, k = shs.shape[0], shs.shape[1]
+        d_shs = torch.empty_like(shs)
+        d_dirs = torch.empty_like(dirs)
+        L.check(lib.gfl_sh_bwd(L.ptr(shs), L.ptr(dirs), L.ptr(vis), L.ptr(d_out.contiguous()), n, k, L.ptr(d_shs),
+                               L.ptr(d_dirs), L.stream()), "compute_sh backward")
+        return d_shs, d_dirs, None
+
+
+def compute_sh(shs, view_dirs, visible=None):
+    """Optional operator (GFlow never calls it: its colour is sigmoid(rgb), trainer.py:68).
+    shs (N,K,3) with K = (degree+1)^2 in {1,4,9,16}, view_dirs (N,3) unit vectors, visible (N,1)
+    bool or None -> (N,3) = sum_k Y_k(dir) shs[:,k] in the real SH basis of the 3DGS code base
+    (no +0.5 offset, no clamp: callers add them)."""
+    if not isinstance(shs, torch.Tensor) or shs.dim() != 3 or shs.shape[2] != 3 or shs.shape[1] not in (1, 4, 9, 16):
+        raise RuntimeError("msplat: shs must have shape (N,K,3) with K in {1,4,9,16}")
+    if shs.dtype != torch.float32:
+        raise RuntimeError(f"msplat: shs must be float32, got {shs.dtype}")
+    L.need_device(shs)
+    dirs = _f32(view_dirs, "view_dirs", (3,))
+    if dirs.shape[0] != shs.shape[0]:
+        raise RuntimeError("msplat: view_dirs must have N rows")
+    vis = None if visible is None else _vis(visible, shs.shape[0])
+    return _ComputeSh.apply(shs.contiguous(), dirs, vis)

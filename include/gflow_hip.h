@@ -118,6 +118,17 @@ int gfl_blend_bwd(const float* uv, const float* conic, const float* opacity, con
                   float* d_uv, float* d_conic, float* d_opacity, float* d_feature, int zero_first,
                   gfl_stream_t stream);
 
+/* ---- A17  compute_sh: real spherical harmonics of degree 0..3 -> colour ------------
+ * Optional operator: GFlow never calls msplat.compute_sh (its colour is sigmoid(rgb),
+ * trainer.py:68), so there is no reference call site; basis and constants follow the
+ * 3D Gaussian Splatting code base.  shs[N][K][3], K = (degree+1)^2 in {1,4,9,16};
+ * dirs[N][3] unit view directions; visible[N] or NULL; out[N][3] = sum_k Y_k(dir) shs[k]
+ * (no +0.5, no clamp).  Backward: d_shs[N][K][3], d_dirs[N][3] (may be NULL). */
+int gfl_sh_fwd(const float* shs, const float* dirs, const uint8_t* visible, int N, int K, float* out,
+               gfl_stream_t stream);
+int gfl_sh_bwd(const float* shs, const float* dirs, const uint8_t* visible, const float* d_out, int N, int K,
+               float* d_shs, float* d_dirs, gfl_stream_t stream);
+
 /* ---- A9  apply_float_colormap(depth,"turbo",non_zero=True)  (color.py:24-44) ----
  * Entirely on the device (the reference round-trips through the host every
  * iteration).  lut[256,3]; out[N,3]; workspace >= 16 bytes. */

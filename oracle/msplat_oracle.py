@@ -362,3 +362,37 @@ def alpha_blending_loops(uv, conic, opacity, feature, gaussian_ids_sorted, tile_
             final_T[y, x] = T
             n_contrib[y, x] = last
     return out, final_T, n_contrib
+
+
+# --------------------------------------------------------------------------- A17
+SH_C0 = 0.28209479177387814
+SH_C1 = 0.4886025119029199
+SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+         1.445305721320277, -0.5900435899266435)
+
+
+def sh_basis(dirs, K):
+    """Real SH basis values (N,K) at unit directions (N,3), degrees 0..3, in the sign convention of
+    the 3D Gaussian Splatting code base.  No reference call site exists (GFlow never evaluates SH);
+    pinned by orthonormality over the sphere in tests/test_oracle_kat.py."""
+    x, y, z = dirs[:, 0], dirs[:, 1], dirs[:, 2]
+    b = [torch.full_like(x, SH_C0)]
+    if K >= 4:
+        b += [-SH_C1 * y, SH_C1 * z, -SH_C1 * x]
+    if K >= 9:
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        b += [SH_C2[0] * xy, SH_C2[1] * yz, SH_C2[2] * (2 * zz - xx - yy), SH_C2[3] * xz, SH_C2[4] * (xx - yy)]
+    if K >= 16:
+        b += [SH_C3[0] * y * (3 * xx - yy), SH_C3[1] * xy * z, SH_C3[2] * y * (4 * zz - xx - yy),
+              SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy), SH_C3[4] * x * (4 * zz - xx - yy), SH_C3[5] * z * (xx - yy),
+              SH_C3[6] * x * (xx - 3 * yy)]
+    return torch.stack(b[:K], dim=1)
+
+
+def compute_sh(shs, view_dirs, visible=None):
+    """shs (N,K,3), view_dirs (N,3) -> (N,3); rows with visible == False are zero."""
+    out = (sh_basis(view_dirs, shs.shape[1]).unsqueeze(2) * shs).sum(dim=1)
+    if visible is not None:
+        out = out * visible.reshape(-1, 1).to(out.dtype)
+    return out

@@ -356,3 +356,29 @@ def test_fullsize_gradient_sums(big):
     lhs = feat.grad.double().sum().item()
     rhs = (out.detach().double() * w.double()).sum().item()     # out = sum of weights = 1 - T_final
     assert abs(lhs - rhs) <= 1e-4 * abs(rhs)
+
+
+@pytest.mark.parametrize("K", [1, 4, 9, 16])
+def test_compute_sh_matches_oracle(K):
+    """A17 (optional operator): forward and both gradients against the oracle's autograd."""
+    import gflow_amd.msplat as msplat
+    from oracle import msplat_oracle as MO
+    g = torch.Generator().manual_seed(K)
+    n = 1000
+    shs = torch.randn(n, K, 3, generator=g)
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=1)
+    vis = (torch.rand(n, 1, generator=g) > 0.1)
+    a_shs, a_d = shs.clone().requires_grad_(True), d.clone().requires_grad_(True)
+    ref = MO.compute_sh(a_shs, a_d, vis)
+    wgt = torch.randn(n, 3, generator=g)
+    (ref * wgt).sum().backward()
+    b_shs, b_d = shs.to("cuda").requires_grad_(True), d.to("cuda").requires_grad_(True)
+    out = msplat.compute_sh(b_shs, b_d, vis.to("cuda"))
+    (out * wgt.to("cuda")).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(b_shs.grad.cpu().numpy(), a_shs.grad.numpy(), rtol=1e-5, atol=1e-6)
+    ref_d = a_d.grad if a_d.grad is not None else torch.zeros_like(d)       # degree 0 does not depend on the direction
+    np.testing.assert_allclose(b_d.grad.cpu().numpy(), ref_d.numpy(), rtol=1e-4, atol=1e-5)
+    # no mask, empty input
+    assert msplat.compute_sh(b_shs.detach(), b_d.detach()).shape == (n, 3)
+    assert msplat.compute_sh(torch.zeros(0, K, 3, device="cuda"), torch.zeros(0, 3, device="cuda")).shape == (0, 3)

@@ -162,3 +162,32 @@ def test_gradcheck_float64_full_render():
         return (torch.cat([o["rgb"], o["depth_map"]]) * wts).sum()
 
     assert torch.autograd.gradcheck(fn, (*leaves, extr), atol=1e-6, rtol=1e-4, nondet_tol=0.0)
+
+
+def test_sh_basis_is_orthonormal_on_the_sphere():
+    """The only pin available for A17 (no reference call site): the 16 real harmonics are
+    orthonormal, integral over the unit sphere of Y_i Y_j = delta_ij (Gauss-Legendre x uniform
+    azimuth quadrature, exact for these polynomial degrees), and degree 0 is the constant
+    1 / (2 sqrt(pi))."""
+    nz, nphi = 16, 32
+    zs, wz = np.polynomial.legendre.leggauss(nz)
+    phi = (np.arange(nphi) + 0.5) * 2 * np.pi / nphi
+    Z, PHI = np.meshgrid(zs, phi, indexing="ij")
+    R = np.sqrt(1 - Z ** 2)
+    dirs = torch.tensor(np.stack([R * np.cos(PHI), R * np.sin(PHI), Z], -1).reshape(-1, 3))
+    w = torch.tensor(np.repeat(wz, nphi) * 2 * np.pi / nphi)
+    B = MO.sh_basis(dirs, 16)                                    # (Q,16) float64
+    gram = (B * w.unsqueeze(1)).T @ B
+    np.testing.assert_allclose(gram.numpy(), np.eye(16), atol=1e-12)
+    assert abs(B[0, 0].item() - 0.5 / np.sqrt(np.pi)) < 1e-15
+
+
+def test_sh_degree_zero_is_constant_and_visible_masks():
+    g = torch.Generator().manual_seed(1)
+    shs = torch.randn(5, 4, 3, generator=g, dtype=torch.float64)
+    d = torch.nn.functional.normalize(torch.randn(5, 3, generator=g, dtype=torch.float64), dim=1)
+    out0 = MO.compute_sh(shs[:, :1], d)
+    np.testing.assert_allclose(out0.numpy(), (MO.SH_C0 * shs[:, 0]).numpy(), rtol=1e-15)
+    vis = torch.tensor([1, 0, 1, 1, 0], dtype=torch.bool).reshape(5, 1)
+    out = MO.compute_sh(shs, d, vis)
+    assert torch.all(out[~vis.reshape(-1)] == 0)
