@@ -102,6 +102,10 @@ def main(argv=None):
     ap.add_argument("--iterations_after", type=int, default=300)
     ap.add_argument("--iterations_camera", type=int, default=150)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--sequence", action="append", default=None,
+                    help="path of a prepared sequence folder (images + the reference's sibling folders, "
+                         "gflow_amd/io.py); may be given several times, one clip each; default: synthetic clips")
+    ap.add_argument("--resize", type=int, default=None, help="shorter image side after loading a --sequence")
     args = ap.parse_args(argv)
     from . import synthetic as S
     rank = int(os.environ.get("RANK", "0"))
@@ -118,8 +122,13 @@ def main(argv=None):
     local = {k: 0.0 for k in METRIC_NAMES}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for ci in shard(args.clips, rank, world):
-        frames = S.make_clip(args.frames, args.height, args.width, seed=ci)
+    n_clips = len(args.sequence) if args.sequence else args.clips
+    for ci in shard(n_clips, rank, world):
+        if args.sequence:
+            from . import io as gio
+            frames = gio.load_sequence(args.sequence[ci], resize=args.resize)
+        else:
+            frames = S.make_clip(args.frames, args.height, args.width, seed=ci)
         m = fit_clip(frames, dev, cfg, seed=ci, log=(lambda s: print(f"[rank {rank} clip {ci}] {s}")) if args.verbose else None)
         for k in METRIC_NAMES:
             local[k] += m[k]

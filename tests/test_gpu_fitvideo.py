@@ -105,3 +105,17 @@ def test_fused_iteration_is_hipgraph_capturable():
     torch.cuda.synchronize()
     assert int(graphed.step.item()) == 4
     assert torch.isfinite(graphed.render).all()
+
+
+def test_clip_read_back_from_disk_fits_like_the_in_memory_clip(tmp_path):
+    """A clip laid out on disk in the reference's folder convention (gflow_amd/io.py) and read back
+    fits to the same quality as the in-memory clip (the PNGs quantise the image to 8 bits)."""
+    from gflow_amd import io as gio
+    from gflow_amd.fit_video import fit_clip
+    frames = _clip()
+    seq = gio.write_sequence(frames, str(tmp_path / "clip"))
+    disk = gio.load_sequence(seq, frame_range=len(frames))
+    a = fit_clip(frames, DEV, SMALL, seed=0)
+    b = fit_clip(disk, DEV, SMALL, seed=0)
+    assert b["frames"] == 3 and b["iterations"] == a["iterations"]
+    assert abs(a["psnr_sum"] - b["psnr_sum"]) / 3 < 1.0, (a, b)

@@ -102,3 +102,32 @@ def test_two_rank_gloo_reduction():
         assert o["clips"] == 5 and o["frames"] == 20 and o["iterations"] == 500 and o["psnr_sum"] == 150.0
         assert o["wall_s"] == 2.0                               # MAX over ranks
         assert o["splats_final"] == 3000
+
+
+def test_sequence_readers_round_trip(tmp_path):
+    """gflow_amd.io: the reference's on-disk convention (fit_video.py:79-99, read.py, conversion.py)."""
+    from gflow_amd import io as gio
+    from gflow_amd import synthetic as S
+    frames = S.make_clip(3, 48, 80, seed=2)
+    seq = gio.write_sequence(frames, str(tmp_path / "clip"))
+    p = gio.sequence_paths(seq)
+    assert [len(p[k]) for k in ("img", "depth", "flow", "occ", "move", "camera")] == [2, 2, 2, 1, 2, 2]   # frame_range = n-1
+    back = gio.load_sequence(seq, frame_range=3)
+    assert len(back) == 3
+    for a, b in zip(frames, back):
+        assert b["image"].shape == (48, 80, 3) and b["depth"].shape == (48, 80, 1)
+        assert (b["image"] - a["image"].float()).abs().max() <= 0.5 / 255 + 1e-6
+        assert torch.equal(b["depth"].squeeze(-1), a["depth"].squeeze(-1).float())
+        assert torch.equal(b["move_mask"], a["move_mask"].bool())
+        assert b["focal"] == a["focal"] and list(b["pp"]) == list(a["pp"])
+    assert torch.equal(back[0]["flow"], frames[0]["flow"].float())
+    assert torch.equal(back[1]["flow"], frames[1]["flow"].float())
+    assert "occ_mask" in back[1] and "occ_mask" not in back[0]
+    # .flo with a wrong magic number is rejected the way read.py:15-18 does
+    bad = tmp_path / "bad.flo"
+    np.array([1.0], np.float32).tofile(str(bad))
+    assert gio.read_flow(str(bad)) is None
+    # Resize(n): the shorter side becomes n, aspect kept (torchvision semantics)
+    half = gio.load_sequence(seq, resize=24, frame_range=3)
+    assert half[0]["image"].shape == (24, 40, 3) and half[0]["flow"].shape == (24, 40, 2)
+    assert half[0]["move_mask"].shape == (24, 40) and half[0]["depth"].shape == (24, 40, 1)
