@@ -258,16 +258,17 @@ def test_fused_fullsize_matches_operator_path():
     assert 60000 < eng.K < 4_000_000
 
 
-def test_fused_fullsize_gradients_match_operator_path():
-    """480p / 60k splats: more tiles than queues (seven scheduling rounds), ~250 heavy tiles split
-    in two in the backward pass, and -- second iteration -- the schedule built from the first
-    iteration's measured work.  With lr = 0 the parameters stay put, so after two iterations
-    Adam's first moment is (0.1 + 0.09) * g."""
+@pytest.mark.parametrize("H,W,N", [(480, 854, 60000), (720, 1280, 150000)])
+def test_fused_fullsize_gradients_match_operator_path(H, W, N):
+    """480p / 60k splats: more tiles than queues, ~250 heavy tiles walked in segments in the
+    backward pass, and -- second iteration -- the schedule built from the first iteration's
+    measured work.  720p / 150k: 3600 tiles for 2048 resident workgroups, so the workgroups
+    pull several tiles each through the per-queue counters.  With lr = 0 the parameters stay put,
+    so after two iterations Adam's first moment is (0.1 + 0.09) * g."""
     from gflow_amd import losses
     from gflow_amd import synthetic as S
     import gflow_amd.render as R
     from gflow_amd.fused import COLS
-    H, W, N = 480, 854, 60000
     frame = S.make_frame(H, W, seed=0)
     raw = S.init_splats(frame, N, seed=0, grown=True)
     keys = ("xyz", "scale", "rotate", "opacity", "rgb")
