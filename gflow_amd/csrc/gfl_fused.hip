@@ -360,6 +360,10 @@ __device__ __forceinline__ unsigned block_mask(float u, float v, float cutoff, i
     return m;
 }
 
+#ifdef GFL_TRACE
+__device__ long long g_fwd_trace[16384 * 8];     // analysis build: per-tile timeline of the forward blend
+#endif
+
 __global__ void __launch_bounds__(256, 8) fused_blend_fwd_kernel(const float* __restrict__ rec,
                                                               const int32_t* __restrict__ ids,
                                                               const int32_t* __restrict__ tile_range, float bg, int W,
@@ -387,6 +391,10 @@ __global__ void __launch_bounds__(256, 8) fused_blend_fwd_kernel(const float* __
     const int seg = heavy_seg(end - start, parts);
     float* ck = ckpt + (size_t)item.queue * (HEAVY_PARTS - 1) * 5 * 256 + tid;
     int ck_next = 1;                                 // next boundary to checkpoint: position ck_next * seg
+#ifdef GFL_TRACE
+    const long long trace_t0 = wall_clock64();
+    int trace_units = 0;
+#endif
 
     float T = 1.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int last = 0;
@@ -418,12 +426,17 @@ __global__ void __launch_bounds__(256, 8) fused_blend_fwd_kernel(const float* __
             // Two hit splats per trip: their records are fetched and their alphas evaluated
             // together (independent work hides the LDS latency); only the T recurrence is serial.
             // The body is branch-free: a lane that skips a splat contributes w = 0.
+            // (Four per trip, and requesting the next pair's records one trip ahead, were both
+            // measured slower: they spill at the 64-VGPR budget of 8 workgroups per CU.)
             while (bits) {
                 const int ja = c0 + (int)__builtin_ctzll(bits);
                 bits &= bits - 1;
                 const bool two = bits != 0ull;
                 const int jb = two ? c0 + (int)__builtin_ctzll(bits) : ja;
                 bits &= bits - 1;            // no-op when bits is already 0
+#ifdef GFL_TRACE
+                trace_units += two ? 2 : 1;
+#endif
                 const float4 pa0 = recs[ja].p0, pa1 = recs[ja].p1, pa2 = recs[ja].p2;
                 const float4 pb0 = recs[jb].p0, pb1 = recs[jb].p1, pb2 = recs[jb].p2;
                 float alpha_a, alpha_b, G;
@@ -469,6 +482,20 @@ __global__ void __launch_bounds__(256, 8) fused_blend_fwd_kernel(const float* __
         float* c5 = ck + (size_t)(ck_next - 1) * 5 * 256;
         c5[0] = T; c5[256] = a0; c5[512] = a1; c5[768] = a2; c5[1024] = a3;
     }
+#ifdef GFL_TRACE
+    if (lane == 0 && tile < 16384) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        long long* tr = g_fwd_trace + (size_t)tile * 8;
+        if (wave == 0) {
+            tr[0] = trace_t0; tr[1] = wall_clock64();
+            tr[2] = ((long long)(end - start) << 32) | (unsigned)(end - start);
+            tr[3] = ((long long)(xcc & 15) << 32) | hw;
+        }
+        tr[4 + wave] = (unsigned)trace_units;
+    }
+#endif
   }
 }
 
@@ -1218,6 +1245,9 @@ int gfl_fit_iteration(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stre
 }
 
 #ifdef GFL_TRACE
+int gfl_debug_read_fwd_trace(long long* out, int n_tiles) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gfl::g_fwd_trace), (size_t)n_tiles * 8 * sizeof(long long));
+}
 int gfl_debug_read_bwd_trace(long long* out, int n_tiles) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gfl::g_bwd_trace), (size_t)n_tiles * 8 * sizeof(long long));
 }

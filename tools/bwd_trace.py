@@ -1,5 +1,6 @@
-"""Per-tile timeline of the backward blend (needs a library built with `make TRACE=1`).
-    gpurun -- python tools/bwd_trace.py
+"""Per-tile timeline of the backward (or, with --fwd, forward) blend; --fit: on a real first-frame fit
+instead of the bench scene (needs a library built with `make TRACE=1`).
+    gpurun -- python tools/bwd_trace.py [--fwd] [--fit]
 """
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,7 +41,8 @@ torch.cuda.synchronize()
 T = tr.engine.T
 NT = 16384
 buf = (ctypes.c_longlong * (NT * 8))()
-fn = lib.gfl_debug_read_bwd_trace
+FWD = "--fwd" in sys.argv     # the forward blend instead of the backward
+fn = lib.gfl_debug_read_fwd_trace if FWD else lib.gfl_debug_read_bwd_trace
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert fn(buf, NT) == 0
