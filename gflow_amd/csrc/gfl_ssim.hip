@@ -24,8 +24,10 @@ constexpr int SW = 11;           // SSIM window
 constexpr int SR = SW / 2;       // halo
 constexpr int ST = 16;           // output tile edge
 constexpr int SI = ST + 2 * SR;  // staged tile edge (26)
-constexpr int SP = 28;           // staged row pitch (floats): 16-byte aligned rows, 16 readable from col 12
-constexpr int HP = 20;           // row-filtered pitch (floats): 16-byte aligned 4-float groups
+constexpr int SP = 48;           // staged row pitch (floats).  The row pass reads 16-byte chunks, four lanes per
+                                 // row: with a pitch of 48 floats four consecutive rows fall on disjoint banks
+                                 // (28 gave a 2-way conflict on every read: 60 % of the LDS cycles, rocprofv3 PMC)
+constexpr int HP = 24;           // row-filtered pitch (floats): the column pass's four row pairs on disjoint banks
 constexpr float SSIM_C1 = 0.01f * 0.01f;
 constexpr float SSIM_C2 = 0.03f * 0.03f;
 
@@ -228,8 +230,9 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(
             }
         }
     }
-    for (int i = tid; i < SI * SP; i += 256) {
-        const int r = i / SP, q = i - r * SP;
+    for (int i = tid; i < SI * 32; i += 256) {       // 28 of every 32 slots: columns 26, 27 are zero padding
+        const int r = i >> 5, q = i & 31;
+        if (q >= 28) continue;
         const int x = x0 + q, y = y0 + r;
         const bool in = q < SI && x >= 0 && y >= 0 && x < W && y < H;
         const size_t p = (size_t)y * W + x;
