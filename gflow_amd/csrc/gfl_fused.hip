@@ -968,10 +968,32 @@ __global__ void __launch_bounds__(1024) fused_camera_adam_kernel(
         acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w; acc[4] += b.x; acc[5] += b.y; acc[6] += b.z;
         acc[7] += b.w; acc[8] += c.x; acc[9] += c.y; acc[10] += c.z; acc[11] += c.w;
     }
-    for (int r = threadIdx.x; r < n_ssim; r += 1024) acc[13] += p_ssim[r];
-    for (int r = threadIdx.x; r < n_grad; r += 1024) {
-        const float4 q = reinterpret_cast<const float4*>(p_grad)[r];
-        acc[12] += q.x; acc[14] += q.y; acc[15] += q.z; acc[16] += q.w;
+    // one workgroup, nothing to overlap a load with but other loads: issue them in batches
+    // (one load per trip made this kernel a chain of ~8 dependent L2 round trips)
+    for (int r0 = threadIdx.x; r0 < n_ssim; r0 += 8 * 1024) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (r0 + u * 1024 < n_ssim) ? p_ssim[r0 + u * 1024] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[13] += v[u];
+    }
+    for (int r0 = threadIdx.x; r0 < n_grad; r0 += 4 * 1024) {
+        float4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            q[u] = (r0 + u * 1024 < n_grad) ? reinterpret_cast<const float4*>(p_grad)[r0 + u * 1024] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc[12] += q[u].x; acc[14] += q[u].y; acc[15] += q[u].z; acc[16] += q[u].w; }
+    }
+    // thread 0 needs these after the reduction: request them now
+    float pz[7], pm[7], pv[7], ab[2], abm[2], abv[2];
+    int e_step = 0;
+    if (threadIdx.x == 0) {
+        e_step = *d_step;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { pz[k] = pose[k]; pm[k] = pose_m[k]; pv[k] = pose_v[k]; }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { ab[k] = depth_ab[k]; abm[k] = ab_m[k]; abv[k] = ab_v[k]; }
     }
     __shared__ float red[16][NV];
     __shared__ float ge[NV];
@@ -992,10 +1014,10 @@ __global__ void __launch_bounds__(1024) fused_camera_adam_kernel(
     if (threadIdx.x >= NV && threadIdx.x < NV + 3) sums[threadIdx.x - NV + 5] = 0.f;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int e = *d_step;
+        const int e = e_step;
         if (step_camera) {
             // d_extr (rows R|t) -> d_pose; q = raw/|raw| in XYZW order
-            const float rx = pose[0], ry = pose[1], rz = pose[2], rw = pose[3];
+            const float rx = pz[0], ry = pz[1], rz = pz[2], rw = pz[3];
             const float n = sqrtf(rx * rx + ry * ry + rz * rz + rw * rw);
             const float x = rx / n, y = ry / n, z = rz / n, w = rw / n;
             const float* dR = ge;   // dR[i][j] = ge[4 i + j]
@@ -1015,10 +1037,16 @@ __global__ void __launch_bounds__(1024) fused_camera_adam_kernel(
             float ss, isb;
             adam_scalars(ac_cam, e, ac_cam.lr, ss, isb);
 #pragma unroll
-            for (int k = 0; k < 7; ++k) pose[k] = adam_update(pose[k], gp[k], pose_m[k], pose_v[k], ac_cam, ss, isb);
+            for (int k = 0; k < 7; ++k) {
+                pose[k] = adam_update(pz[k], gp[k], pm[k], pv[k], ac_cam, ss, isb);
+                pose_m[k] = pm[k]; pose_v[k] = pv[k];
+            }
             adam_scalars(ac_ab, e, ac_ab.lr, ss, isb);
 #pragma unroll
-            for (int k = 0; k < 2; ++k) depth_ab[k] = adam_update(depth_ab[k], ge[15 + k], ab_m[k], ab_v[k], ac_ab, ss, isb);
+            for (int k = 0; k < 2; ++k) {
+                depth_ab[k] = adam_update(ab[k], ge[15 + k], abm[k], abv[k], ac_ab, ss, isb);
+                ab_m[k] = abm[k]; ab_v[k] = abv[k];
+            }
         }
         *d_step = e + 1;
     }
