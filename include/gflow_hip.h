@@ -187,7 +187,12 @@ int gfl_step_increment(int32_t* d_step, gfl_stream_t stream);
  * Optional per-splat inputs (NULL = term absent): flow_target[cap][2] + flow_w[cap]
  * (weight = mask/(2 count), trainer.py:511-528), still_target[cap][3] + still_w[cap]
  * (weight = mask/count, trainer.py:505-509), row_flags[cap] (bit0: xyz gradient
- * frozen, trainer.py:543-546). */
+ * frozen, trainer.py:543-546).
+ * workspace: gfl_fit_workspace_bytes(...) bytes, ZERO-INITIALISED ONCE by the host and then left
+ * alone between calls: besides scratch it holds the tile scheduler's feedback (the work the
+ * backward blend measured per tile, used to balance the next iteration's blend launches over the
+ * CUs).  Garbage there cannot change a result, only the balance.  The tile grid is limited to
+ * 16384 tiles (GFL_ERR_INVALID beyond). */
 typedef struct gfl_fit_state {
     int32_t N, cap, W, H, K_cap, reserved;
     float *params, *adam_m, *adam_v;
