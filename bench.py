@@ -104,15 +104,17 @@ def cpu_baseline(seconds_budget=25.0):
     fit.step()                                   # warm-up (allocator, thread pool)
     t0 = time.time()
     n = 0
+    timers = {}
     while n < 1 or (time.time() - t0 < seconds_budget and n < 8):
-        fit.step()
+        fit.step(timers)
         n += 1
     dt = (time.time() - t0) / n
     return {"value": (1.0 / dt) / ITERS_PER_FRAME, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{n} fit iterations (after 1 warm-up) of the same 480x854 / 60k-splat frame with the "
                       f"eager-PyTorch CPU oracle (own restatement; the reference has no CPU rasteriser), "
                       f"{dt * 1000:.0f} ms/iteration",
-            "ms_per_step": dt * 1000.0}
+            "ms_per_step": dt * 1000.0,
+            "phase_ms": {k: v / n * 1000.0 for k, v in timers.items()}}
 
 
 def main():
