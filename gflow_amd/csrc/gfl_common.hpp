@@ -74,7 +74,7 @@ __device__ __forceinline__ int xcd_logical_block(int b, int nb) {
     return x * q + min(x, r) + i;
 }
 
-// Reduce-scatter of ten per-lane values over the wave (blend backward: du dv dA dB dC do df0..3).
+// Reduce-scatter of ten per-lane values over the wave (blend backward: five conic/centre moments, do, df0..3).
 // gfx950's v_permlane32_swap / v_permlane16_swap exchange half-waves / rows between two
 // registers, so "swap + add" halves the number of live values while summing lane pairs:
 //   stage 1  10 -> 5 values (lanes i, i+32),  stage 2  5 -> 3 values (rows 2k, 2k+1),
