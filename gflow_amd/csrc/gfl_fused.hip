@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
         const Splat s = load_splat(params, i);
         const Proj p = project_fwd(c, s.x, s.y, s.z, W, H, nearest, extent);
         float depth = 0.f, A = 0.f, B = 0.f, C = 0.f;
-        int rad = 0;
+        int rad = 0, nt_slots = 0;
         if (p.vis) {
             u = p.u; v = p.v; depth = p.pz;
             float cov[6];
@@ -132,6 +132,7 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
                 const int nt = (x1 - x0) * (y1 - y0);
                 if (nt > 0) {
                     rad = r;
+                    nt_slots = min(nt, SLOT_MAX);
                     A = e.c / e.det; B = -e.b / e.det; C = e.a / e.det;
                     cutoff = alpha_cutoff(s.o, e.lam);
                     if (nt > WIDE_TILES) {
@@ -150,8 +151,10 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
         r4[2] = make_float4(s.c[2], depth, cutoff, __int_as_float(rad));
         int4* iv = reinterpret_cast<int4*>(slot_inv + (size_t)i * SLOT_MAX);
         const int4 none = make_int4(-1, -1, -1, -1);
+        // only the slots of the splat's own tile rectangle are ever read (gather of the backward)
 #pragma unroll
-        for (int q = 0; q < SLOT_MAX / 4; ++q) iv[q] = none;
+        for (int q = 0; q < SLOT_MAX / 4; ++q)
+            if (4 * q < nt_slots) iv[q] = none;
         if (wnt > SLOT_MAX) {
             // too many tiles for the slot row: reserve wnt entries of the pool; the row's first
             // entry carries the pool offset as -2 - offset
