@@ -78,7 +78,8 @@ __device__ __forceinline__ int xcd_logical_block(int b, int nb) {
 // gfx950's v_permlane32_swap / v_permlane16_swap exchange half-waves / rows between two
 // registers, so "swap + add" halves the number of live values while summing lane pairs:
 //   stage 1  10 -> 5 values (lanes i, i+32),  stage 2  5 -> 3 values (rows 2k, 2k+1),
-//   stage 3  three 16-lane DPP reductions.      ~30 VALU ops instead of 10 x 6 dependent DPP adds.
+//   stage 3  the three values folded over the 16 lanes of a row (9 ops, below).
+//   ~27 VALU ops instead of 10 x 6 dependent DPP adds.
 // Afterwards, in row r = (hi, odd) = (lane>>5, (lane>>4)&1) every lane holds
 //   x0 = sum of component 2*odd + hi,  x1 = sum of component 4 + 2*odd + hi,
 //   x2 = sum of component 8 + hi (even rows only).
@@ -113,21 +114,24 @@ __device__ __forceinline__ float wave_reduce_scatter10(const float (&v)[10], int
         permlane16_swap(a, b);
         x[2] = a + b;
     }
-#define GFL_ROW_STEP(ctrl)                                                                                            \
-    {                                                                                                                 \
-        const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x[0]), ctrl, 0xF, 0xF, true)); \
-        const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x[1]), ctrl, 0xF, 0xF, true)); \
-        const float t2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x[2]), ctrl, 0xF, 0xF, true)); \
-        x[0] += t0; x[1] += t1; x[2] += t2;                                                                           \
-    }
-    GFL_ROW_STEP(0xB1)    // quad_perm [1,0,3,2]
-    GFL_ROW_STEP(0x4E)    // quad_perm [2,3,0,1]
-    GFL_ROW_STEP(0x141)   // row_half_mirror
-    GFL_ROW_STEP(0x140)   // row_mirror
-#undef GFL_ROW_STEP
+    // stage 3: the three values of a 16-lane row.  Instead of three independent 4-step reductions
+    // (12 DPP adds) the values are folded onto lane classes on the way: after the xor-1 step the
+    // even lanes carry x0 and the odd lanes x1, after the xor-2 step lanes with bit 1 set carry x2;
+    // two rotations by 4 and 8 lanes (which keep the low two lane bits) finish the sums: 9 ops.
+#define GFL_DPP(val, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (val)), ctrl, 0xF, 0xF, true))
+    const bool b0 = lane & 1, b1 = lane & 2;
+    const float keep01 = b0 ? x[1] : x[0], send01 = b0 ? x[0] : x[1];
+    const float y = keep01 + GFL_DPP(send01, 0xB1);          // quad_perm [1,0,3,2]
+    const float z = x[2] + GFL_DPP(x[2], 0xB1);
+    const float keep = b1 ? z : y, send = b1 ? y : z;
+    float t = keep + GFL_DPP(send, 0x4E);                    // quad_perm [2,3,0,1]
+    t += GFL_DPP(t, 0x124);                                  // row_ror:4
+    t += GFL_DPP(t, 0x128);                                  // row_ror:8
+#undef GFL_DPP
+    // lane & 3 == 0: x0 total, == 1: x1 total, >= 2: x2 total
     const int hi = lane >> 5, odd = (lane >> 4) & 1, sel = lane & 15;
     comp = sel == 0 ? 2 * odd + hi : (sel == 1 ? 4 + 2 * odd + hi : ((sel == 2 && odd == 0) ? 8 + hi : -1));
-    return sel == 0 ? x[0] : (sel == 1 ? x[1] : x[2]);
+    return t;
 }
 
 // Deterministic block-level reduction of NV values -> one partial row per block.
