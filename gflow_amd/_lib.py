@@ -45,6 +45,8 @@ SIGNATURES = {
     "gfl_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
     "gfl_loss_fwd_bwd": (c_int, [_P, _P, _P, _P, _P, c_float, c_float, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "gfl_loss_fwd_bwd_partials": (c_int, [_P, _P, _P, _P, _P, c_float, c_float, c_int, c_int, _P, _P, _P, c_size_t, _P, _P, _P, _P, _P]),
+    "gfl_loss_prepare_gt": (c_int, [_P, _P, c_int, c_int, _P, _P]),
+    "gfl_loss_fwd_bwd_partials_cached": (c_int, [_P, _P, _P, _P, _P, c_float, c_float, c_int, c_int, _P, _P, _P, c_size_t, _P, _P, _P, _P, _P, _P]),
     "gfl_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, c_float, c_float, c_float, c_float, _P, c_float, c_int, _P]),
     "gfl_step_increment": (c_int, [_P, _P]),
     "gfl_tile_sort_only": (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),
@@ -53,6 +55,7 @@ SIGNATURES = {
     "gfl_fit_forward": (c_int, [_P, _P, _P]),          # struct pointers; typed in gflow_amd/fused.py
     "gfl_fit_backward_step": (c_int, [_P, _P, _P]),
     "gfl_fit_iteration": (c_int, [_P, _P, _P]),
+    "gfl_fit_prepare_targets": (c_int, [_P, _P]),
     "gfl_selftest_reduce10": (c_int, [_P, _P, _P, _P]),
     "gfl_abi_sizes": (c_int, [_P, _P]),
     "gfl_profile_enable": (c_int, [ctypes.c_uint]),

@@ -1115,7 +1115,8 @@ size_t gfl_fit_workspace_bytes(int cap, int K_cap, int W, int H) {
            + up256((size_t)SCHED_MAX_QUEUES * sched_queue_capacity((int)T, 64) * sizeof(int32_t))   // queue items
            + 2 * up256(2 * SCHED_MAX_QUEUES * sizeof(int32_t))                      // queue lengths, pull counters
            + up256((size_t)SCHED_MAX_QUEUES * (HEAVY_PARTS - 1) * 5 * 256 * sizeof(float))                  // heavy-tile checkpoints
-           + up256(gfl_loss_workspace_bytes(W, H)) + 256;
+           + up256(gfl_loss_workspace_bytes(W, H)) + 256
+           + up256((size_t)6 * W * H * sizeof(float));                                 // SSIM statistics of the target
 }
 
 struct FitWs {
@@ -1131,6 +1132,7 @@ struct FitWs {
     float* ckpt;             // [queue][boundary][T a0 a1 a2 a3][256 pixels] forward state at the heavy tile's segment boundaries
     void* loss_ws;
     size_t loss_ws_bytes;
+    float* gt_stats;         // [3][2][H][W] conv(y), conv(y^2) of the current target (gfl_fit_prepare_targets)
 };
 
 static FitWs carve(const gfl_fit_state* st) {
@@ -1167,6 +1169,7 @@ static FitWs carve(const gfl_fit_state* st) {
     w.sched.cap_q = sched_queue_capacity((int)T, w.sched.nq);
     w.loss_ws = p;
     w.loss_ws_bytes = up256(gfl_loss_workspace_bytes(st->W, st->H));
+    w.gt_stats = (float*)((char*)p + w.loss_ws_bytes + 256);
     return w;
 }
 
@@ -1244,9 +1247,12 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
     int n_ssim = 0, n_grad = 0;
     {
         StageScope p(ST_LOSS, s);
-        rc = gfl_loss_fwd_bwd_partials(st->render, st->gt_rgb, st->gt_depth, st->keep, st->depth_ab, hp->lambda_rgb,
-                                       hp->lambda_depth, st->W, st->H, st->d_render, st->err_px, w.loss_ws,
-                                       w.loss_ws_bytes, &p_ssim, &n_ssim, &p_grad, &n_grad, stream);
+        // the footprint mask changes keep (and with it the masked target) every iteration
+        const float* gt_stats = (st->gt_cached && !st->foot_flags) ? w.gt_stats : nullptr;
+        rc = gfl_loss_fwd_bwd_partials_cached(st->render, st->gt_rgb, st->gt_depth, st->keep, st->depth_ab,
+                                              hp->lambda_rgb, hp->lambda_depth, st->W, st->H, st->d_render,
+                                              st->err_px, w.loss_ws, w.loss_ws_bytes, gt_stats, &p_ssim, &n_ssim,
+                                              &p_grad, &n_grad, stream);
     }
     if (rc) return rc;
     {
@@ -1279,6 +1285,13 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
                                                     ac_cam, ac, hp->step_camera, st->step, st->d_extr);
     }
     return check_launch();
+}
+
+int gfl_fit_prepare_targets(const gfl_fit_state* st, gfl_stream_t stream) {
+    if (!st || st->W <= 0 || st->H <= 0 || !st->gt_rgb || !st->workspace) return GFL_ERR_INVALID;
+    if (st->workspace_bytes < gfl_fit_workspace_bytes(st->cap, st->K_cap, st->W, st->H)) return GFL_ERR_WORKSPACE;
+    const FitWs w = carve(st);
+    return gfl_loss_prepare_gt(st->gt_rgb, st->keep, st->W, st->H, w.gt_stats, stream);
 }
 
 int gfl_fit_iteration(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream) {

@@ -69,21 +69,29 @@ __device__ __forceinline__ float ld_gt(const float* __restrict__ gt_rgb, const u
 // HWC ground-truth lines); dmaps[3 channels][3 maps][H][W]; partial[block] = sum of S
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// MODE 0: all five maps from scratch.
+// MODE 1: mu2 = conv(y) and E[y^2] = conv(y^2) come from gt_stats[3 channels][2][H][W], computed once
+//         per ground-truth image by MODE 2 with the same arithmetic (the target does not change
+//         during the hundreds of iterations of a fit): three maps instead of five through LDS and
+//         the filter passes.
+// MODE 2: write gt_stats, nothing else.
+template <int MODE>
 __global__ void __launch_bounds__(256) ssim_stats_kernel(const float* __restrict__ render,
                                                          const float* __restrict__ gt_rgb,
                                                          const uint8_t* __restrict__ keep, int W, int H, int gx,
                                                          int gy, Win win, float scale /* dL/dS per element */,
-                                                         float* __restrict__ dmaps, float* __restrict__ partial) {
-    // The kernel is bound by VALU issue (62 % busy, rocprofv3 PMC), so the five maps are staged
-    // as (x, y), (x^2, y^2), xy with the products formed ONCE per staged pixel, and both filter
-    // passes run on packed pairs: two v_pk_fma_f32 + one v_fma_f32 per tap instead of five FMAs and
-    // three multiplies.
-    __shared__ v2f s_xy[SI][SI + 1];
-    __shared__ v2f s_qq[SI][SI + 1];
-    __shared__ float s_x_y[SI][SI + 1];
-    __shared__ v2f h_mu[SI][ST + 1];
-    __shared__ v2f h_ee[SI][ST + 1];
-    __shared__ float h_xy[SI][ST + 1];
+                                                         float* __restrict__ dmaps, float* __restrict__ partial,
+                                                         float* __restrict__ gt_stats) {
+    // The kernel was bound by VALU issue (62 % busy, rocprofv3 PMC), so the maps are staged as
+    // packed pairs with the products formed ONCE per staged pixel, and both filter passes run
+    // v_pk_fma_f32 on the pairs.  pair = (x, y) and (x^2, y^2) in MODE 0, (x, x^2) in MODE 1,
+    // (y, y^2) in MODE 2; the fifth map xy is a plain float (MODE 0 and 1).
+    __shared__ v2f s_a[SI][SI + 1];
+    __shared__ v2f s_b[MODE == 0 ? SI : 1][SI + 1];
+    __shared__ float s_x_y[MODE == 2 ? 1 : SI][SI + 1];
+    __shared__ v2f h_a[SI][ST + 1];
+    __shared__ v2f h_b[MODE == 0 ? SI : 1][ST + 1];
+    __shared__ float h_xy[MODE == 2 ? 1 : SI][ST + 1];
     const int lb = xcd_logical_block(blockIdx.x, gx * gy * 3);
     const int c = lb % 3, tile = lb / 3;
     const int bx = tile % gx, by = tile / gx;
@@ -91,43 +99,64 @@ __global__ void __launch_bounds__(256) ssim_stats_kernel(const float* __restrict
     const int tid = threadIdx.x;
     for (int i = tid; i < SI * SI; i += 256) {
         const int r = i / SI, q = i - r * SI;
-        const float xv = ld_render(render, keep, c, x0 + q, y0 + r, W, H);
+        const float xv = MODE == 2 ? 0.f : ld_render(render, keep, c, x0 + q, y0 + r, W, H);
         const float yv = ld_gt(gt_rgb, keep, c, x0 + q, y0 + r, W, H);
-        s_xy[r][q] = (v2f){xv, yv};
-        s_qq[r][q] = (v2f){xv * xv, yv * yv};
-        s_x_y[r][q] = xv * yv;
+        if (MODE == 0) {
+            s_a[r][q] = (v2f){xv, yv};
+            s_b[r][q] = (v2f){xv * xv, yv * yv};
+        } else if (MODE == 1) {
+            s_a[r][q] = (v2f){xv, xv * xv};
+        } else {
+            s_a[r][q] = (v2f){yv, yv * yv};
+        }
+        if (MODE != 2) s_x_y[r][q] = xv * yv;
     }
     __syncthreads();
     for (int i = tid; i < SI * ST; i += 256) {
         const int r = i / ST, q = i - r * ST;
-        v2f a_mu = {0.f, 0.f}, a_ee = {0.f, 0.f};
+        v2f a_a = {0.f, 0.f}, a_b = {0.f, 0.f};
         float a_xy = 0.f;
 #pragma unroll
         for (int k = 0; k < SW; ++k) {
             const float w = win.w[k];
             const v2f w2 = {w, w};
-            a_mu = __builtin_elementwise_fma(w2, s_xy[r][q + k], a_mu);
-            a_ee = __builtin_elementwise_fma(w2, s_qq[r][q + k], a_ee);
-            a_xy = fmaf(w, s_x_y[r][q + k], a_xy);
+            a_a = __builtin_elementwise_fma(w2, s_a[r][q + k], a_a);
+            if (MODE == 0) a_b = __builtin_elementwise_fma(w2, s_b[r][q + k], a_b);
+            if (MODE != 2) a_xy = fmaf(w, s_x_y[r][q + k], a_xy);
         }
-        h_mu[r][q] = a_mu; h_ee[r][q] = a_ee; h_xy[r][q] = a_xy;
+        h_a[r][q] = a_a;
+        if (MODE == 0) h_b[r][q] = a_b;
+        if (MODE != 2) h_xy[r][q] = a_xy;
     }
     __syncthreads();
     const int lx = tid & 15, ly = tid >> 4;
     const int px = bx * ST + lx, py = by * ST + ly;
     float sval = 0.f;
     if (px < W && py < H) {
-        v2f mu = {0.f, 0.f}, ee = {0.f, 0.f};
+        v2f fa = {0.f, 0.f}, fb = {0.f, 0.f};
         float e12 = 0.f;
 #pragma unroll
         for (int k = 0; k < SW; ++k) {
             const float w = win.w[k];
             const v2f w2 = {w, w};
-            mu = __builtin_elementwise_fma(w2, h_mu[ly + k][lx], mu);
-            ee = __builtin_elementwise_fma(w2, h_ee[ly + k][lx], ee);
-            e12 = fmaf(w, h_xy[ly + k][lx], e12);
+            fa = __builtin_elementwise_fma(w2, h_a[ly + k][lx], fa);
+            if (MODE == 0) fb = __builtin_elementwise_fma(w2, h_b[ly + k][lx], fb);
+            if (MODE != 2) e12 = fmaf(w, h_xy[ly + k][lx], e12);
         }
-        const float mu1 = mu.x, mu2 = mu.y, e11 = ee.x, e22 = ee.y;
+        const size_t plane = (size_t)H * W, pix = (size_t)py * W + px;
+        if (MODE == 2) {
+            gt_stats[(size_t)(2 * c) * plane + pix] = fa.x;          // mu2
+            gt_stats[(size_t)(2 * c + 1) * plane + pix] = fa.y;      // E[y^2]
+            return;
+        }
+        float mu1, mu2, e11, e22;
+        if (MODE == 0) {
+            mu1 = fa.x; mu2 = fa.y; e11 = fb.x; e22 = fb.y;
+        } else {
+            mu1 = fa.x; e11 = fa.y;
+            mu2 = gt_stats[(size_t)(2 * c) * plane + pix];
+            e22 = gt_stats[(size_t)(2 * c + 1) * plane + pix];
+        }
         const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
         const float s1 = e11 - mu1s, s2 = e22 - mu2s, s12 = e12 - mu12;
         const float A1 = 2.f * mu12 + SSIM_C1, A2 = 2.f * s12 + SSIM_C2;
@@ -137,12 +166,12 @@ __global__ void __launch_bounds__(256) ssim_stats_kernel(const float* __restrict
         const float d_e11 = -sval / B2;
         const float d_e12 = 2.f * A1 * inv;
         const float d_mu1 = 2.f * mu2 * (A2 - A1) * inv - 2.f * mu1 * sval * (1.f / B1 - 1.f / B2);
-        const size_t plane = (size_t)H * W, pix = (size_t)py * W + px;
         float* base = dmaps + (size_t)c * 3 * plane;
         base[pix] = scale * d_mu1;
         base[plane + pix] = scale * d_e11;
         base[2 * plane + pix] = scale * d_e12;
     }
+    if (MODE == 2) return;
     float v[1] = {sval};
     const int bid = c * gx * gy + tile;
     // block_reduce_store indexes by blockIdx.x only -> reduce by hand here
@@ -349,7 +378,8 @@ size_t gfl_loss_workspace_bytes(int W, int H) {
 static int loss_launch(const float* render, const float* gt_rgb, const float* gt_depth, const uint8_t* keep,
                        const float* depth_ab, float lambda_rgb, float lambda_depth, int W, int H, float* d_render,
                        float* err_px, float* sums, void* workspace, size_t workspace_bytes, gfl_stream_t stream,
-                       const float** p_ssim_out, int* n_ssim, const float** p_grad_out, int* n_grad) {
+                       const float** p_ssim_out, int* n_ssim, const float** p_grad_out, int* n_grad,
+                       const float* gt_stats = nullptr) {
     if (W <= 0 || H <= 0 || !render || !gt_rgb || !d_render || !err_px || !workspace) return GFL_ERR_INVALID;
     if (lambda_depth != 0.f && (!gt_depth || !depth_ab)) return GFL_ERR_INVALID;
     if (workspace_bytes < gfl_loss_workspace_bytes(W, H)) return GFL_ERR_WORKSPACE;
@@ -361,8 +391,12 @@ static int loss_launch(const float* render, const float* gt_rgb, const float* gt
     static const Win win = make_window();
     const float hw = (float)W * (float)H;
     // L = lambda_rgb * (mean mse + 1 - mean S)  ->  dL/dS = -lambda_rgb / (3HW)
-    ssim_stats_kernel<<<gx * gy * 3, 256, 0, s>>>(render, gt_rgb, keep, W, H, gx, gy, win, -lambda_rgb / (3.f * hw),
-                                               dmaps, p_ssim);
+    if (gt_stats)
+        ssim_stats_kernel<1><<<gx * gy * 3, 256, 0, s>>>(render, gt_rgb, keep, W, H, gx, gy, win, -lambda_rgb / (3.f * hw),
+                                                      dmaps, p_ssim, const_cast<float*>(gt_stats));
+    else
+        ssim_stats_kernel<0><<<gx * gy * 3, 256, 0, s>>>(render, gt_rgb, keep, W, H, gx, gy, win, -lambda_rgb / (3.f * hw),
+                                                      dmaps, p_ssim, nullptr);
     loss_grad_kernel<<<gx * gy * 4, 256, 0, s>>>(render, gt_rgb, gt_depth, keep, depth_ab, dmaps, W, H, gx, gy, win,
                                               lambda_rgb * 2.f / (3.f * hw), lambda_depth / hw, d_render, err_px,
                                               p_grad);
@@ -387,6 +421,25 @@ int gfl_loss_fwd_bwd_partials(const float* render, const float* gt_rgb, const fl
     if (!p_ssim || !n_ssim || !p_grad || !n_grad) return GFL_ERR_INVALID;
     return loss_launch(render, gt_rgb, gt_depth, keep, depth_ab, lambda_rgb, lambda_depth, W, H, d_render, err_px,
                        nullptr, workspace, workspace_bytes, stream, p_ssim, n_ssim, p_grad, n_grad);
+}
+
+int gfl_loss_prepare_gt(const float* gt_rgb, const uint8_t* keep, int W, int H, float* gt_stats, gfl_stream_t stream) {
+    if (W <= 0 || H <= 0 || !gt_rgb || !gt_stats) return GFL_ERR_INVALID;
+    const int gx = (W + ST - 1) / ST, gy = (H + ST - 1) / ST;
+    static const Win win = make_window();
+    ssim_stats_kernel<2><<<gx * gy * 3, 256, 0, (hipStream_t)stream>>>(nullptr, gt_rgb, keep, W, H, gx, gy, win, 0.f, nullptr,
+                                                                     nullptr, gt_stats);
+    return check_launch();
+}
+
+int gfl_loss_fwd_bwd_partials_cached(const float* render, const float* gt_rgb, const float* gt_depth,
+                                     const uint8_t* keep, const float* depth_ab, float lambda_rgb, float lambda_depth,
+                                     int W, int H, float* d_render, float* err_px, void* workspace,
+                                     size_t workspace_bytes, const float* gt_stats, const float** p_ssim, int* n_ssim,
+                                     const float** p_grad, int* n_grad, gfl_stream_t stream) {
+    if (!p_ssim || !n_ssim || !p_grad || !n_grad) return GFL_ERR_INVALID;
+    return loss_launch(render, gt_rgb, gt_depth, keep, depth_ab, lambda_rgb, lambda_depth, W, H, d_render, err_px,
+                       nullptr, workspace, workspace_bytes, stream, p_ssim, n_ssim, p_grad, n_grad, gt_stats);
 }
 
 }  // extern "C"

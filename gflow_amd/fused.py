@@ -22,7 +22,7 @@ _I = ctypes.c_int32
 
 
 class FitState(ctypes.Structure):          # mirrors gfl_fit_state
-    _fields_ = [("N", _I), ("cap", _I), ("W", _I), ("H", _I), ("K_cap", _I), ("reserved", _I),
+    _fields_ = [("N", _I), ("cap", _I), ("W", _I), ("H", _I), ("K_cap", _I), ("gt_cached", _I),
                 ("params", _P), ("adam_m", _P), ("adam_v", _P), ("rec", _P), ("d_rec", _P),
                 ("flow_target", _P), ("flow_w", _P), ("still_target", _P), ("still_w", _P), ("row_flags", _P),
                 ("pose", _P), ("pose_m", _P), ("pose_v", _P),
@@ -206,6 +206,10 @@ class FitEngine:
                             ("workspace", self.workspace)):
                 setattr(s, name, None if t is None else t.data_ptr())
             s.workspace_bytes = self.workspace.numel()
+            if self.gt_rgb is not None and self.foot_flags is None:
+                # SSIM statistics of the (masked) target, once per set_targets (gfl_fit_prepare_targets)
+                L.check(self.lib.gfl_fit_prepare_targets(ctypes.byref(s), L.stream()), "fit prepare targets")
+                s.gt_cached = 1
             self._state = s
         return self._state
 

@@ -154,6 +154,16 @@ int gfl_loss_fwd_bwd_partials(const float* render, const float* gt_rgb, const fl
                               float* d_render, float* err_px, void* workspace, size_t workspace_bytes,
                               const float** p_ssim, int* n_ssim, const float** p_grad, int* n_grad,
                               gfl_stream_t stream);
+/* The ground truth does not change during the iterations of a fit: gfl_loss_prepare_gt computes its
+ * two SSIM statistics once (gt_stats[3][2][H][W]: conv(y), conv(y^2), same arithmetic as the full
+ * kernel) and the _cached variant then filters three maps instead of five.  keep must be the mask
+ * the later calls use. */
+int gfl_loss_prepare_gt(const float* gt_rgb, const uint8_t* keep, int W, int H, float* gt_stats, gfl_stream_t stream);
+int gfl_loss_fwd_bwd_partials_cached(const float* render, const float* gt_rgb, const float* gt_depth,
+                                     const uint8_t* keep, const float* depth_ab, float lambda_rgb, float lambda_depth,
+                                     int W, int H, float* d_render, float* err_px, void* workspace,
+                                     size_t workspace_bytes, const float* gt_stats, const float** p_ssim, int* n_ssim,
+                                     const float** p_grad, int* n_grad, gfl_stream_t stream);
 int gfl_loss_fwd_bwd(const float* render, const float* gt_rgb, const float* gt_depth, const uint8_t* keep,
                      const float* depth_ab, float lambda_rgb, float lambda_depth, int W, int H,
                      float* d_render, float* err_px, float* sums, void* workspace, size_t workspace_bytes,
@@ -194,7 +204,8 @@ int gfl_step_increment(int32_t* d_step, gfl_stream_t stream);
  * CUs).  Garbage there cannot change a result, only the balance.  The tile grid is limited to
  * 16384 tiles (GFL_ERR_INVALID beyond). */
 typedef struct gfl_fit_state {
-    int32_t N, cap, W, H, K_cap, reserved;
+    int32_t N, cap, W, H, K_cap;
+    int32_t gt_cached;   /* 1: gfl_fit_prepare_targets ran for the current gt_rgb / keep (ignored with foot_flags) */
     float *params, *adam_m, *adam_v;
     float *rec, *d_rec;
     const float *flow_target, *flow_w, *still_target, *still_w;
@@ -238,6 +249,9 @@ int gfl_fit_forward(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream
 /* loss + backward + optimiser step on the state gfl_fit_forward left behind */
 int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream);
 int gfl_fit_iteration(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream);
+/* once per ground-truth image / keep mask: SSIM statistics of the target into the workspace; set
+ * st->gt_cached = 1 afterwards (0 is always valid: everything is then recomputed per iteration) */
+int gfl_fit_prepare_targets(const gfl_fit_state* st, gfl_stream_t stream);
 /* the per-tile sort of gfl_bin_sort alone (keys already scattered into segments) */
 int gfl_tile_sort_only(const int32_t* tile_offsets, int T, int K_cap, void* keys, int32_t* ids,
                        int32_t* tile_range, gfl_stream_t stream);

@@ -138,3 +138,48 @@ def test_colormap_matches_golden(golden_dir):
     got = apply_float_colormap(d.to(DEV), "turbo", non_zero=True).cpu()
     mism = (ref != got).any(dim=1).double().mean().item()
     assert mism <= 2e-3            # (x*255).long() may land one bin over on a rounding edge
+
+
+@pytest.mark.parametrize("with_mask", [False, True])
+def test_cached_target_statistics_match_full_kernel(with_mask):
+    """gfl_loss_prepare_gt + gfl_loss_fwd_bwd_partials_cached (three filtered maps, the target's two
+    read back) against gfl_loss_fwd_bwd_partials (five maps): the same numbers up to the compiler's
+    choice of fused multiply-adds in the two instantiations."""
+    import ctypes
+    from gflow_amd import _lib as L
+    lib = L.load()
+    H, W = 70, 101
+    g = torch.Generator().manual_seed(11)
+    render = torch.rand(4, H, W, generator=g).to(DEV)
+    gt = torch.rand(H, W, 3, generator=g).to(DEV)
+    gd = (1 + torch.rand(H, W, generator=g)).to(DEV)
+    keep = (torch.rand(H, W, generator=g) > 0.2).to(torch.uint8).to(DEV) if with_mask else None
+    ab = torch.tensor([1.1, -0.05], device=DEV)
+
+    def run(cached):
+        d = torch.empty_like(render)
+        err = torch.empty(H, W, device=DEV)
+        ws = torch.zeros(lib.gfl_loss_workspace_bytes(W, H), dtype=torch.uint8, device=DEV)
+        ps, pg = ctypes.c_void_p(), ctypes.c_void_p()
+        ns, ng = ctypes.c_int(), ctypes.c_int()
+        common = (L.ptr(render), L.ptr(gt), L.ptr(gd), L.ptr(keep), L.ptr(ab), 1.0, 0.1, W, H, L.ptr(d), L.ptr(err),
+                  L.ptr(ws), ws.numel())
+        tail = (ctypes.byref(ps), ctypes.byref(ns), ctypes.byref(pg), ctypes.byref(ng), L.stream())
+        if cached:
+            stats = torch.empty(6, H, W, device=DEV)
+            L.check(lib.gfl_loss_prepare_gt(L.ptr(gt), L.ptr(keep), W, H, L.ptr(stats), L.stream()), "prepare")
+            L.check(lib.gfl_loss_fwd_bwd_partials_cached(*common, L.ptr(stats), *tail), "cached")
+        else:
+            L.check(lib.gfl_loss_fwd_bwd_partials(*common, *tail), "plain")
+        torch.cuda.synchronize()
+        n = ns.value
+        off = ps.value - ws.data_ptr()
+        part = ws[off:off + 4 * n].view(torch.float32).clone()
+        return d, err, part
+
+    d0, e0, p0 = run(False)
+    d1, e1, p1 = run(True)
+    assert torch.equal(e0, e1)
+    scale = d0.abs().max().item()
+    assert (d0 - d1).abs().max().item() <= 2e-6 * scale
+    torch.testing.assert_close(p0, p1, rtol=1e-6, atol=1e-5)
