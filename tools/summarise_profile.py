@@ -21,7 +21,7 @@ STAGE_OF = {                       # kernel -> bench.py stage name
 
 
 def short(name):
-    name = name.split("(")[0]
+    name = name.split("(")[0].split("<")[0]
     return name.replace("gfl::", "").replace("void ", "").strip()
 
 
