@@ -133,7 +133,6 @@ __device__ __forceinline__ void sort_tile_and_emit(unsigned long long* __restric
     for (int e = 0; e < E; ++e) {
         const int idx = tid * E + e;
         if (idx < n) {
-            seg[idx] = key[e];
             const int g = (int32_t)(unsigned)(key[e] & 0xffffffffull);
             ids[start + idx] = g;
             if (slot_inv) write_slot(slot_rec, slot_inv, slot_pool, g, tile, gx, gy, start + idx);
