@@ -572,6 +572,7 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
     int units = 0;
 #ifdef GFL_TRACE
     const long long trace_t0 = wall_clock64();
+    int trace_lanes = 0;
 #endif
 
     float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, T = 1.f, S = 0.f;
@@ -642,6 +643,9 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
                 float alpha, G;
                 const bool valid = splat_alpha2(p0, p1, fx, fy, alpha, G) && (pos < last);
                 if (__ballot(valid) == 0ull) continue;
+#ifdef GFL_TRACE
+                trace_lanes += __popcll(__ballot(valid));
+#endif
                 ++units;                     // wave-uniform: work feedback for the tile scheduler
                 // (an interleaved two-splat version of this body was measured slower, twice)
                 float v[10];
@@ -673,7 +677,7 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
             tr[2] = ((long long)total << 32) | (unsigned)depth_n;
             tr[3] = ((long long)(xcc & 15) << 32) | hw;
         }
-        tr[4 + wave] = (unsigned)units;
+        tr[4 + wave] = ((long long)trace_lanes << 32) | (unsigned)units;
     }
 #endif
   }

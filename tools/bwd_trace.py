@@ -84,3 +84,6 @@ for r in rows[-2:]:
 U = np.array([r[1] for r in rows]); E = np.array([r[0] for r in rows])
 print("CU units mean %.0f max %d min %d ; end mean %.1f min %.1f max %.1f ; corr(end, units) %.2f" %
       (U.mean(), U.max(), U.min(), E.mean(), E.min(), E.max(), np.corrcoef(E, U)[0, 1]))
+if not FWD:
+    lanes = (a[:, 4:8] >> 32).sum()
+    print("valid lanes per unit: %.1f of 64" % (lanes / max(units.sum(), 1)))
