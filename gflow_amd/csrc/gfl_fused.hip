@@ -486,6 +486,7 @@ __global__ void __launch_bounds__(256, 8) fused_blend_fwd_kernel(const float* __
         c5[0] = T; c5[256] = a0; c5[512] = a1; c5[768] = a2; c5[1024] = a3;
     }
 #ifdef GFL_TRACE
+    const int trace_done = __popcll(__ballot(done && inside));
     if (lane == 0 && tile < 16384) {
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -496,7 +497,7 @@ __global__ void __launch_bounds__(256, 8) fused_blend_fwd_kernel(const float* __
             tr[2] = ((long long)(end - start) << 32) | (unsigned)(end - start);
             tr[3] = ((long long)(xcc & 15) << 32) | hw;
         }
-        tr[4 + wave] = (unsigned)trace_units;
+        tr[4 + wave] = ((long long)trace_done << 32) | (unsigned)trace_units;
     }
 #endif
   }

@@ -87,3 +87,8 @@ print("CU units mean %.0f max %d min %d ; end mean %.1f min %.1f max %.1f ; corr
 if not FWD:
     lanes = (a[:, 4:8] >> 32).sum()
     print("valid lanes per unit: %.1f of 64" % (lanes / max(units.sum(), 1)))
+if FWD:
+    done_px = (a[:, 4:8] >> 32).sum(1)
+    heavy = total > np.percentile(total, 95)
+    print("terminated pixels per tile (of 256): all tiles mean %.1f ; 5%% longest lists mean %.1f max %d" %
+          (done_px.mean(), done_px[heavy].mean(), done_px.max()))
