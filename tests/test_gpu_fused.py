@@ -358,3 +358,42 @@ def test_fused_gradients_with_four_segment_heavy_tiles():
         got = m1[:, a:b] / 0.1
         rel = ((got - ref).norm() / ref.norm()).item()
         assert rel < 2e-3, f"d_{k}: relative L2 error {rel:.2e}"
+
+
+def test_fullsize_properties_sorted_lists_and_feature_linearity():
+    """Size-independent properties at the benchmark size (480p, 60k splats), no oracle needed:
+    every tile list is ordered by (depth, id); the list covers exactly the pairs counted; the blend
+    is linear in the features (bg = 0) and reproduces itself."""
+    from gflow_amd import synthetic as S
+    import gflow_amd.msplat as msplat
+    H, W, N = 480, 854, 60000
+    frame = S.make_frame(H, W, seed=1)
+    raw = S.init_splats(frame, N, seed=1, grown=True)
+    s = dict(W=W, H=H, intr=raw["intr"])
+    eng = _engine({k: raw[k] for k in ("xyz", "scale", "rotate", "opacity", "rgb")}, s, frame["image"], frame["depth"])
+    eng.forward()
+    eng.check_overflow()
+    K = eng.K
+    tr = eng.tile_range.long()
+    lens = tr[:, 1] - tr[:, 0]
+    assert int(lens.sum()) == K and int(lens.min()) >= 0
+    ids = eng.ids[:K].long()
+    depth = eng.depth.reshape(-1)[ids]
+    tile_of = torch.repeat_interleave(torch.arange(tr.shape[0], device=DEV), lens)
+    same_tile = tile_of[1:] == tile_of[:-1]
+    d0, d1 = depth[:-1], depth[1:]
+    ordered = (d1 > d0) | ((d1 == d0) & (ids[1:] > ids[:-1]))
+    assert bool((ordered | ~same_tile).all()), "a tile list is not sorted by (depth, id)"
+    assert bool((depth > 0).all()), "a culled splat was binned"
+    # linearity of the operator in the features and run-to-run reproducibility of the forward
+    rec = eng.rec[:N]
+    uv, conic, op = rec[:, 0:2].contiguous(), rec[:, 2:5].contiguous(), rec[:, 5:6].contiguous()
+    g = torch.Generator(device=DEV).manual_seed(0)
+    f1, f2 = torch.rand(N, 3, device=DEV, generator=g), torch.rand(N, 3, device=DEV, generator=g)
+    blend = lambda f: msplat.alpha_blending(uv, conic, op, f, eng.ids[:K], eng.tile_range, 0.0, W, H)
+    a, b, c = blend(f1), blend(f2), blend(f1 + 2.0 * f2)
+    assert (c - (a + 2.0 * b)).abs().max().item() < 2e-5
+    assert torch.equal(blend(f1), a)
+    first = eng.render.clone()
+    eng.forward()
+    assert torch.equal(eng.render, first), "the fused forward is not reproducible"
