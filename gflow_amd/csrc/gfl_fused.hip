@@ -689,37 +689,61 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
 // is > 0 (trainer.py:426-451).  With a black background that is exactly the set of pixels some
 // moving splat reaches with alpha >= 1/255 in a tile it was binned into: the first such splat in
 // depth order always blends (T = 1), and every colour is a sigmoid, hence > 0.  So no second sort
-// and composite: one wave per flagged splat marks its pixels, in any order.
+// and composite: the flagged splats of every tile list mark their pixels, in any order.
 __global__ void __launch_bounds__(256) keep_init_kernel(const uint8_t* __restrict__ move_mask, int P, int all_masked,
                                                         uint8_t* __restrict__ keep) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < P) keep[i] = (all_masked || (move_mask && move_mask[i])) ? 0 : 1;
 }
 
-__global__ void __launch_bounds__(256) footprint_kernel(const float* __restrict__ rec,
-                                                        const uint8_t* __restrict__ foot_flags, int N, int W, int H,
-                                                        int gx, int gy, uint8_t* __restrict__ keep) {
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (i >= N || !foot_flags[i]) return;
-    const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)i * REC);
-    const float4 p0 = r4[0], p1 = r4[1], p2 = r4[2];
-    const int rad = __float_as_int(p2.w);
-    if (rad <= 0 || p2.z < 0.f) return;                   // culled, or never reaches alpha >= 1/255
-    int tx0, tx1, ty0, ty1;
-    tile_rect(p0.x, p0.y, rad, gx, gy, tx0, tx1, ty0, ty1);
-    // pixels of the binned tiles, clipped to the box around the alpha >= 1/255 disc
-    const float r = sqrtf(p2.z) + 1.f;
-    const int bx0 = max(tx0 * GFL_TILE, (int)floorf(p0.x - r)), bx1 = min(min(tx1 * GFL_TILE, W), (int)ceilf(p0.x + r) + 1);
-    const int by0 = max(ty0 * GFL_TILE, (int)floorf(p0.y - r)), by1 = min(min(ty1 * GFL_TILE, H), (int)ceilf(p0.y + r) + 1);
-    const int bw = bx1 - bx0, bh = by1 - by0;
-    if (bw <= 0 || bh <= 0) return;
-    for (int q = lane; q < bw * bh; q += 64) {
-        const int py = by0 + q / bw, px = bx0 + q % bw;
-        if (!tile_hit2(p0.x, p0.y, p2.z, px / GFL_TILE, py / GFL_TILE)) continue;   // the pair was not binned
-        float alpha, G;
-        if (splat_alpha2(p0, p1, (float)px, (float)py, alpha, G)) keep[(size_t)py * W + px] = 0;
+// One workgroup per tile walks the tile's list (already binned and sorted by the forward that just
+// ran) and evaluates only the flagged splats, lanes = pixels as in the blend; a wave stops as soon
+// as all its pixels are marked.  (A first version gave every flagged splat one wave that walked the
+// splat's bounding box: later frames of a clip grow moving splats hundreds of pixels wide, and
+// that launch then took 325 us.)
+__global__ void __launch_bounds__(256) footprint_kernel(const float* __restrict__ rec, const int32_t* __restrict__ ids,
+                                                        const int32_t* __restrict__ tile_range,
+                                                        const uint8_t* __restrict__ foot_flags, int W, int H, int gx,
+                                                        uint8_t* __restrict__ keep) {
+    __shared__ RecLDS recs[FB];
+    __shared__ unsigned char s_mask[FB];
+    const int tile = blockIdx.x;
+    const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int px = tx * GFL_TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * GFL_TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float fx = (float)px, fy = (float)py;
+    const int start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
+    bool marked = !inside;                               // nothing left to find for this lane
+    for (int base = start; base < end; base += FB) {
+        if (__syncthreads_and(marked)) break;
+        const int idx = base + tid;
+        unsigned char m = 0;
+        if (idx < end) {
+            const int g = ids[idx];
+            if (foot_flags[g]) {
+                const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g * REC);
+                const float4 p0 = r4[0], p1 = r4[1], p2 = r4[2];
+                recs[tid].p0 = p0; recs[tid].p1 = p1;
+                m = (unsigned char)block_mask(p0.x, p0.y, p2.z, tx * GFL_TILE, ty * GFL_TILE);
+            }
+        }
+        s_mask[tid] = m;
+        __syncthreads();
+        const int cnt = min(FB, end - base);
+        for (int c0 = 0; c0 < cnt && !__all(marked); c0 += 64) {
+            const int slot = c0 + lane;
+            unsigned long long bits = __ballot(slot < cnt && ((s_mask[slot] >> wave) & 1));
+            while (bits) {
+                const int j = c0 + (int)__builtin_ctzll(bits);
+                bits &= bits - 1;
+                float alpha, G;
+                if (splat_alpha2(recs[j].p0, recs[j].p1, fx, fy, alpha, G)) marked = true;
+            }
+        }
     }
+    if (inside && marked) keep[(size_t)py * W + px] = 0;
 }
 
 // ------------------------------------------------- preprocess backward + Adam (A13)
@@ -1232,8 +1256,8 @@ int gfl_fit_forward(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream
             const int P = st->W * st->H;
             keep_init_kernel<<<(P + 255) / 256, 256, 0, s>>>(st->move_mask, P, hp->bg > 0.f ? 1 : 0, st->keep);
             if (!(hp->bg > 0.f) && st->N > 0)
-                footprint_kernel<<<(st->N + 3) / 4, 256, 0, s>>>(st->rec, st->foot_flags, st->N, st->W, st->H, gx, gy,
-                                                               st->keep);
+                footprint_kernel<<<T, 256, 0, s>>>(st->rec, st->ids, st->tile_range, st->foot_flags, st->W, st->H, gx,
+                                                   st->keep);
         }
     }
     return check_launch();
