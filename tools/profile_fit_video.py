@@ -34,4 +34,4 @@ m = FV.fit_clip(frames, dev, dict(num_points=60000), seed=0)
 torch.cuda.synchronize()
 pr.disable()
 print("fit_clip s", time.perf_counter() - t0, m)
-pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
+pstats.Stats(pr).sort_stats("tottime").print_stats(28)
