@@ -56,6 +56,7 @@ SIGNATURES = {
     "gfl_fit_backward_step": (c_int, [_P, _P, _P]),
     "gfl_fit_iteration": (c_int, [_P, _P, _P]),
     "gfl_fit_prepare_targets": (c_int, [_P, _P]),
+    "gfl_fit_schedule_info": (c_int, [_P, _P, _P, _P, _P]),
     "gfl_selftest_reduce10": (c_int, [_P, _P, _P, _P]),
     "gfl_abi_sizes": (c_int, [_P, _P]),
     "gfl_profile_enable": (c_int, [ctypes.c_uint]),

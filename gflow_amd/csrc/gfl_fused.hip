@@ -1323,6 +1323,18 @@ int gfl_fit_prepare_targets(const gfl_fit_state* st, gfl_stream_t stream) {
     return gfl_loss_prepare_gt(st->gt_rgb, st->keep, st->W, st->H, w.gt_stats, stream);
 }
 
+int gfl_fit_schedule_info(const gfl_fit_state* st, int* n_queues, int* queue_capacity, const int32_t** d_lists,
+                          const int32_t** d_counts) {
+    if (!st || !n_queues || !queue_capacity || !d_lists || !d_counts || !st->workspace) return GFL_ERR_INVALID;
+    if (st->workspace_bytes < gfl_fit_workspace_bytes(st->cap, st->K_cap, st->W, st->H)) return GFL_ERR_WORKSPACE;
+    const FitWs w = carve(st);
+    *n_queues = w.sched.nq;
+    *queue_capacity = w.sched.cap_q;
+    *d_lists = w.sched.list;
+    *d_counts = w.sched.count;
+    return GFL_OK;
+}
+
 int gfl_fit_iteration(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream) {
     int rc = gfl_fit_forward(st, hp, stream);
     if (rc) return rc;

@@ -256,6 +256,19 @@ class FitEngine:
     def K(self):
         return int(self.tile_offsets[self.T].item())
 
+    def schedule(self):
+        """The tile queues of the last forward as a list of 1-D int64 tensors (tile ids per queue)."""
+        nq, cap = ctypes.c_int(), ctypes.c_int()
+        lists, counts = ctypes.c_void_p(), ctypes.c_void_p()
+        L.check(self.lib.gfl_fit_schedule_info(ctypes.byref(self.state()), ctypes.byref(nq), ctypes.byref(cap),
+                                               ctypes.byref(lists), ctypes.byref(counts)), "fit schedule info")
+        off_l = lists.value - self.workspace.data_ptr()
+        off_c = counts.value - self.workspace.data_ptr()
+        torch.cuda.synchronize(self.dev)
+        lst = self.workspace[off_l:off_l + 4 * nq.value * cap.value].view(torch.int32).reshape(nq.value, cap.value).cpu()
+        cnt = self.workspace[off_c:off_c + 4 * nq.value].view(torch.int32).cpu()
+        return [(lst[c, :int(cnt[c])] & 0x0fffffff).long() for c in range(nq.value)]
+
     def check_overflow(self):
         if int(self.overflow.item()):
             self.overflow.zero_()          # the flag is sticky on the device

@@ -397,3 +397,27 @@ def test_fullsize_properties_sorted_lists_and_feature_linearity():
     first = eng.render.clone()
     eng.forward()
     assert torch.equal(eng.render, first), "the fused forward is not reproducible"
+
+
+@pytest.mark.parametrize("H,W,N", [(48, 64, 800), (256, 272, 6000), (480, 854, 60000)])
+def test_tile_schedule_is_a_partition_of_the_tiles(H, W, N):
+    """Every tile sits in exactly one queue, before and after the scheduler has work feedback (12,
+    272 and 1620 tiles against 256 queues: fewer tiles than queues, one partial extra round, many)."""
+    from gflow_amd import synthetic as S
+    frame = S.make_frame(H, W, seed=3)
+    raw = S.init_splats(frame, N, seed=3, grown=True)
+    s = dict(W=W, H=H, intr=raw["intr"])
+    eng = _engine({k: raw[k] for k in ("xyz", "scale", "rotate", "opacity", "rgb")}, s, frame["image"], frame["depth"],
+                  lr=1e-3, lambda_rgb=1.0, lambda_depth=0.1)
+    T = eng.T
+    for it in range(3):
+        eng.iteration()
+        queues = eng.schedule()
+        tiles = torch.cat(queues)
+        assert tiles.numel() == T, f"iteration {it}: {tiles.numel()} scheduled items for {T} tiles"
+        assert torch.equal(torch.sort(tiles).values, torch.arange(T)), f"iteration {it}: not a partition"
+    # with feedback the queues carry similar loads (weights = list lengths as a proxy here)
+    if T >= 1024:
+        lens = (eng.tile_range[:, 1] - eng.tile_range[:, 0]).cpu().float()
+        loads = torch.tensor([float(lens[q].sum()) for q in queues])
+        assert loads.max() < 1.6 * loads.mean()
