@@ -328,6 +328,8 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* _
 
 // ------------------------------------------------------------------- blend (C = 4)
 constexpr int BLEND_WG_PER_CU = 8;
+constexpr int FWD_WG_PER_CU = 6;       // the forward blend trades two workgroups per CU for 72 VGPRs (FWD_UNITS)
+constexpr int FWD_UNITS = 4;
 constexpr int FB = 256;   // staged splats per batch (forward)
 constexpr int FBB = 192;  // backward: 18.6 KB of LDS per workgroup -> 8 workgroups per CU, so that all
                           // 1620 tiles of a 480p frame are resident at once (no second round)
@@ -367,7 +369,7 @@ __device__ __forceinline__ unsigned block_mask(float u, float v, float cutoff, i
 __device__ long long g_fwd_trace[16384 * 8];     // analysis build: per-tile timeline of the forward blend
 #endif
 
-__global__ void __launch_bounds__(256, 8) fused_blend_fwd_kernel(const float* __restrict__ rec,
+__global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(const float* __restrict__ rec,
                                                               const int32_t* __restrict__ ids,
                                                               const int32_t* __restrict__ tile_range, float bg, int W,
                                                               int H, int gx, float* __restrict__ out,
@@ -426,45 +428,47 @@ __global__ void __launch_bounds__(256, 8) fused_blend_fwd_kernel(const float* __
             const int slot = c0 + lane;
             const bool hit = slot < cnt && ((s_mask[slot] >> wave) & 1);
             unsigned long long bits = __ballot(hit);
-            // Two hit splats per trip: their records are fetched and their alphas evaluated
-            // together (independent work hides the LDS latency); only the T recurrence is serial.
-            // The body is branch-free: a lane that skips a splat contributes w = 0.
-            // (Four per trip, and requesting the next pair's records one trip ahead, were both
-            // measured slower: they spill at the 64-VGPR budget of 8 workgroups per CU.)
+            // FWD_UNITS (4) hit splats per trip: their records are fetched and their alphas
+            // evaluated together; only the T recurrence is serial.  The body is branch-free: a lane
+            // that skips a splat contributes w = 0.  A wave issues one instruction at a time, so the
+            // wave of a long list is bound by its own instruction count (a heavy workgroup left
+            // ALONE on its CU still took ~380 cycles per splat): four per trip amortise the scalar
+            // loop control (two: 52 us; four at 72 VGPRs, six workgroups per CU: 48 us; four at the
+            // 64-VGPR budget of eight workgroups spill and gain nothing; requesting the next
+            // records a trip ahead was slower: LDS returns in order, the wait covers them too).
             while (bits) {
-                const int ja = c0 + (int)__builtin_ctzll(bits);
-                bits &= bits - 1;
-                const bool two = bits != 0ull;
-                const int jb = two ? c0 + (int)__builtin_ctzll(bits) : ja;
-                bits &= bits - 1;            // no-op when bits is already 0
-#ifdef GFL_TRACE
-                trace_units += two ? 2 : 1;
-#endif
-                const float4 pa0 = recs[ja].p0, pa1 = recs[ja].p1, pa2 = recs[ja].p2;
-                const float4 pb0 = recs[jb].p0, pb1 = recs[jb].p1, pb2 = recs[jb].p2;
-                float alpha_a, alpha_b, G;
-                const bool va = splat_alpha2(pa0, pa1, fx, fy, alpha_a, G);
-                const bool vb = splat_alpha2(pb0, pb1, fx, fy, alpha_b, G) && two;
-                {
-                    const float test_T = T * (1.f - alpha_a);
-                    const bool live = va && !done;
-                    const bool stop = live && test_T < GFL_T_MIN;
-                    const bool use = live && !stop;
-                    const float w = use ? alpha_a * T : 0.f;
-                    a0 = fmaf(pa1.z, w, a0); a1 = fmaf(pa1.w, w, a1); a2 = fmaf(pa2.x, w, a2); a3 = fmaf(pa2.y, w, a3);
-                    T = use ? test_T : T;
-                    last = use ? base - start + ja + 1 : last;
-                    done = done || stop;
+                int j[FWD_UNITS];
+                bool on[FWD_UNITS];
+#pragma unroll
+                for (int u = 0; u < FWD_UNITS; ++u) {
+                    on[u] = bits != 0ull;
+                    j[u] = on[u] ? c0 + (int)__builtin_ctzll(bits) : j[0];
+                    bits &= bits - 1;        // no-op when bits is already 0
                 }
-                {
-                    const float test_T = T * (1.f - alpha_b);
-                    const bool live = vb && !done;
+#ifdef GFL_TRACE
+#pragma unroll
+                for (int u = 0; u < FWD_UNITS; ++u) trace_units += on[u] ? 1 : 0;
+#endif
+                float4 q0[FWD_UNITS], q1[FWD_UNITS], q2[FWD_UNITS];
+#pragma unroll
+                for (int u = 0; u < FWD_UNITS; ++u) { q0[u] = recs[j[u]].p0; q1[u] = recs[j[u]].p1; q2[u] = recs[j[u]].p2; }
+                float al[FWD_UNITS];
+                bool val[FWD_UNITS];
+#pragma unroll
+                for (int u = 0; u < FWD_UNITS; ++u) {
+                    float G;
+                    val[u] = splat_alpha2(q0[u], q1[u], fx, fy, al[u], G) && on[u];
+                }
+#pragma unroll
+                for (int u = 0; u < FWD_UNITS; ++u) {
+                    const float test_T = T * (1.f - al[u]);
+                    const bool live = val[u] && !done;
                     const bool stop = live && test_T < GFL_T_MIN;
                     const bool use = live && !stop;
-                    const float w = use ? alpha_b * T : 0.f;
-                    a0 = fmaf(pb1.z, w, a0); a1 = fmaf(pb1.w, w, a1); a2 = fmaf(pb2.x, w, a2); a3 = fmaf(pb2.y, w, a3);
+                    const float w = use ? al[u] * T : 0.f;
+                    a0 = fmaf(q1[u].z, w, a0); a1 = fmaf(q1[u].w, w, a1); a2 = fmaf(q2[u].x, w, a2); a3 = fmaf(q2[u].y, w, a3);
                     T = use ? test_T : T;
-                    last = use ? base - start + jb + 1 : last;
+                    last = use ? base - start + j[u] + 1 : last;
                     done = done || stop;
                 }
                 if (__all(done)) break;
@@ -1123,10 +1127,10 @@ static int blend_queues() {
 }
 
 // workgroups of a blend launch: up to 8 per queue (all resident), fewer for small tile grids
-static int blend_grid(int T) {
+static int blend_grid(int T, int max_per_cu = BLEND_WG_PER_CU) {
     const int nq = blend_queues();
     int per = (T + nq - 1) / nq + 1;
-    if (per > BLEND_WG_PER_CU) per = BLEND_WG_PER_CU;
+    if (per > max_per_cu) per = max_per_cu;
     return nq * per;
 }
 
@@ -1249,7 +1253,7 @@ int gfl_fit_forward(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream
     {
         StageScope p(ST_BLEND_FWD, s);
         const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters, w.sched.nq, w.sched.cap_q};
-        fused_blend_fwd_kernel<<<blend_grid(T), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx,
+        fused_blend_fwd_kernel<<<blend_grid(T, FWD_WG_PER_CU), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx,
                                                              st->render, st->final_T, st->n_contrib, q, w.ckpt);
         if (st->foot_flags) {
             if (!st->keep) return GFL_ERR_INVALID;
