@@ -401,12 +401,14 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     int trace_units = 0;
 #endif
 
-    float T = 1.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    // Tw: working transmittance, set to 0 when the pixel stops (T would fall below 1e-4) so that
+    // everything behind blends with weight 0 without a per-splat "done" flag; T keeps the value
+    // the pixel stopped at.  (Lanes outside the image start stopped.)
+    float T = 1.f, Tw = inside ? 1.f : 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int last = 0;
-    bool done = !inside;
 
     for (int base = start; base < end; base += FB) {
-        if (__syncthreads_and(done)) break;
+        if (__syncthreads_and(Tw == 0.f)) break;
         const int idx = base + tid;
         if (idx < end) {
             const int g = ids[idx];
@@ -417,9 +419,9 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
         }
         __syncthreads();
         const int cnt = min(FB, end - base);
-        if (__all(done)) continue;      // this wave is finished; keep meeting the barriers
+        if (__all(Tw == 0.f)) continue;      // this wave is finished; keep meeting the barriers
         for (int c0 = 0; c0 < cnt; c0 += 64) {
-            if (__all(done)) break;
+            if (__all(Tw == 0.f)) break;
             if (ck_next < parts && base - start + c0 == ck_next * seg) {
                 float* c5 = ck + (size_t)(ck_next - 1) * 5 * 256;
                 c5[0] = T; c5[256] = a0; c5[512] = a1; c5[768] = a2; c5[1024] = a3;
@@ -461,17 +463,16 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                 }
 #pragma unroll
                 for (int u = 0; u < FWD_UNITS; ++u) {
-                    const float test_T = T * (1.f - al[u]);
-                    const bool live = val[u] && !done;
-                    const bool stop = live && test_T < GFL_T_MIN;
-                    const bool use = live && !stop;
-                    const float w = use ? al[u] * T : 0.f;
+                    const float a = val[u] ? al[u] : 0.f;
+                    const float test_T = Tw * (1.f - a);
+                    const bool stop = test_T < GFL_T_MIN;            // now, or earlier (Tw = 0)
+                    const float w = stop ? 0.f : a * Tw;
                     a0 = fmaf(q1[u].z, w, a0); a1 = fmaf(q1[u].w, w, a1); a2 = fmaf(q2[u].x, w, a2); a3 = fmaf(q2[u].y, w, a3);
-                    T = use ? test_T : T;
-                    last = use ? base - start + j[u] + 1 : last;
-                    done = done || stop;
+                    T = stop ? T : test_T;
+                    Tw = stop ? 0.f : test_T;
+                    last = (val[u] && !stop) ? base - start + j[u] + 1 : last;
                 }
-                if (__all(done)) break;
+                if (__all(Tw == 0.f)) break;
             }
         }
     }
@@ -490,7 +491,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
         c5[0] = T; c5[256] = a0; c5[512] = a1; c5[768] = a2; c5[1024] = a3;
     }
 #ifdef GFL_TRACE
-    const int trace_done = __popcll(__ballot(done && inside));
+    const int trace_done = __popcll(__ballot(Tw == 0.f && inside));
     if (lane == 0 && tile < 16384) {
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
