@@ -94,25 +94,33 @@ __device__ __forceinline__ void permlane16_swap(float& a, float& b) {
     asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
+// five (three) independent swaps behind ONE hazard nop: the operands of all of them are written
+// before the block, and no swap reads what another one wrote
+__device__ __forceinline__ void permlane32_swap_x5(float (&a)[5], float (&b)[5]) {
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %5\n\tv_permlane32_swap_b32 %1, %6\n\tv_permlane32_swap_b32 %2, %7\n\t"
+        "v_permlane32_swap_b32 %3, %8\n\tv_permlane32_swap_b32 %4, %9"
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]));
+}
+__device__ __forceinline__ void permlane16_swap_x3(float (&a)[3], float (&b)[3]) {
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %3\n\tv_permlane16_swap_b32 %1, %4\n\tv_permlane16_swap_b32 %2, %5"
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));
+}
+
 __device__ __forceinline__ float wave_reduce_scatter10(const float (&v)[10], int lane, int& comp) {
     float w[5];
+    {
+        float a[5] = {v[0], v[2], v[4], v[6], v[8]}, b[5] = {v[1], v[3], v[5], v[7], v[9]};
+        permlane32_swap_x5(a, b);     // a = {a_lo, b_lo}, b = {a_hi, b_hi}
 #pragma unroll
-    for (int m = 0; m < 5; ++m) {
-        float a = v[2 * m], b = v[2 * m + 1];
-        permlane32_swap(a, b);        // a = {a_lo, b_lo}, b = {a_hi, b_hi}
-        w[m] = a + b;                 // lanes 0-31: component 2m, lanes 32-63: component 2m+1
+        for (int m = 0; m < 5; ++m) w[m] = a[m] + b[m];   // lanes 0-31: component 2m, lanes 32-63: component 2m+1
     }
     float x[3];
     {
-        float a = w[0], b = w[1];
-        permlane16_swap(a, b);        // a = {a_r0, b_r0, a_r2, b_r2}, b = {a_r1, b_r1, a_r3, b_r3}
-        x[0] = a + b;
-        a = w[2]; b = w[3];
-        permlane16_swap(a, b);
-        x[1] = a + b;
-        a = w[4]; b = 0.f;
-        permlane16_swap(a, b);
-        x[2] = a + b;
+        float a[3] = {w[0], w[2], w[4]}, b[3] = {w[1], w[3], 0.f};
+        permlane16_swap_x3(a, b);     // a = {a_r0, b_r0, a_r2, b_r2}, b = {a_r1, b_r1, a_r3, b_r3}
+        x[0] = a[0] + b[0];
+        x[1] = a[1] + b[1];
+        x[2] = a[2] + b[2];
     }
     // stage 3: the three values of a 16-lane row.  Instead of three independent 4-step reductions
     // (12 DPP adds) the values are folded onto lane classes on the way: after the xor-1 step the
