@@ -83,7 +83,7 @@ __device__ __forceinline__ int xcd_logical_block(int b, int nb) {
 // Afterwards, in row r = (hi, odd) = (lane>>5, (lane>>4)&1) every lane holds
 //   x0 = sum of component 2*odd + hi,  x1 = sum of component 4 + 2*odd + hi,
 //   x2 = sum of component 8 + hi (even rows only).
-// Returns the value lane (lane & 15) in {0,1,2} owns and its component index in `comp` (-1: none).
+// Returns the value this lane ends up with; reduce_scatter10_component(lane) says which component it is.
 // NOTE (ROCm 7.2 hipcc): __builtin_amdgcn_permlane{16,32}_swap returns the updated vdst in BOTH
 // elements of its result (verified on hardware), so the swaps are issued as inline asm; the
 // leading s_nop covers the VALU-write -> permlane-read hazard that hipcc does not pad inside asm.
@@ -106,7 +106,7 @@ __device__ __forceinline__ void permlane16_swap_x3(float (&a)[3], float (&b)[3])
         : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));
 }
 
-__device__ __forceinline__ float wave_reduce_scatter10(const float (&v)[10], int lane, int& comp) {
+__device__ __forceinline__ float wave_reduce_scatter10(const float (&v)[10], int lane) {
     float w[5];
     {
         float a[5] = {v[0], v[2], v[4], v[6], v[8]}, b[5] = {v[1], v[3], v[5], v[7], v[9]};
@@ -137,9 +137,15 @@ __device__ __forceinline__ float wave_reduce_scatter10(const float (&v)[10], int
     t += GFL_DPP(t, 0x128);                                  // row_ror:8
 #undef GFL_DPP
     // lane & 3 == 0: x0 total, == 1: x1 total, >= 2: x2 total
-    const int hi = lane >> 5, odd = (lane >> 4) & 1, sel = lane & 15;
-    comp = sel == 0 ? 2 * odd + hi : (sel == 1 ? 4 + 2 * odd + hi : ((sel == 2 && odd == 0) ? 8 + hi : -1));
     return t;
+}
+
+// which of the ten components the value returned to this lane belongs to (-1: a duplicate, not to
+// be used).  Depends on the lane only: callers evaluate it ONCE, outside their loops (inside, the
+// compiler turned the nested selects into a dozen exec-mask instructions per call).
+__device__ __forceinline__ int reduce_scatter10_component(int lane) {
+    const int hi = lane >> 5, odd = (lane >> 4) & 1, sel = lane & 15;
+    return sel == 0 ? 2 * odd + hi : (sel == 1 ? 4 + 2 * odd + hi : ((sel == 2 && odd == 0) ? 8 + hi : -1));
 }
 
 // Deterministic block-level reduction of NV values -> one partial row per block.

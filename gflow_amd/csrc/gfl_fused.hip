@@ -560,6 +560,7 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
     __shared__ int32_t s_units;
     __shared__ int32_t s_ticket;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int comp = reduce_scatter10_component(lane);     // the component this lane adds into acc[][]
   for (bool first = true;; first = false) {
     const TileItem item = next_item(queue, &s_ticket, first, true);
     const int tile = item.tile;
@@ -656,8 +657,7 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
                 // (an interleaved two-splat version of this body was measured slower, twice)
                 float v[10];
                 blend_bwd_terms(p0, p1, p2, fx, fy, valid, alpha, G, g0, g1, g2, g3, T, S, v);
-                int comp;
-                const float mine = wave_reduce_scatter10(v, lane, comp);
+                const float mine = wave_reduce_scatter10(v, lane);
                 if (comp >= 0) atomicAdd(&acc[j][comp], mine);
             }
         }

@@ -11,8 +11,8 @@ __global__ void __launch_bounds__(64) selftest_reduce10_kernel(const float* __re
     float v[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) v[k] = in[lane * 10 + k];
-    int comp;
-    const float mine = wave_reduce_scatter10(v, lane, comp);
+    const int comp = reduce_scatter10_component(lane);
+    const float mine = wave_reduce_scatter10(v, lane);
     if (comp >= 0) out[comp] = mine;
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
