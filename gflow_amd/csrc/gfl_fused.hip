@@ -376,10 +376,14 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                                                               float* __restrict__ final_T,
                                                               int32_t* __restrict__ n_contrib, TileQueue queue,
                                                               float* __restrict__ ckpt) {
-    __shared__ RecLDS recs[FB];
+    __shared__ RecLDS recs[FB + 1];          // recs[FB]: an all-zero record (opacity 0: never blends)
     __shared__ unsigned char s_mask[FB];
     __shared__ int32_t s_ticket;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        recs[FB].p0 = z; recs[FB].p1 = z; recs[FB].p2 = z;
+    }
   for (bool first = true;; first = false) {
     const TileItem item = next_item(queue, &s_ticket, first, false);
     const int tile = item.tile;
@@ -439,17 +443,15 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
             // 64-VGPR budget of eight workgroups spill and gain nothing; requesting the next
             // records a trip ahead was slower: LDS returns in order, the wait covers them too).
             while (bits) {
-                int j[FWD_UNITS];
-                bool on[FWD_UNITS];
+                int j[FWD_UNITS];            // missing splats of the last trip: the null record
 #pragma unroll
                 for (int u = 0; u < FWD_UNITS; ++u) {
-                    on[u] = bits != 0ull;
-                    j[u] = on[u] ? c0 + (int)__builtin_ctzll(bits) : j[0];
+                    j[u] = bits ? c0 + (int)__builtin_ctzll(bits) : FB;
                     bits &= bits - 1;        // no-op when bits is already 0
                 }
 #ifdef GFL_TRACE
 #pragma unroll
-                for (int u = 0; u < FWD_UNITS; ++u) trace_units += on[u] ? 1 : 0;
+                for (int u = 0; u < FWD_UNITS; ++u) trace_units += j[u] != FB ? 1 : 0;
 #endif
                 float4 q0[FWD_UNITS], q1[FWD_UNITS], q2[FWD_UNITS];
 #pragma unroll
@@ -459,7 +461,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
 #pragma unroll
                 for (int u = 0; u < FWD_UNITS; ++u) {
                     float G;
-                    val[u] = splat_alpha2(q0[u], q1[u], fx, fy, al[u], G) && on[u];
+                    val[u] = splat_alpha2(q0[u], q1[u], fx, fy, al[u], G);
                 }
 #pragma unroll
                 for (int u = 0; u < FWD_UNITS; ++u) {
