@@ -72,48 +72,45 @@ __device__ __forceinline__ void sort_tile_regs(unsigned long long* __restrict__ 
     if (key[0] == 1ull) return;      // (forces the loads to complete before the time stamp)
     SORT_TRACE(1);
 #endif
+    // One merge step per k; inside it the partner distance runs k/2, k/4, ..., 1: first the distances
+    // that reach other waves, then the lane distances 32 .. 1 as six guarded blocks with the distance a
+    // compile-time constant (a switch on a run-time distance cost as many scalar instructions per
+    // step as the exchange itself), then the distances inside the lane.
     for (int k = 2; k <= npow; k <<= 1) {
-        for (int j = k >> 1; j >= 1; j >>= 1) {
-            if (j < E) {
-                // partner inside the lane: constant register indices for every possible j
+        const int j0 = k >> 1;
+        for (int j = j0; j >= 64 * E; j >>= 1) {
+            const int tj = j / E;
+            const bool lower = (tid & tj) == 0;
 #pragma unroll
-                for (int jj = 1; jj < E; jj <<= 1) {
-                    if (jj != j) continue;
+            for (int e = 0; e < E; ++e) {
+                __syncthreads();
+                sk[tid] = key[e];
+                __syncthreads();
+                const unsigned long long other = sk[tid ^ tj];
+                const bool up = ((tid * E + e) & k) == 0;
+                const bool take_min = lower == up;
+                key[e] = ((key[e] < other) == take_min) ? key[e] : other;
+            }
+        }
+        if (j0 >= 32 * E) exchange_in_wave<E, 32>(key, k, tid);
+        if (j0 >= 16 * E) exchange_in_wave<E, 16>(key, k, tid);
+        if (j0 >= 8 * E) exchange_in_wave<E, 8>(key, k, tid);
+        if (j0 >= 4 * E) exchange_in_wave<E, 4>(key, k, tid);
+        if (j0 >= 2 * E) exchange_in_wave<E, 2>(key, k, tid);
+        if (j0 >= E) exchange_in_wave<E, 1>(key, k, tid);
 #pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        if (e & jj) continue;
-                        const int f = e | jj;
-                        const bool up = ((tid * E + e) & k) == 0;
-                        const unsigned long long x = key[e], y = key[f];
-                        const bool sw = (x > y) == up;
-                        key[e] = sw ? y : x;
-                        key[f] = sw ? x : y;
-                    }
-                }
-            } else {
-                const int tj = j / E;                  // lane distance of the partner
-                if (tj >= 64) {
-                    const bool lower = (tid & tj) == 0;
+        for (int jj = E >> 1; jj >= 1; jj >>= 1) {
+            if (j0 < jj) continue;
+            // partner inside the lane
 #pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        __syncthreads();
-                        sk[tid] = key[e];
-                        __syncthreads();
-                        const unsigned long long other = sk[tid ^ tj];
-                        const bool up = ((tid * E + e) & k) == 0;
-                        const bool take_min = lower == up;
-                        key[e] = ((key[e] < other) == take_min) ? key[e] : other;
-                    }
-                } else {
-                    switch (tj) {
-                        case 1: exchange_in_wave<E, 1>(key, k, tid); break;
-                        case 2: exchange_in_wave<E, 2>(key, k, tid); break;
-                        case 4: exchange_in_wave<E, 4>(key, k, tid); break;
-                        case 8: exchange_in_wave<E, 8>(key, k, tid); break;
-                        case 16: exchange_in_wave<E, 16>(key, k, tid); break;
-                        default: exchange_in_wave<E, 32>(key, k, tid); break;
-                    }
-                }
+            for (int e = 0; e < E; ++e) {
+                if (e & jj) continue;
+                const int f = e | jj;
+                const bool up = ((tid * E + e) & k) == 0;
+                const unsigned long long x = key[e], y = key[f];
+                const bool sw = (x > y) == up;
+                key[e] = sw ? y : x;
+                key[f] = sw ? x : y;
             }
         }
     }
