@@ -125,10 +125,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-pass", action="store_true",
                     help="skip the second, event-instrumented pass (used under rocprofv3)")
+    ap.add_argument("--size", default=None,
+                    help="HxWxN to time another configuration (e.g. 720x1280x200000 = BASELINE configs[4]); "
+                         "the default and the metric are configs[1]")
     ap.add_argument("--no-clip", action="store_true",
                     help="skip the end-to-end fit of a short synthetic clip (extra field clip_fit)")
     args = ap.parse_args()
 
+    global H, W, N_SPLATS
+    if args.size:
+        H, W, N_SPLATS = (int(v) for v in args.size.lower().split("x"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -220,7 +226,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: first-frame fit iteration, 480x854, 60000 splats (grown footprint), "
+            "config": {"workload": ("configs[1]" if (H, W, N_SPLATS) == (480, 854, 60000) else "other") +
+                                   f": first-frame fit iteration, {H}x{W}, {N_SPLATS} splats (grown footprint), "
                                    "lambda rgb/depth/var = 1/0.1/10, one clip per GPU",
                        "iterations_per_frame": ITERS_PER_FRAME, "splat_tile_pairs_K": K,
                        "parallelism": f"clip-sharded x{world}"},
