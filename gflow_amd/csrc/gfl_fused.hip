@@ -331,8 +331,8 @@ constexpr int BLEND_WG_PER_CU = 8;
 constexpr int FWD_WG_PER_CU = 6;       // the forward blend trades two workgroups per CU for 72 VGPRs (FWD_UNITS)
 constexpr int FWD_UNITS = 4;
 constexpr int FB = 256;   // staged splats per batch (forward)
-constexpr int FBB = 192;  // backward: 18.6 KB of LDS per workgroup -> 8 workgroups per CU, so that all
-                          // 1620 tiles of a 480p frame are resident at once (no second round)
+constexpr int FBB = 192;  // backward: 18.6 KB of LDS per workgroup -> 8 workgroups per CU (the tile queues of
+                          // gfl_sched.hpp assume that all workgroups of a blend launch are resident)
 
 struct RecLDS {
     float4 p0, p1, p2;    // p2 = (b, depth, cutoff, radius bits)
@@ -798,7 +798,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
     // The tile sort left each pair's list position in the splat's slot row; splats covering more
     // than SLOT_MAX tiles (a handful per frame) are handled by the whole wave below.
     float4 rp0 = make_float4(0.f, 0.f, 0.f, 0.f), rp2 = rp0;
-    float4 d0 = rp0, d1 = rp0, d2 = rp0;   // du dv dA dB | dC do dr dg | db ddepth
+    float4 d0 = rp0, d1 = rp0, d2 = rp0;   // gathered: s0 s1 s2 s3 | s4 do dr dg | db ddepth (moments, see below)
     float4 d0g = rp0, d1g = rp0, d2g = rp0;
     bool big = false;
     int big_nt = 0;

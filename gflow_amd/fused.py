@@ -222,7 +222,7 @@ class FitEngine:
                 "fit backward/step")
 
     def iteration(self, use_graph=False):
-        """One full iteration.  ``use_graph=True`` replays a hipGraph of the ~12 launches (captured
+        """One full iteration.  ``use_graph=True`` replays a hipGraph of the ten launches (captured
         lazily, re-captured whenever a pointer, a size or a hyper-parameter changed); it is ignored
         while the library's stage profiler is recording events."""
         if use_graph and not PROFILE["mask"] and self._launched:
