@@ -421,3 +421,28 @@ def test_tile_schedule_is_a_partition_of_the_tiles(H, W, N):
         lens = (eng.tile_range[:, 1] - eng.tile_range[:, 0]).cpu().float()
         loads = torch.tensor([float(lens[q].sum()) for q in queues])
         assert loads.max() < 1.6 * loads.mean()
+
+
+@pytest.mark.parametrize("W,H,N", [(17, 9, 1), (33, 65, 7), (100, 40, 300), (16, 16, 50), (250, 31, 1200)])
+def test_fused_iteration_on_odd_sizes_matches_operator_path(W, H, N):
+    """Image sizes that are not multiples of the tile, one-tile images, a handful of splats: the
+    fused forward equals the operator path and an iteration runs (queues shorter than the CU count,
+    partial tiles, empty tiles)."""
+    import gflow_amd.render as R
+    s = random_scene(N, W, H, seed=W + H + N, sigma_px=2.0, tilt=False)
+    raw = _raw_from_scene(s)
+    img, dep = _targets(H, W, 3)
+    eng = _engine(raw, s, img, dep, lr=1e-3, lambda_rgb=1.0, lambda_depth=0.1, lambda_var=1.0)
+    eng.forward()
+    act = [a.to(DEV) for a in FO.activate(raw)]
+    extr = LO.pose_to_extr(eng.pose.cpu()).to(DEV)
+    og = R.render_multiple([*act, s["intr"].to(DEV), extr, 0.0, W, H], ["rgb", "depth_map"])
+    close_frac(eng.render, torch.cat([og["rgb"], og["depth_map"]]), 2e-5, 2e-6, bad_frac=1e-3, hard=2e-2,
+               what=f"{W}x{H}, {N} splats")
+    before = eng.params[:N].clone()
+    for _ in range(3):
+        eng.iteration()
+    eng.check_overflow()
+    assert torch.isfinite(eng.params[:N]).all() and torch.isfinite(eng.render).all()
+    assert not torch.equal(eng.params[:N], before)
+    assert sum(q.numel() for q in eng.schedule()) == eng.T
