@@ -1,17 +1,19 @@
-"""Benchmark of the hot path: one "step" = one optimisation iteration of the GFlow
-first-frame fit (rasterise forward, photometric+SSIM+depth+var loss, rasterise
-backward, Adam) at BASELINE.json configs[1]: 480x854, 60 000 splats, synthetic frame.
+"""Benchmark of the hot path at BASELINE.json configs[1]: 480x854, 60 000 splats, synthetic data.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1 without a launcher: bench.py re-executes itself under torch.distributed.run, one rank per GPU)
 
-Each rank fits its own synthetic clip frame (no data-path collective, "weak" scaling);
-one all-reduce(MAX) of the wall time and one all-reduce(SUM) of a small metrics vector
-at the end.  Rank 0 prints ONE JSON line.
-
-value = frames/s: iterations/s divided by the iterations GFlow spends per frame with
-the README flags on a 60-frame clip, (500 + 59*(150+300))/60 = 450.83 (README.md:89-107).
-Inputs are resident in HBM before the timed region.
+Two measurements per rank, both with the inputs resident in HBM and bracketed by a barrier and a
+device synchronisation:
+  * the step: K optimisation iterations of the first-frame fit (rasterise forward, photometric + SSIM +
+    depth + var loss, rasterise backward, Adam) after W warm-up iterations -> ms_per_step,
+    iterations_per_s and the roofline block of the dominant kernel;
+  * the metric: an actual fit_video fit of one synthetic clip per rank (--clip-frames, default 8; README
+    iteration counts 500 / 150 / 300, image-driven initialisation, densification, camera-only and joint
+    stages, the reference's snapshots every 10th iteration) -> value = frames of all ranks / slowest
+    rank's wall time.  Clips are independent: no data-path collective, "weak" scaling,
+    one all-reduce(SUM) of a small metrics vector and one all-reduce(MAX) of the wall time.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -69,29 +71,23 @@ def pmc_traffic(kind):
         return {"traffic": None}
 
 
-def clip_fit(dev, frames_n=4):
-    """End-to-end check of the derived frames/s: an actual fit of a short synthetic clip through
-    gflow_amd.fit_video.fit_clip (image-driven initialisation, densification, camera-only and
-    joint stages, all host work included; clip synthesis excluded).  Real fits are heavier per
-    iteration than the steady-state step timed above: densification piles splats into few tiles."""
+def clip_fit(dev, rank, frames_n, snapshot_interval):
+    """The metric itself: an actual fit of one synthetic clip through gflow_amd.fit_video.fit_clip
+    (image-driven initialisation, densification, camera-only and joint stages, snapshots, all host
+    work included; clip synthesis and a two-frame warm-up fit excluded).  Returns the clip's
+    metrics dict and the wall seconds of the timed fit."""
     from gflow_amd import synthetic as S
     from gflow_amd import fit_video as FV
-    frames = S.make_clip(frames_n, H, W, seed=0)
-    FV.fit_clip(frames[:2], dev, dict(num_points=N_SPLATS), seed=0)          # warm-up
+    frames = S.make_clip(frames_n, H, W, seed=rank)
+    cfg = dict(num_points=N_SPLATS)
+    FV.fit_clip(frames[:2], dev, cfg, seed=rank, snapshot_interval=snapshot_interval)      # warm-up
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    m = FV.fit_clip(frames, dev, dict(num_points=N_SPLATS), seed=0)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    # frame 0 costs 500 iterations, every later frame 150 + 300: extrapolate to the 60-frame clip
-    it_per_s = m["iterations"] / dt
-    return {"frames": frames_n, "wall_s": dt, "iterations": m["iterations"], "iterations_per_s": it_per_s,
-            "frames_per_s_this_clip": frames_n / dt, "frames_per_s_60_frame_clip": it_per_s / ITERS_PER_FRAME,
-            "psnr_mean_db": m["psnr_sum"] / frames_n, "splats_final": m["splats_final"]}
+    return frames, cfg
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The oracle's fit iteration on the host cores, same workload, bounded sample."""
+def cpu_baseline():
+    """The oracle's fit iteration on the host cores: 3 warm-ups + 20 timed iterations of
+    the bench workload (480x854, 60 000 splats) and of the C1-size workload (10 000 splats)."""
     from gflow_amd import synthetic as S
     from oracle.fit_oracle import OracleFit
     # eager torch on hundreds of threads thrashes on the many small index ops of the
@@ -99,22 +95,42 @@ def cpu_baseline(seconds_budget=25.0):
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     frame = S.make_frame(H, W, seed=0)
-    raw = S.init_splats(frame, N_SPLATS, seed=0, grown=True)
-    fit = OracleFit(raw, raw["intr"], frame, lr=4e-3, iterations=500, lambda_depth=0.1, lambda_var=10.0)
-    fit.step()                                   # warm-up (allocator, thread pool)
-    t0 = time.time()
-    n = 0
-    timers = {}
-    while n < 1 or (time.time() - t0 < seconds_budget and n < 8):
-        fit.step(timers)
-        n += 1
-    dt = (time.time() - t0) / n
+    out = {}
+    for name, n_splats in (("c2", N_SPLATS), ("c1", 10000)):
+        raw = S.init_splats(frame, n_splats, seed=0, grown=True)
+        fit = OracleFit(raw, raw["intr"], frame, lr=4e-3, iterations=500, lambda_depth=0.1, lambda_var=10.0)
+        for _ in range(3):
+            fit.step()                               # warm-up (allocator, thread pool)
+        timers = {}
+        t0 = time.time()
+        n = 0
+        while n < 20 and (n < 5 or time.time() - t0 < 40.0):
+            fit.step(timers)
+            n += 1
+        dt = (time.time() - t0) / n
+        out[name] = {"splats": n_splats, "iterations_timed": n, "ms_per_step": dt * 1000.0,
+                     "phase_ms": {k: v / n * 1000.0 for k, v in timers.items()}}
+    dt = out["c2"]["ms_per_step"] / 1000.0
     return {"value": (1.0 / dt) / ITERS_PER_FRAME, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} fit iterations (after 1 warm-up) of the same 480x854 / 60k-splat frame with the "
-                      f"eager-PyTorch CPU oracle (own restatement; the reference has no CPU rasteriser), "
-                      f"{dt * 1000:.0f} ms/iteration",
-            "ms_per_step": dt * 1000.0,
-            "phase_ms": {k: v / n * 1000.0 for k, v in timers.items()}}
+            "sample": f"{out['c2']['iterations_timed']} fit iterations (after 3 warm-ups) of the same 480x854 / 60k-splat "
+                      f"frame with the eager-PyTorch CPU oracle (own restatement; the reference has no CPU rasteriser), "
+                      f"{dt * 1000:.0f} ms/iteration; frames/s = iterations/s / {ITERS_PER_FRAME:.2f} iterations per frame; "
+                      f"C1-size (10k splats) sample alongside",
+            "ms_per_step": out["c2"]["ms_per_step"], "phase_ms": out["c2"]["phase_ms"], "c1_10k_splats": out["c1"]}
+
+
+def respawn(args):
+    """--gpus N without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -129,55 +145,72 @@ def main():
                     help="HxWxN to time another configuration (e.g. 720x1280x200000 = BASELINE configs[4]); "
                          "the default and the metric are configs[1]")
     ap.add_argument("--no-clip", action="store_true",
-                    help="skip the end-to-end fit of a short synthetic clip (extra field clip_fit)")
+                    help="skip the clip fit; value is then DERIVED from the step (iterations/s / 450.83) and says so")
+    ap.add_argument("--clip-frames", type=int, default=8)
+    ap.add_argument("--snapshot-interval", type=int, default=10,
+                    help="snapshots of the clip fit (the reference keeps three images every 10th iteration, "
+                         "trainer.py:573-582); 0 = none")
     args = ap.parse_args()
 
     global H, W, N_SPLATS
     if args.size:
         H, W, N_SPLATS = (int(v) for v in args.size.lower().split("x"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        sys.exit("bench.py needs a HIP device")
+    # (ranks share devices only when a box has fewer GPUs than ranks -- a functional run, e.g. CI; RCCL
+    # refuses two ranks on one device, so the two tiny metric all-reduces then go over gloo)
+    shared = world > n_dev
+    torch.cuda.set_device(local_rank % n_dev)
+    dev = torch.device("cuda", local_rank % n_dev)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        backend = "gloo" if shared else "nccl"
+        if shared:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
+    red_dev = torch.device("cpu") if backend == "gloo" else dev
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
 
     from gflow_amd import _lib
     from gflow_amd import synthetic as S
+    from gflow_amd import fit_video as FV
     from gflow_amd.trainer import SimpleGaussian
     lib = _lib.load()
 
+    # ---------------------------------------------------------------- the step
     frame = S.make_frame(H, W, seed=rank)
     raw = S.init_splats(frame, N_SPLATS, seed=rank, grown=True)
     tr = SimpleGaussian(frame["image"], frame["depth"], num_points=N_SPLATS, device=dev, seed=rank)
     tr.load_camera(focal=frame["focal"], pp=frame["pp"])
     for k in ("xyz", "scale", "rotate", "opacity", "rgb"):
         tr._attributes[k] = raw[k].to(dev)
-    total = args.warmup + args.steps
     kw = dict(lr=4e-3, lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0, move_mask=frame["move_mask"],
               densify_interval=0, snapshot_interval=0)
     stepper = tr.make_stepper(iterations=500, **kw)
     for _ in range(args.warmup):
         stepper()
-    # ---- timed region: exactly K steps, no instrumentation (an event pair between two kernels
+    # timed region: exactly K steps, no instrumentation (an event pair between two kernels
     # opens a 5-10 us bubble on the stream, measured with rocprofv3)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         stepper()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    barrier()
     elapsed = time.perf_counter() - t0
-    # ---- the same K steps again with HIP events recorded by the library on the launch stream
+    # the same K steps again with HIP events recorded by the library on the launch stream
     # around every stage: per-kernel durations for the roofline block
     kern_all = {}
     if not args.no_stage_pass:
@@ -189,18 +222,32 @@ def main():
         set_profile(0)
         kern_all = profile_read(lib)
     kern = {k: kern_all[k] for k in ("blend_fwd", "loss", "blend_bwd") if k in kern_all}
-
     K = tr.engine.K if tr.engine is not None else int(tr.last_K)
-    psnr = float(tr.psnr_of(stepper.last_render))
-    stats = torch.tensor([elapsed, float(args.steps), psnr, float(K)], dtype=torch.float64, device=dev)
-    tmax = stats[:1].clone()
+    psnr_step = float(tr.psnr_of(stepper.last_render))
+    del stepper, tr
+
+    # -------------------------------------------------------------- the metric
+    clip = None
+    clip_wall = 0.0
+    if not args.no_clip:
+        frames, cfg = clip_fit(dev, rank, args.clip_frames, args.snapshot_interval)
+        barrier()
+        t0 = time.perf_counter()
+        clip = FV.fit_clip(frames, dev, cfg, seed=rank, snapshot_interval=args.snapshot_interval)
+        barrier()
+        clip_wall = time.perf_counter() - t0
+
+    vec = [elapsed, float(args.steps), psnr_step, float(K)]
+    if clip is not None:
+        vec += [clip[k] for k in ("frames", "iterations", "rasterisations", "psnr_sum", "splats_final")]
+    stats = torch.tensor(vec, dtype=torch.float64, device=red_dev)
+    tmax = torch.tensor([elapsed, clip_wall], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-    wall = float(tmax.item())
-    total_steps = float(stats[1].item())
     if rank == 0:
-        it_per_s = total_steps / wall
+        wall = float(tmax[0].item())
+        it_per_s = float(stats[1].item()) / wall
         P = H * W
         roof = {}
         for kind, ms in kern.items():
@@ -213,9 +260,28 @@ def main():
             roofline = {"bound": "hbm", "kernel": dom, "achieved": roof[dom]["GBps"], "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": roof[dom]["GBps"] / HBM_PEAK_GBPS}
             roofline.update(pmc_traffic(dom))
+        derived = it_per_s / ITERS_PER_FRAME
+        workload = ("configs[1]" if (H, W, N_SPLATS) == (480, 854, 60000) else "other") + f": {H}x{W}, {N_SPLATS} splats"
+        if clip is not None:
+            cw = float(tmax[1].item())
+            frames_all, iters_all = float(stats[4].item()), float(stats[5].item())
+            value = frames_all / cw
+            clip_out = {"frames_per_rank": args.clip_frames, "wall_s": cw, "iterations": iters_all,
+                        "iterations_per_s": iters_all / cw, "rasterisations_per_s": float(stats[6].item()) / cw,
+                        "psnr_mean_db": float(stats[7].item()) / frames_all,
+                        "splats_final_mean": float(stats[8].item()) / world,
+                        "snapshot_interval": args.snapshot_interval,
+                        "frames_per_s_60_frame_clip": (iters_all / cw) / ITERS_PER_FRAME}
+            workload += (f"; value = measured fit_video fit of one {args.clip_frames}-frame synthetic clip per GPU "
+                         f"(iterations 500 first / 150 camera-only + 300 joint per later frame, densification on, "
+                         f"snapshots every {args.snapshot_interval} iterations); ms_per_step = one first-frame fit "
+                         f"iteration (grown footprint, lambda rgb/depth/var = 1/0.1/10)")
+        else:
+            value, clip_out = derived, None
+            workload += "; value DERIVED from the first-frame fit iteration (no clip fit in this run)"
         out = {
             "metric": "GFlow fit_video frames/sec (fwd+bwd+step) @60k Gaussians 480p",
-            "value": it_per_s / ITERS_PER_FRAME,
+            "value": value,
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -226,25 +292,24 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": ("configs[1]" if (H, W, N_SPLATS) == (480, 854, 60000) else "other") +
-                                   f": first-frame fit iteration, {H}x{W}, {N_SPLATS} splats (grown footprint), "
-                                   "lambda rgb/depth/var = 1/0.1/10, one clip per GPU",
-                       "iterations_per_frame": ITERS_PER_FRAME, "splat_tile_pairs_K": K,
-                       "parallelism": f"clip-sharded x{world}"},
+            "config": {"workload": workload, "iterations_per_frame": ITERS_PER_FRAME, "splat_tile_pairs_K": K / world,
+                       "parallelism": f"clip-sharded x{world}", "collective_backend": backend},
+            "value_kind": "measured clip fit" if clip is not None else "derived from the step",
+            "clip_fit": clip_out,
             "iterations_per_s": it_per_s,
             "rasterisations_fwd_bwd_per_s": it_per_s,
-            "psnr_mean_db": float(stats[2].item()) / world,
+            "frames_per_s_derived_from_step": derived,
+            "psnr_step_mean_db": float(stats[2].item()) / world,
             "roofline": roofline,
             "kernels": roof,
             "stage_ms": kern_all,
-            "end_to_end_algorithmic_GBps": (724 * N_SPLATS + 124 * K + 96 * P) * it_per_s / world / 1e9,
+            "end_to_end_algorithmic_GBps": (724 * N_SPLATS + 124 * K / world + 96 * P) * it_per_s / world / 1e9,
         }
-        if world == 1 and not args.no_clip:
-            out["clip_fit"] = clip_fit(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

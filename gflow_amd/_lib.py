@@ -55,6 +55,8 @@ SIGNATURES = {
     "gfl_fit_forward": (c_int, [_P, _P, _P]),          # struct pointers; typed in gflow_amd/fused.py
     "gfl_fit_backward_step": (c_int, [_P, _P, _P]),
     "gfl_fit_iteration": (c_int, [_P, _P, _P]),
+    "gfl_render_fwd": (c_int, [_P, _P, _P]),
+    "gfl_render_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "gfl_fit_prepare_targets": (c_int, [_P, _P]),
     "gfl_fit_schedule_info": (c_int, [_P, _P, _P, _P, _P]),
     "gfl_selftest_reduce10": (c_int, [_P, _P, _P, _P]),

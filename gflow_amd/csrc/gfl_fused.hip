@@ -57,11 +57,24 @@ struct Splat {           // activated parameters of one splat
     float o, c[3];
 };
 
-__device__ __forceinline__ Splat splat_from_row(const float4& a, const float4& b, const float4& c, const float4& d) {
+// activated: the row already holds what the rasteriser consumes (scale, unit quaternion, opacity, colour) --
+// the differentiable operator gfl_render_*, whose caller applies GFlow's activations in PyTorch (render.py:6-20)
+__device__ __forceinline__ Splat splat_from_row(const float4& a, const float4& b, const float4& c, const float4& d,
+                                                bool activated = false) {
     Splat s;
     s.x = a.x; s.y = a.y; s.z = a.z;
     s.raw_s[0] = a.w; s.raw_s[1] = b.x; s.raw_s[2] = b.y;
     s.raw_q[0] = b.z; s.raw_q[1] = b.w; s.raw_q[2] = c.x; s.raw_q[3] = c.y;
+    if (activated) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s.s[k] = s.raw_s[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s.q[k] = s.raw_q[k];
+        s.qn = 1.f;
+        s.o = c.z;
+        s.c[0] = c.w; s.c[1] = d.x; s.c[2] = d.y;
+        return s;
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) s.s[k] = fabsf(s.raw_s[k]);                       // trainer.py:65
     s.qn = fmaxf(sqrtf(s.raw_q[0] * s.raw_q[0] + s.raw_q[1] * s.raw_q[1] + s.raw_q[2] * s.raw_q[2] +
@@ -73,9 +86,9 @@ __device__ __forceinline__ Splat splat_from_row(const float4& a, const float4& b
     return s;
 }
 
-__device__ __forceinline__ Splat load_splat(const float* __restrict__ params, int i) {
+__device__ __forceinline__ Splat load_splat(const float* __restrict__ params, int i, bool activated = false) {
     const float4* row = reinterpret_cast<const float4*>(params + (size_t)i * ROW);
-    return splat_from_row(row[0], row[1], row[2], row[3]);
+    return splat_from_row(row[0], row[1], row[2], row[3], activated);
 }
 
 // squared radius of the disc outside which alpha < 1/255 for every pixel, with a
@@ -95,18 +108,31 @@ __device__ __forceinline__ bool tile_hit2(float u, float v, float cutoff, int tx
     return ddx * ddx + ddy * ddy <= cutoff;
 }
 
+// rows of the scale term (trainer.py:495-502): the reference's `within_index` ALIASES valid_uv_index, which is
+// narrowed in place to the still (camera-only stage) / moving (joint stage) rows at trainer.py:467-471, so
+// scale and 1/depth are both taken over: inside the image AND (unlabelled OR still / moving by stage).
+// flags: bit0 = still, bit1 = the row has a still/moving label;  mode: 1 = joint stage, 2 = camera-only stage
+__device__ __forceinline__ bool scale_row(float u, float v, int W, int H, unsigned flags, int mode) {
+    const bool within = u > 0.f && u < (float)(W - 1) && v > 0.f && v < (float)(H - 1);
+    const bool labelled = flags & 2u, still = flags & 1u;
+    return within && (!labelled || (mode == 2 ? still : !still));
+}
+
 // ------------------------------------------------------------------ preprocess fwd
 __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
     const float* __restrict__ params, const float* __restrict__ intr, const float* __restrict__ pose, int N, int W, int H,
     float nearest, float extent, int gx, int gy, float* __restrict__ rec, int32_t* __restrict__ slot_inv,
     int32_t* __restrict__ hist_g, float* __restrict__ extr_out, int32_t* __restrict__ overflow,
-    int32_t* __restrict__ slot_pool, int32_t* __restrict__ pool_counter, int pool_cap) {
+    int32_t* __restrict__ slot_pool, int32_t* __restrict__ pool_counter, int pool_cap, int op_mode,
+    const uint8_t* __restrict__ row_flags, int scale_rows_mode, int32_t* __restrict__ scale_cnt) {
+    // op_mode (gfl_render_fwd): activated attributes in the rows, camera = the extrinsic in extr_out
+    // scale_rows_mode != 0 (lambda_scale): count the rows the scale term averages over, per block
     extern __shared__ int32_t hist[];
     const int T = gx * gy;
     for (int t = threadIdx.x; t < T; t += BIN_BLOCK) hist[t] = 0;
     __syncthreads();
-    const Cam c = cam_from_pose(intr, pose);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const Cam c = op_mode ? load_cam(intr, extr_out) : cam_from_pose(intr, pose);
+    if (!op_mode && blockIdx.x == 0 && threadIdx.x == 0) {
         extr_out[0] = c.r00; extr_out[1] = c.r01; extr_out[2] = c.r02; extr_out[3] = c.t0;
         extr_out[4] = c.r10; extr_out[5] = c.r11; extr_out[6] = c.r12; extr_out[7] = c.t1;
         extr_out[8] = c.r20; extr_out[9] = c.r21; extr_out[10] = c.r22; extr_out[11] = c.t2;
@@ -115,8 +141,9 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
     float u = 0.f, v = 0.f, cutoff = 0.f;
     int wx0 = 0, wy0 = 0, wnx = 0, wnt = 0;      // rectangle of a "wide" splat (walked by the wave below)
     int woff = -1;                               // its offset in the slot pool (more than SLOT_MAX tiles)
+    bool in_scale_rows = false;
     if (i < N) {
-        const Splat s = load_splat(params, i);
+        const Splat s = load_splat(params, i, op_mode != 0);
         const Proj p = project_fwd(c, s.x, s.y, s.z, W, H, nearest, extent);
         float depth = 0.f, A = 0.f, B = 0.f, C = 0.f;
         int rad = 0, nt_slots = 0;
@@ -149,6 +176,7 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
         r4[0] = make_float4(u, v, A, B);
         r4[1] = make_float4(C, s.o, s.c[0], s.c[1]);
         r4[2] = make_float4(s.c[2], depth, cutoff, __int_as_float(rad));
+        in_scale_rows = scale_rows_mode && scale_row(u, v, W, H, row_flags ? row_flags[i] : 0, scale_rows_mode);
         int4* iv = reinterpret_cast<int4*>(slot_inv + (size_t)i * SLOT_MAX);
         const int4 none = make_int4(-1, -1, -1, -1);
         // only the slots of the splat's own tile rectangle are ever read (gather of the backward)
@@ -182,6 +210,18 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
                 if (tile_hit2(su, sv, sc, tx, ty)) atomicAdd(&hist[ty * gx + tx], 1);
                 if (soff >= 0) slot_pool[soff + q] = -1;
             }
+        }
+    }
+    if (scale_rows_mode) {
+        // (no atomics on global memory: one partial per block, folded by every block of the backward kernel)
+        const int wcnt = __popcll(__ballot(in_scale_rows));
+        __shared__ int32_t s_cnt[BIN_BLOCK / 64];
+        if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = wcnt;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int w = 0; w < BIN_BLOCK / 64; ++w) tot += s_cnt[w];
+            scale_cnt[blockIdx.x] = tot;
         }
     }
     __syncthreads();
@@ -697,12 +737,6 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
 // moving splat reaches with alpha >= 1/255 in a tile it was binned into: the first such splat in
 // depth order always blends (T = 1), and every colour is a sigmoid, hence > 0.  So no second sort
 // and composite: the flagged splats of every tile list mark their pixels, in any order.
-__global__ void __launch_bounds__(256) keep_init_kernel(const uint8_t* __restrict__ move_mask, int P, int all_masked,
-                                                        uint8_t* __restrict__ keep) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < P) keep[i] = (all_masked || (move_mask && move_mask[i])) ? 0 : 1;
-}
-
 // One workgroup per tile walks the tile's list (already binned and sorted by the forward that just
 // ran) and evaluates only the flagged splats, lanes = pixels as in the blend; a wave stops as soon
 // as all its pixels are marked.  (A first version gave every flagged splat one wave that walked the
@@ -775,6 +809,8 @@ __device__ __forceinline__ float adam_update(float p, float g, float& m, float& 
 }
 
 struct RegCfg {                 // per-splat regularisers (trainer.py:490-530)
+    float lambda_scale;         // lambda_scale (the row count divides it in the kernel)
+    int scale_blocks;           // partial counts to fold (blocks of the preprocess launch)
     float lambda_var;           // lambda_var / N
     float lambda_flow;          // lambda_flow (per-row weight in flow_w carries 1/(2 count))
     float lambda_still;         // lambda_still (per-row weight in still_w carries 1/count)
@@ -782,6 +818,10 @@ struct RegCfg {                 // per-splat regularisers (trainer.py:490-530)
     int freeze_all;             // camera_only, trainer.py:548-551
 };
 
+// OP = true is the differentiable operator's backward (gfl_render_bwd): the rows hold ACTIVATED attributes, the
+// camera is the extrinsic `pose` points at (12 floats), the caller's dL/d uv and dL/d depth join the gradient, and
+// the 14 gradients are WRITTEN to d_params rows instead of stepping Adam (no regularisers, no masks).
+template <bool OP>
 __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel(
     float* __restrict__ params, float* __restrict__ adam_m, float* __restrict__ adam_v, const float* __restrict__ intr,
     const float* __restrict__ pose, const float* __restrict__ rec, float* __restrict__ d_rec,
@@ -789,8 +829,20 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
     const int32_t* __restrict__ tile_range, const int32_t* __restrict__ slot_inv, int gx, int gy, int N, int W, int H,
     const float* __restrict__ flow_target, const float* __restrict__ flow_w, const float* __restrict__ still_target,
     const float* __restrict__ still_w, const uint8_t* __restrict__ row_flags, RegCfg rc, AdamCfg ac,
-    const int32_t* __restrict__ d_step, float* __restrict__ partial) {
+    const int32_t* __restrict__ d_step, float* __restrict__ partial, const float* __restrict__ d_uv_in,
+    const float* __restrict__ d_depth_in, float* __restrict__ d_params, const int32_t* __restrict__ scale_cnt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float scale_w = 0.f;                              // lambda_scale / rows of the scale term
+    if (!OP && rc.lambda_scale != 0.f) {
+        __shared__ int32_t s_rows;
+        if (threadIdx.x == 0) s_rows = 0;
+        __syncthreads();
+        int c = 0;
+        for (int b = threadIdx.x; b < rc.scale_blocks; b += REDUCE_BLOCK) c += scale_cnt[b];
+        if (c) atomicAdd(&s_rows, c);
+        __syncthreads();
+        scale_w = s_rows > 0 ? rc.lambda_scale / (float)s_rows : 0.f;
+    }
     float e[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) e[k] = 0.f;
@@ -810,7 +862,10 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
         const float4* mrow = reinterpret_cast<const float4*>(adam_m + (size_t)i * ROW);
         const float4* vrow = reinterpret_cast<const float4*>(adam_v + (size_t)i * ROW);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { prow_v[q] = prow[q]; mrow_v[q] = mrow[q]; vrow_v[q] = vrow[q]; }
+        for (int q = 0; q < 4; ++q) {
+            prow_v[q] = prow[q];
+            if (!OP) { mrow_v[q] = mrow[q]; vrow_v[q] = vrow[q]; }
+        }
         const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)i * REC);
         rp0 = r4[0]; rp2 = r4[2];
         {
@@ -888,8 +943,8 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
         }
     }
     if (i < N) {
-        const Cam c = cam_from_pose(intr, pose);
-        const Splat s = splat_from_row(prow_v[0], prow_v[1], prow_v[2], prow_v[3]);
+        const Cam c = OP ? load_cam(intr, pose) : cam_from_pose(intr, pose);
+        const Splat s = splat_from_row(prow_v[0], prow_v[1], prow_v[2], prow_v[3], OP);
         if (big) { d0 = d0g; d1 = d1g; d2 = d2g; }
         {
             // moments of the backward blend -> du dv dA dB dC (blend_bwd_terms)
@@ -907,10 +962,22 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
         float g[14];
 #pragma unroll
         for (int k = 0; k < 14; ++k) g[k] = 0.f;
+        float scale_g = 0.f;                                // d(scale term) / d|s_k| = scale_g * |s_k|
         const bool vis = rp2.y != 0.f;                      // depth != 0  (render.py:29)
         if (vis) {
             float du = d0.x, dv = d0.y, dd = d2.y;
-            if (flow_w) {                                   // flow term acts on uv (trainer.py:520-528)
+            if (OP) {                                       // the caller's own use of uv / depth (flow, scale losses)
+                if (d_uv_in) { du += d_uv_in[2 * i]; dv += d_uv_in[2 * i + 1]; }
+                if (d_depth_in) dd += d_depth_in[i];
+            }
+            if (!OP && scale_w != 0.f &&
+                scale_row(rp0.x, rp0.y, W, H, row_flags ? row_flags[i] : 0, rc.freeze_all ? 2 : 1)) {
+                // mean over the rows of |scale| / depth (trainer.py:495-502): d/d depth here, d/d scale below
+                const float nrm = sqrtf(s.s[0] * s.s[0] + s.s[1] * s.s[1] + s.s[2] * s.s[2]);
+                dd -= scale_w * nrm / (rp2.y * rp2.y);
+                scale_g = nrm > 0.f ? scale_w / (nrm * rp2.y) : 0.f;
+            }
+            if (!OP && flow_w) {                            // flow term acts on uv (trainer.py:520-528)
                 const float w = rc.lambda_flow * flow_w[i];
                 if (w != 0.f) {
                     du += 2.f * w * (rp0.x - flow_target[2 * i]);
@@ -933,19 +1000,34 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
                 cov3d_bwd(s.s, s.q, gcov, ds, dq);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) g[3 + k] = ds[k];
-                // through F.normalize: q = raw / n
-                const float dot = s.q[0] * dq[0] + s.q[1] * dq[1] + s.q[2] * dq[2] + s.q[3] * dq[3];
+                if (OP) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) g[6 + k] = (dq[k] - s.q[k] * dot) / s.qn;
+                    for (int k = 0; k < 4; ++k) g[6 + k] = dq[k];
+                } else {
+                    // through F.normalize: q = raw / n
+                    const float dot = s.q[0] * dq[0] + s.q[1] * dq[1] + s.q[2] * dq[2] + s.q[3] * dq[3];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) g[6 + k] = (dq[k] - s.q[k] * dot) / s.qn;
+                }
             }
             cam_grad_to_world(c, s.x, s.y, s.z, gx_, gy_, gz_, g[0], g[1], g[2], e);
         }
+        if (OP) {
+            // gradients wrt the activated attributes, as msplat's operators return them
+            float4* o4 = reinterpret_cast<float4*>(d_params + (size_t)i * ROW);
+            o4[0] = make_float4(g[0], g[1], g[2], g[3]);
+            o4[1] = make_float4(g[4], g[5], g[6], g[7]);
+            o4[2] = make_float4(g[8], g[9], d1.y, d1.z);
+            o4[3] = make_float4(d1.w, d2.x, 0.f, 0.f);
+        } else {
         // blended attributes: opacity = sigmoid(10 x), rgb = sigmoid(x)
         g[10] = d1.y * 10.f * s.o * (1.f - s.o);
         g[11] = d1.z * s.c[0] * (1.f - s.c[0]);
         g[12] = d1.w * s.c[1] * (1.f - s.c[1]);
         g[13] = d2.x * s.c[2] * (1.f - s.c[2]);
-        // scale: |x| backward, then the variance regulariser (trainer.py:490-493)
+        // scale: the two regularisers on |x| (trainer.py:490-502), then the backward of |x|
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g[3 + k] += scale_g * s.s[k];
         if (rc.lambda_var != 0.f) {
             const float mean = (s.s[0] + s.s[1] + s.s[2]) * (1.f / 3.f);
             const float var = 0.5f * ((s.s[0] - mean) * (s.s[0] - mean) + (s.s[1] - mean) * (s.s[1] - mean) +
@@ -995,6 +1077,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
             prow[q] = make_float4(pv[4 * q], pv[4 * q + 1], pv[4 * q + 2], pv[4 * q + 3]);
             mrow[q] = make_float4(mv[4 * q], mv[4 * q + 1], mv[4 * q + 2], mv[4 * q + 3]);
             vrow[q] = make_float4(vv[4 * q], vv[4 * q + 1], vv[4 * q + 2], vv[4 * q + 3]);
+        }
         }
     }
     block_reduce_store<12, REDUCE_BLOCK>(e, partial);
@@ -1152,7 +1235,8 @@ size_t gfl_fit_workspace_bytes(int cap, int K_cap, int W, int H) {
            + 2 * up256(2 * SCHED_MAX_QUEUES * sizeof(int32_t))                      // queue lengths, pull counters
            + up256((size_t)SCHED_MAX_QUEUES * (HEAVY_PARTS - 1) * 5 * 256 * sizeof(float))                  // heavy-tile checkpoints
            + up256(gfl_loss_workspace_bytes(W, H)) + 256
-           + up256((size_t)6 * W * H * sizeof(float));                                 // SSIM statistics of the target
+           + up256((size_t)6 * W * H * sizeof(float))                                  // SSIM statistics of the target
+           + up256((size_t)fit_nblk(cap > 0 ? cap : 1) * sizeof(int32_t));             // rows of the scale term per block
 }
 
 struct FitWs {
@@ -1169,6 +1253,7 @@ struct FitWs {
     void* loss_ws;
     size_t loss_ws_bytes;
     float* gt_stats;         // [3][2][H][W] conv(y), conv(y^2) of the current target (gfl_fit_prepare_targets)
+    int32_t* scale_cnt;      // [blocks of the preprocess launch] rows of the scale term (lambda_scale)
 };
 
 static FitWs carve(const gfl_fit_state* st) {
@@ -1206,6 +1291,7 @@ static FitWs carve(const gfl_fit_state* st) {
     w.loss_ws = p;
     w.loss_ws_bytes = up256(gfl_loss_workspace_bytes(st->W, st->H));
     w.gt_stats = (float*)((char*)p + w.loss_ws_bytes + 256);
+    w.scale_cnt = (int32_t*)((char*)w.gt_stats + up256((size_t)6 * st->W * st->H * sizeof(float)));
     return w;
 }
 
@@ -1222,7 +1308,7 @@ static int fit_check(const gfl_fit_state* st, const gfl_fit_hyper* hp) {
 // kernels of gfl_bin.hip / gfl_loss.hip reused through their C entry points
 // (gfl_loss_fwd_bwd, gfl_tile_sort_only: declared in gflow_hip.h)
 
-int gfl_fit_forward(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream) {
+static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream, int op_mode) {
     int rc = fit_check(st, hp);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
@@ -1236,7 +1322,10 @@ int gfl_fit_forward(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream
         fused_preprocess_fwd_kernel<<<nblk, BIN_BLOCK, lds, s>>>(st->params, st->intr, st->pose, st->N, st->W, st->H,
                                                                 hp->nearest, hp->extent, gx, gy, st->rec, w.slot_inv,
                                                                 w.hist, st->extr, st->overflow, w.slot_pool,
-                                                                w.pool_counter, st->K_cap);
+                                                                w.pool_counter, st->K_cap, op_mode, st->row_flags,
+                                                                (!op_mode && hp->lambda_scale != 0.f)
+                                                                    ? (hp->freeze_all_splats ? 2 : 1) : 0,
+                                                                w.scale_cnt);
     }
     {
         StageScope p(ST_COLSCAN, s);
@@ -1259,13 +1348,54 @@ int gfl_fit_forward(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream
         fused_blend_fwd_kernel<<<blend_grid(T, FWD_WG_PER_CU), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx,
                                                              st->render, st->final_T, st->n_contrib, q, w.ckpt);
         if (st->foot_flags) {
+            // keep is in/out here: the footprint of this iteration's flagged splats is cleared from it, so it
+            // carries the running union over the iterations of the stage exactly like the reference, which
+            // rebinds move_mask = move_gs_mask | move_mask inside its loop (trainer.py:451).  The caller
+            // initialises keep = !move_mask (all zero for a non-black background, where every pixel of the
+            // extra render is > 0).
             if (!st->keep) return GFL_ERR_INVALID;
-            const int P = st->W * st->H;
-            keep_init_kernel<<<(P + 255) / 256, 256, 0, s>>>(st->move_mask, P, hp->bg > 0.f ? 1 : 0, st->keep);
             if (!(hp->bg > 0.f) && st->N > 0)
                 footprint_kernel<<<T, 256, 0, s>>>(st->rec, st->ids, st->tile_range, st->foot_flags, st->W, st->H, gx,
                                                    st->keep);
         }
+    }
+    return check_launch();
+}
+
+int gfl_fit_forward(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream) {
+    return fit_forward_impl(st, hp, stream, 0);
+}
+
+int gfl_render_fwd(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream) {
+    if (st && st->foot_flags) return GFL_ERR_INVALID;
+    return fit_forward_impl(st, hp, stream, 1);
+}
+
+int gfl_render_bwd(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float* d_render, const float* d_uv,
+                   const float* d_depth, float* d_params, float* d_extr, gfl_stream_t stream) {
+    int rc = fit_check(st, hp);
+    if (rc) return rc;
+    if (!d_render || !d_params || !d_extr) return GFL_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int gx = (st->W + GFL_TILE - 1) / GFL_TILE, gy = (st->H + GFL_TILE - 1) / GFL_TILE, T = gx * gy;
+    const FitWs w = carve(st);
+    {
+        StageScope p(ST_BLEND_BWD, s);
+        const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters + w.sched.nq, w.sched.nq, w.sched.cap_q};
+        fused_blend_bwd_kernel<<<blend_grid(T), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx,
+                                                             st->final_T, st->n_contrib, d_render, w.pair_grad, q,
+                                                             w.sched.work, w.ckpt, st->render);
+    }
+    const int rows = reduce_rows(st->N > 0 ? st->N : 1);
+    RegCfg rcfg = {};
+    AdamCfg ac = {};
+    {
+        StageScope p(ST_PRE_BWD_ADAM, s);
+        fused_preprocess_bwd_adam_kernel<true><<<rows, REDUCE_BLOCK, 0, s>>>(
+            st->params, nullptr, nullptr, st->intr, st->extr, st->rec, st->d_rec, w.pair_grad, w.slot_pool, st->tile_range,
+            w.slot_inv, gx, gy, st->N, st->W, st->H, nullptr, nullptr, nullptr, nullptr, nullptr, rcfg, ac, nullptr,
+            w.partial, d_uv, d_depth, d_params, nullptr);
+        fold_partials_kernel<12><<<1, 256, 0, s>>>(w.partial, rows, d_extr);
     }
     return check_launch();
 }
@@ -1300,6 +1430,8 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
     }
     const int rows = reduce_rows(st->N > 0 ? st->N : 1);
     RegCfg rcfg;
+    rcfg.lambda_scale = hp->lambda_scale;
+    rcfg.scale_blocks = fit_nblk(st->N > 0 ? st->N : 1);
     rcfg.lambda_var = st->N > 0 ? hp->lambda_var / (float)st->N : 0.f;
     rcfg.lambda_flow = hp->lambda_flow;
     rcfg.lambda_still = hp->lambda_still;
@@ -1310,9 +1442,10 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
     ac_cam.lr = hp->lr_camera;
     {
         StageScope p(ST_PRE_BWD_ADAM, s);
-        fused_preprocess_bwd_adam_kernel<<<rows, REDUCE_BLOCK, 0, s>>>(
+        fused_preprocess_bwd_adam_kernel<false><<<rows, REDUCE_BLOCK, 0, s>>>(
             st->params, st->adam_m, st->adam_v, st->intr, st->pose, st->rec, st->d_rec, w.pair_grad, w.slot_pool,
-            st->tile_range, w.slot_inv, gx, gy, st->N, st->W, st->H, st->flow_target, st->flow_w, st->still_target, st->still_w, st->row_flags, rcfg, ac, st->step, w.partial);
+            st->tile_range, w.slot_inv, gx, gy, st->N, st->W, st->H, st->flow_target, st->flow_w, st->still_target,
+            st->still_w, st->row_flags, rcfg, ac, st->step, w.partial, nullptr, nullptr, nullptr, w.scale_cnt);
     }
     {
         StageScope p(ST_CAMERA, s);

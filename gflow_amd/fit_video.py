@@ -48,8 +48,11 @@ def reduce_metrics(local, wall_seconds, dist=None, device="cpu"):
     return out
 
 
-def fit_clip(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, log=None):
-    """Fit one clip; returns the metrics dict of this clip (PSNR summed over its frames)."""
+def fit_clip(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, log=None, load_extr=True):
+    """Fit one clip; returns the metrics dict of this clip (PSNR summed over its frames).
+    ``load_extr`` (default True, like the reference's flag): frames that carry a camera pose
+    (``extr``, read from the sequence's camera files) load it before they are fitted
+    (fit_video.py:115-116, :252-253)."""
     from .trainer import SimpleGaussian
     c = dict(DEFAULTS)
     c.update(cfg or {})
@@ -57,6 +60,8 @@ def fit_clip(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, 
     tr = SimpleGaussian(f0["image"], f0["depth"], num_points=c["num_points"], background=c["background"],
                         device=device, seed=seed, fused=fused)
     tr.load_camera(focal=f0["focal"], pp=f0["pp"])
+    if load_extr and f0.get("extr") is not None:
+        tr.load_camera(extr=f0["extr"])
     tr.init_gaussians_from_image(f0["image"], f0["depth"], num_points=c["num_points"])
     common = dict(lambda_rgb=c["lambda_rgb"], lambda_depth=c["lambda_depth"], lambda_scale=c["lambda_scale"],
                   densify_occ_percent=c["densify_occ_percent"], densify_err_thre=c["densify_err_thre"],
@@ -72,6 +77,8 @@ def fit_clip(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, 
         tr.set_gt_image(fr["image"])
         tr.set_gt_depth(fr["depth"])
         tr.set_gt_flow(frames[i - 1]["flow"])            # flow from frame i-1 to i (fit_video.py:250)
+        if load_extr and fr.get("extr") is not None:
+            tr.load_camera(extr=fr["extr"])              # fit_video.py:252-253
         if c["camera_first"]:                            # fit_video.py:256-278
             tr.train(iterations=c["iterations_camera"], lr_camera=c["lr_camera_after"], lambda_var=0.0,
                      lambda_still=0.0, lambda_flow=c["lambda_flow"], densify_interval=c["densify_interval"],

@@ -38,7 +38,7 @@ class FitState(ctypes.Structure):          # mirrors gfl_fit_state
 class FitHyper(ctypes.Structure):          # mirrors gfl_fit_hyper
     _fields_ = [("bg", ctypes.c_float), ("nearest", ctypes.c_float), ("extent", ctypes.c_float),
                 ("lambda_rgb", ctypes.c_float), ("lambda_depth", ctypes.c_float), ("lambda_var", ctypes.c_float),
-                ("lambda_flow", ctypes.c_float), ("lambda_still", ctypes.c_float),
+                ("lambda_flow", ctypes.c_float), ("lambda_still", ctypes.c_float), ("lambda_scale", ctypes.c_float),
                 ("lr", ctypes.c_float), ("lr_camera", ctypes.c_float), ("beta1", ctypes.c_float),
                 ("beta2", ctypes.c_float), ("eps", ctypes.c_float), ("lr_end_factor", ctypes.c_float),
                 ("total_iters", _I), ("freeze_rgb", _I), ("freeze_all_splats", _I), ("step_camera", _I)]
@@ -49,10 +49,12 @@ def _declare(lib):
         return
     lib.gfl_fit_workspace_bytes.restype = ctypes.c_size_t
     lib.gfl_fit_workspace_bytes.argtypes = [ctypes.c_int] * 4
-    for name in ("gfl_fit_forward", "gfl_fit_backward_step", "gfl_fit_iteration"):
+    for name in ("gfl_fit_forward", "gfl_fit_backward_step", "gfl_fit_iteration", "gfl_render_fwd"):
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(FitState), ctypes.POINTER(FitHyper), _P]
+    lib.gfl_render_bwd.restype = ctypes.c_int
+    lib.gfl_render_bwd.argtypes = [ctypes.POINTER(FitState), ctypes.POINTER(FitHyper), _P, _P, _P, _P, _P, _P]
     lib._fit_declared = True
 
 
@@ -77,7 +79,7 @@ class FitEngine:
         self.T = self.gx * self.gy
         self.N = 0
         self.hp = FitHyper(bg=bg, nearest=0.2, extent=1.3, lambda_rgb=1.0, lambda_depth=0.0, lambda_var=0.0,
-                           lambda_flow=0.0, lambda_still=0.0, lr=1e-2, lr_camera=0.0, beta1=0.9, beta2=0.999,
+                           lambda_flow=0.0, lambda_still=0.0, lambda_scale=0.0, lr=1e-2, lr_camera=0.0, beta1=0.9, beta2=0.999,
                            eps=1e-8, lr_end_factor=0.1, total_iters=0, freeze_rgb=0, freeze_all_splats=0,
                            step_camera=1)
         f32 = dict(dtype=torch.float32, device=self.dev)
@@ -107,6 +109,7 @@ class FitEngine:
         self.K_cap_req = K_cap
         self._graph = self._graph_key = None
         self._launched = False
+        self.busy = False              # checked out by the differentiable operator (gflow_amd.render)
         self._alloc(int(capacity))
 
     # ------------------------------------------------------------------ storage
@@ -130,7 +133,29 @@ class FitEngine:
 
     def ensure_capacity(self, n):
         if n > self.cap:
+            regs = (self.flow_target, self.flow_w, self.still_target, self.still_w, self.row_flags, self.foot_flags)
+            m, v = self.adam_m, self.adam_v
+            old_n = self.N
             self._alloc(max(n, 2 * self.cap))
+            self.adam_m[:old_n], self.adam_v[:old_n] = m[:old_n], v[:old_n]
+            # per-row side inputs are capacity-sized: re-pad them (the kernels index them by row up to N)
+            grown = []
+            for t in regs:
+                if t is None:
+                    grown.append(None)
+                    continue
+                g = torch.zeros((self.cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.dev)
+                g[:t.shape[0]] = t
+                grown.append(g)
+            self.flow_target, self.flow_w, self.still_target, self.still_w, self.row_flags, self.foot_flags = grown
+
+    def set_count(self, n):
+        """Rows [0, n) are live (rows were appended in place behind the old ones)."""
+        if n > self.cap:
+            raise RuntimeError("FitEngine.set_count beyond the capacity; call ensure_capacity first")
+        self.N = int(n)
+        if self._state is not None:
+            self._state.N = self.N
 
     def set_splats(self, attrs):
         """attrs: dict xyz (N,3), scale (N,3), rotate (N,4), opacity (N,1), rgb (N,3) RAW values.
@@ -164,13 +189,18 @@ class FitEngine:
         self._state = None
 
     def set_footprint_mask(self, move_mask, moving_rows):
-        """Camera-only stage (trainer.py:426-451): from now on every forward rebuilds
-        ``keep = ~(move_mask | footprint of the splats flagged in moving_rows)``."""
+        """Camera-only stage (trainer.py:426-451): from now on every forward clears the footprint of
+        the splats flagged in ``moving_rows`` from ``keep``, which starts as ``~move_mask`` -- the
+        running union the reference builds with ``move_mask = move_gs_mask | move_mask`` in its loop.
+        With a non-black background every pixel of the reference's extra render is > 0: all masked."""
         self.move_mask = move_mask.to(self.dev).reshape(self.H, self.W).to(torch.uint8).contiguous()
         flags = torch.zeros(self.cap, dtype=torch.uint8, device=self.dev)
         flags[:moving_rows.shape[0]] = moving_rows.to(self.dev).to(torch.uint8)
         self.foot_flags = flags
-        self.keep = torch.empty(self.H, self.W, dtype=torch.uint8, device=self.dev)
+        if self.hp.bg > 0.0:
+            self.keep = torch.zeros(self.H, self.W, dtype=torch.uint8, device=self.dev)
+        else:
+            self.keep = (self.move_mask == 0).to(torch.uint8).contiguous()
         self._state = None
 
     def set_regularisers(self, flow_target=None, flow_w=None, still_target=None, still_w=None, row_flags=None):

@@ -3,11 +3,108 @@
 ``render_multiple`` / ``render_traj`` / ``render2img`` keep the reference's
 signatures and semantics (render.py:6-166) on top of ``gflow_amd.msplat``.
 """
+import ctypes
+import weakref
+
 import numpy as np
 import torch
 
+from . import _lib as L
 from . import msplat
 from .color import apply_float_colormap
+
+FUSED_TYPES = frozenset(("rgb", "uv", "depth", "depth_map"))
+USE_FUSED = True        # render_multiple routes {"rgb","uv","depth","depth_map"} requests through the fused operator
+
+# ------------------------------------------------------------ fused differentiable operator
+_POOL = {}              # (W, H, device) -> [FitEngine]; an engine is checked out from forward until backward
+
+
+def _checkout(W, H, n, dev):
+    from .fused import FitEngine
+    key = (int(W), int(H), str(dev))
+    for eng in _POOL.setdefault(key, []):
+        if not eng.busy:
+            break
+    else:
+        eng = FitEngine(W, H, max(2 * n, 65536), dev)
+        eng.busy = False
+        _POOL[key].append(eng)
+    eng.ensure_capacity(n)
+    if getattr(eng, "pad2", None) is None or eng.pad2.shape[0] < eng.cap:
+        eng.pad2 = torch.zeros(eng.cap, 2, dtype=torch.float32, device=eng.dev)
+    eng.busy = True
+    return eng
+
+
+def _release(eng):
+    eng.busy = False
+
+
+class _FusedRender(torch.autograd.Function):
+    """render(gaussians, camera) -> (rgb, depth_map, uv, depth): gfl_render_fwd / gfl_render_bwd of
+    include/gflow_hip.h -- projection, covariance, EWA, binning, sort and the 4-channel composite in the fused
+    kernels, one library call per direction (render.py:6-108 makes six operator calls).  The library writes straight
+    into the tensors that are returned (fresh render / record buffers per call, the caller's intr / extr are read in
+    place): per direction the host issues one concatenation, two allocations and the call."""
+
+    @staticmethod
+    def forward(ctx, xyz, scale, rotate, opacity, rgb, intr, extr, bg, W, H):
+        dev = xyz.device
+        n = xyz.shape[0]
+        eng = _checkout(W, H, n, dev)
+        try:
+            if n:
+                f = lambda t, c: t.detach().float().reshape(n, c)
+                torch.cat([f(xyz, 3), f(scale, 3), f(rotate, 4), f(opacity, 1), f(rgb, 3), eng.pad2[:n]], dim=1,
+                          out=eng.params[:n])
+            intr_c = intr.detach().float().contiguous().reshape(4)
+            extr_c = extr.detach().float().contiguous().reshape(12)
+            out = torch.empty(4, eng.H, eng.W, dtype=torch.float32, device=dev)
+            rec = torch.empty(max(n, 1), 12, dtype=torch.float32, device=dev)
+            st = eng.state()
+            st.N, st.intr, st.extr, st.render, st.rec = n, intr_c.data_ptr(), extr_c.data_ptr(), out.data_ptr(), rec.data_ptr()
+            eng.hp.bg = float(bg)
+            L.check(eng.lib.gfl_render_fwd(ctypes.byref(st), ctypes.byref(eng.hp), L.stream()), "render")
+        except Exception:
+            _release(eng)
+            raise
+        if any(ctx.needs_input_grad):
+            ctx.eng, ctx.n, ctx.keep = eng, n, (intr_c, extr_c, out, rec)
+            weakref.finalize(ctx, _release, eng)        # a graph that is dropped without backward frees the engine too
+        else:
+            _release(eng)
+        return out[:3], out[3:4], rec[:n, 0:2], rec[:n, 9:10]
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_depth_map, d_uv, d_depth):
+        eng, n = ctx.eng, ctx.n
+        dev = eng.dev
+        H, W = eng.H, eng.W
+        z = lambda c: torch.zeros(c, H, W, dtype=torch.float32, device=dev)
+        d_render = torch.cat([z(3) if d_rgb is None else d_rgb.float(), z(1) if d_depth_map is None else d_depth_map.float()])
+        d_uv = None if d_uv is None else d_uv.float().contiguous()
+        d_depth = None if d_depth is None else d_depth.float().contiguous()
+        d_params = torch.empty(max(n, 1), 16, dtype=torch.float32, device=dev)
+        d_extr = torch.empty(12, dtype=torch.float32, device=dev)
+        L.check(eng.lib.gfl_render_bwd(ctypes.byref(eng.state()), ctypes.byref(eng.hp), L.ptr(d_render), L.ptr(d_uv),
+                                       L.ptr(d_depth), L.ptr(d_params), L.ptr(d_extr), L.stream()), "render backward")
+        _release(eng)
+        g = d_params[:n]
+        return (g[:, 0:3], g[:, 3:6], g[:, 6:10], g[:, 10:11], g[:, 11:14], None, d_extr.reshape(3, 4), None, None, None)
+
+
+def render(gaussians, camera, bg=0.0):
+    """The rasteriser as ONE differentiable operator.  gaussians: dict with the ACTIVATED attributes xyz (N,3),
+    scale (N,3), rotate (N,4, unit, wxyz), opacity (N,1), rgb (N,3); camera: dict with intr (4,), extr (3,4),
+    W, H.  Returns dict(rgb (3,H,W), depth_map (1,H,W), uv (N,2), depth (N,1)) -- what
+    render_multiple(input_group, ["rgb", "uv", "depth", "depth_map"]) returns (render.py:6-108), with gradients to
+    the five attributes and to extr."""
+    L.need_device(gaussians["xyz"])
+    rgb, depth_map, uv, depth = _FusedRender.apply(
+        gaussians["xyz"], gaussians["scale"], gaussians["rotate"], gaussians["opacity"], gaussians["rgb"],
+        camera["intr"], camera["extr"], float(bg), int(camera["W"]), int(camera["H"]))
+    return {"rgb": rgb, "depth_map": depth_map, "uv": uv, "depth": depth}
 
 
 def render_multiple(input_group,
@@ -18,6 +115,11 @@ def render_multiple(input_group,
     rgb (3,H,W), uv (N,2), depth (N,1), depth_map (1,H,W), depth_map_color (3,H,W),
     center (3,H,W)."""
     xyz, scale, rotate, opacity, rgb, intr, extr, bg, W, H = input_group
+    if USE_FUSED and xyz.is_cuda and set(return_type) <= FUSED_TYPES and ("rgb" in return_type or "depth_map" in return_type):
+        # the training call (trainer.py:404-407 minus the two snapshot images): one fused operator
+        full = render(dict(xyz=xyz, scale=scale, rotate=rotate, opacity=opacity, rgb=rgb),
+                      dict(intr=intr, extr=extr, W=W, H=H), bg)
+        return {k: full[k] for k in return_type}
     out = {}
     uv, depth = msplat.project_point(xyz, intr, extr, W, H)
     visible = depth != 0
@@ -58,7 +160,13 @@ def render_traj(input_group, point_num, line_scale=1.0, point_scale=2.0):
     return msplat.alpha_blending(uv, conic, opacity, rgb, ids, tile_range, bg, W, H)
 
 
+def render2img_device(rendered):
+    """(3,H,W) float -> (H,W,3) uint8 tensor ON THE DEVICE: the clamp / x255 / truncation of render.py:158-166
+    without the host round trip (a snapshot used to cost ~6 ms of numpy arithmetic on three 1.2 M-element
+    float images; the iteration it interrupts takes 0.22 ms).  Nothing here waits for the GPU."""
+    return (torch.clamp(rendered.detach(), 0.0, 1.0) * 255.0).to(torch.uint8).permute(1, 2, 0).contiguous()
+
+
 def render2img(rendered):
     """(3,H,W) float -> (H,W,3) uint8 numpy (render.py:158-166)."""
-    rendered = torch.clamp(rendered.detach().permute(1, 2, 0), 0.0, 1.0)
-    return (rendered.cpu().numpy() * 255).astype(np.uint8)
+    return render2img_device(rendered).cpu().numpy()

@@ -264,10 +264,11 @@ class SimpleGaussian:
             xyz[:n_last] = torch.where(inside.unsqueeze(1), xyz_new, xyz[:n_last])
             self._attributes["xyz"] = xyz
 
-        if self.fused and not lambda_scale:
+        if self.fused:
             return self._make_fused_stepper(
                 iterations=iterations, lr=lr, lr_camera=lr_camera, lambda_rgb=lambda_rgb, lambda_depth=lambda_depth,
-                lambda_flow=lambda_flow, lambda_var=lambda_var, lambda_still=lambda_still, move_mask=move_mask,
+                lambda_flow=lambda_flow, lambda_var=lambda_var, lambda_still=lambda_still, lambda_scale=lambda_scale,
+                move_mask=move_mask,
                 densify_interval=densify_interval, densify_times=densify_times, mask=mask, camera_only=camera_only,
                 densify_occ_percent=densify_occ_percent, densify_err_thre=densify_err_thre,
                 densify_err_percent=densify_err_percent, snapshot_interval=snapshot_interval,
@@ -297,7 +298,7 @@ class SimpleGaussian:
                     mrgb = render_mod.render_multiple(grp, ["rgb"])["rgb"]
                     self.rasterisations_done += 1
                     grey = 0.299 * mrgb[0] + 0.587 * mrgb[1] + 0.114 * mrgb[2]
-                    mm = (grey > 0.0) | move_mask
+                    mm = (grey > 0.0) | st.move_mask         # running union (trainer.py:451 rebinds move_mask)
                 st.move_mask = mm
             loss, loss_rgb_pixel, l_rgb, l_depth = losses.image_loss(
                 render4, self.gt_image, self.gt_depth if lambda_depth > 0 else None, self.depth_ab,
@@ -314,14 +315,17 @@ class SimpleGaussian:
                 loss = loss + lambda_var * l_var
                 terms["var"] = l_var
             if lambda_scale:
-                # trainer.py:495-502 (scale rows selected by within_index, depths by valid)
-                l_scale = losses.scale_loss(self.get_attribute("scale"), self.within_index, depth[valid])
+                # trainer.py:495-502: the reference's within_index ALIASES valid_uv_index, which :467-471 narrow in
+                # place, so scale and depth are both taken over `valid`
+                l_scale = losses.scale_loss(self.get_attribute("scale"), valid, depth[valid])
                 loss = loss + lambda_scale * l_scale
                 terms["scale"] = l_scale
             if lambda_still and has_still:
                 m = self.last_still_mask
                 diff = torch.norm(self.get_attribute("xyz")[:m.shape[0]] - self.last_xyz[:m.shape[0]], dim=1)
-                l_still = (diff * m).sum() / m.sum()
+                # (an empty selection gives the reference a NaN LOSS VALUE but finite gradients: the
+                # clamp keeps both finite here)
+                l_still = (diff * m).sum() / m.sum().clamp(min=1)
                 loss = loss + lambda_still * l_still
                 terms["still"] = l_still
             if lambda_flow and self.gt_flow is not None and hasattr(self, "last_uv"):
@@ -332,7 +336,7 @@ class SimpleGaussian:
                 yx = self.last_uv.long()
                 gt_f = self.gt_flow[yx[:, 1].clamp(0, H - 1), yx[:, 0].clamp(0, W - 1)]
                 d = (uv[:self.last_num] - self.last_uv - gt_f) ** 2
-                l_flow = (d * and_mask.unsqueeze(1)).sum() / (2.0 * and_mask.sum())      # mse over selected rows
+                l_flow = (d * and_mask.unsqueeze(1)).sum() / (2.0 * and_mask.sum().clamp(min=1))   # mse over selected rows
                 loss = loss + lambda_flow * l_flow
                 terms["flow"] = l_flow
 
@@ -365,9 +369,9 @@ class SimpleGaussian:
                 self.densify_by_pixels(loss_rgb_pixel, error_threshold=densify_err_thre, percent=densify_err_percent,
                                        mask=None)
             if snap:
-                st.frames.append(render_mod.render2img(render4[:3]))
-                st.frames_depth.append(render_mod.render2img(extras[0]))
-                st.frames_center.append(render_mod.render2img(extras[1]))
+                st.frames.append(render_mod.render2img_device(render4[:3]))
+                st.frames_depth.append(render_mod.render2img_device(extras[0]))
+                st.frames_center.append(render_mod.render2img_device(extras[1]))
             st.uv, st.depth, st.last_render = uv.detach(), depth.detach(), render4.detach()
             st.iteration += 1
 
@@ -386,12 +390,15 @@ class SimpleGaussian:
         """Copy the attribute tensors into the engine's packed rows and re-point
         ``_attributes`` at live views of them."""
         eng = self._engine_for(self.current_pts_num())
-        eng.set_splats(self._attributes)
+        if not (getattr(self, "_engine_live", False) and eng.N == self.current_pts_num()
+                and self._attributes["xyz"].data_ptr() == eng.params.data_ptr()):
+            eng.set_splats(self._attributes)         # (already live views of the engine's rows: nothing to copy)
         self._attributes = eng.views()
+        self._engine_live = True
         return eng
 
     def _make_fused_stepper(self, iterations, lr, lr_camera, lambda_rgb, lambda_depth, lambda_flow, lambda_var,
-                            lambda_still, move_mask, densify_interval, densify_times, mask, camera_only,
+                            lambda_still, lambda_scale, move_mask, densify_interval, densify_times, mask, camera_only,
                             densify_occ_percent, densify_err_thre, densify_err_percent, snapshot_interval,
                             log_interval):
         """Same iteration as ``make_stepper`` but every step is ONE call into
@@ -413,6 +420,7 @@ class SimpleGaussian:
         hp.lambda_rgb = lambda_rgb if lambda_rgb > 0 else 0.0
         hp.lambda_depth = lambda_depth if lambda_depth > 0 else 0.0
         hp.lambda_var, hp.lr, hp.lr_camera = lambda_var, lr, lr_camera
+        hp.lambda_scale = float(lambda_scale or 0.0)
         hp.lr_end_factor, hp.total_iters = 0.1, iterations          # LinearLR(1.0 -> 0.1), trainer.py:384
         hp.freeze_rgb = 1 if later_frame else 0
         hp.freeze_all_splats = 1 if camera_only else 0
@@ -421,13 +429,14 @@ class SimpleGaussian:
         flow_target = flow_w = still_target = still_w = row_flags = None
         if has_still:
             row_flags = torch.zeros(n, dtype=torch.uint8, device=dev)
-            row_flags[:self.still_mask.shape[0]] = self.still_mask.to(torch.uint8)       # trainer.py:543-546
+            # bit0: still (xyz frozen, trainer.py:543-546); bit1: the row has a label (scale term, :467-471)
+            row_flags[:self.still_mask.shape[0]] = self.still_mask.to(torch.uint8) | 2
         if lambda_still and has_still:
             m = self.last_still_mask
             still_target = torch.zeros(n, 3, device=dev)
             still_target[:m.shape[0]] = self.last_xyz[:m.shape[0]]
             still_w = torch.zeros(n, device=dev)
-            still_w[:m.shape[0]] = m.float() / m.sum()
+            still_w[:m.shape[0]] = m.float() / m.sum().clamp(min=1)      # empty selection: weights 0, not 0/0
             hp.lambda_still = lambda_still
         if lambda_flow and self.gt_flow is not None and hasattr(self, "last_uv"):
             and_mask = _within(self.last_uv, W, H)
@@ -440,7 +449,7 @@ class SimpleGaussian:
             flow_target = torch.zeros(n, 2, device=dev)
             flow_target[:self.last_num] = self.last_uv + gt_f
             flow_w = torch.zeros(n, device=dev)
-            flow_w[:self.last_num] = and_mask.float() / (2.0 * and_mask.sum())
+            flow_w[:self.last_num] = and_mask.float() / (2.0 * and_mask.sum().clamp(min=1))
             hp.lambda_flow = lambda_flow
         eng.set_regularisers(flow_target, flow_w, still_target, still_w, row_flags)
         eng.set_targets(self.gt_image, self.gt_depth if lambda_depth > 0 else None,
@@ -457,6 +466,8 @@ class SimpleGaussian:
             eng.set_footprint_mask(move_mask if move_mask is not None else torch.zeros(H, W, dtype=torch.bool),
                                    ~self.still_mask_tentative)
 
+        unit = torch.tensor([1.0, 0.0, 1.0], device=dev)
+
         def extras_from_engine():
             """depth_map_color and center snapshots from the engine's records (render.py:76-106)."""
             rec = eng.rec[:eng.N]
@@ -464,13 +475,13 @@ class SimpleGaussian:
             op, rgb, depth = rec[:, 5:6].contiguous(), rec[:, 6:9].contiguous(), rec[:, 9:10].contiguous()
             dc = render_mod.apply_float_colormap(depth, "turbo", non_zero=True)
             depth_color = msplat.alpha_blending(uv, conic, op, dc, eng.ids, eng.tile_range, self.bg, W, H)
-            unit = torch.tensor([1.0, 0.0, 1.0], device=dev)
             center = msplat.alpha_blending(uv, torch.ones_like(conic) * unit, torch.ones_like(op), rgb, eng.ids,
                                            eng.tile_range, self.bg, W, H)
             return depth_color, center
 
         def one_iteration():
             iteration = st.iteration
+            n_rendered = eng.N                       # rows this iteration projects (densification appends afterwards)
             snap = bool(snapshot_interval) and iteration % snapshot_interval == 0
             if tentative:
                 self.rasterisations_done += 1                # the reference's extra render of the moving set
@@ -478,14 +489,15 @@ class SimpleGaussian:
                 eng.forward()
                 with torch.no_grad():
                     extras = extras_from_engine()
-                st.frames.append(render_mod.render2img(eng.render[:3]))
-                st.frames_depth.append(render_mod.render2img(extras[0]))
-                st.frames_center.append(render_mod.render2img(extras[1]))
+                st.frames.append(render_mod.render2img_device(eng.render[:3]))
+                st.frames_depth.append(render_mod.render2img_device(extras[0]))
+                st.frames_center.append(render_mod.render2img_device(extras[1]))
                 eng.backward_step()
             else:
                 eng.iteration(use_graph=self.use_graph)      # one call (or one hipGraph replay)
             self.rasterisations_done += 1
             self.iterations_done += 1
+            rec_now = eng.rec                        # (densification may re-allocate the engine's buffers below)
             if log_interval and iteration % log_interval == 0:
                 l_rgb, l_depth = eng.loss_terms()
                 total = hp.lambda_rgb * l_rgb + hp.lambda_depth * l_depth
@@ -508,22 +520,16 @@ class SimpleGaussian:
                 self.densify_by_pixels(eng.err_px, error_threshold=densify_err_thre, percent=densify_err_percent,
                                        mask=None)
                 densified = True
-            st.uv, st.depth, st.last_render = eng.uv, eng.depth, eng.render
+            st.uv, st.depth, st.last_render = rec_now[:n_rendered, 0:2], rec_now[:n_rendered, 9:10], eng.render
             if densified:
-                # trainer.py:941-951: the optimiser is replaced by Adam(attributes, lr): moments and
-                # step restart, lr stays constant, pose / depth affine are no longer stepped
-                st.uv, st.depth = eng.uv.clone(), eng.depth.clone()
-                self._pack_to_engine()
+                # trainer.py:941-951: the optimiser is replaced by Adam(attributes, lr): moments and step restart,
+                # lr stays constant, pose / depth affine are no longer stepped.  Flags only: the new rows already
+                # sit behind the old ones in the engine (densification_postfix), their regulariser weights and row
+                # flags are the zeros the capacity-sized buffers were padded with.
+                st.uv, st.depth = st.uv.clone(), st.depth.clone()
                 eng.reset_optimizer(splats=True, camera=False)
                 hp.total_iters = 0
                 hp.step_camera = 0
-                rf = None
-                if has_still:
-                    rf = torch.zeros(eng.N, dtype=torch.uint8, device=dev)
-                    rf[:self.still_mask.shape[0]] = self.still_mask.to(torch.uint8)
-                grow = lambda t, w: None if t is None else torch.cat(
-                    [t[:n], torch.zeros((eng.N - n, w) if w else (eng.N - n,), device=dev, dtype=t.dtype)])
-                eng.set_regularisers(grow(flow_target, 2), grow(flow_w, 0), grow(still_target, 3), grow(still_w, 0), rf)
             st.iteration += 1
 
         st.fn = one_iteration
@@ -539,6 +545,8 @@ class SimpleGaussian:
         for _ in range(iterations):
             st()
         self.train_log = st.log
+        if self.fused and self.engine is not None:
+            self.engine.check_overflow()          # one host read per frame: dropped pairs must not go unnoticed
         camera_only, move_mask = st.camera_only, kw.get("move_mask")
         if move_mask is not None:
             move_mask = move_mask.to(dev).bool()
@@ -583,15 +591,23 @@ class SimpleGaussian:
         self.last_render = st.last_render.clone()
         if save_ckpt:
             self.save_checkpoint(ckpt_name=ckpt_name)
-        return st.frames, st.frames_center, st.frames_depth, still_rgb, still_center, move_rgb, move_center, self.move_seg
+        # the snapshots stayed on the device as uint8 images: ONE copy to the host per list here, not three
+        # blocking copies every 10th iteration (trainer.py:573-582)
+        to_host = lambda lst: [f for f in torch.stack(lst).cpu().numpy()] if lst else []
+        return (to_host(st.frames), to_host(st.frames_center), to_host(st.frames_depth), still_rgb, still_center,
+                move_rgb, move_center, self.move_seg)
 
     # ------------------------------------------------------------ densification
-    def densify_by_pixels(self, error_map, error_threshold=1e-3, percent=0.1, mask=None):
-        """trainer.py:878-939 with the sampling on the device."""
-        H, W, dev = self.H, self.W, self.device
+    def densify_weights(self, error_map, error_threshold=1e-3, mask=None):
+        """The sampling weights of trainer.py:880-897 on the device: (masked error map with the uniform floor, the
+        boolean mask).  Nothing here reads back."""
+        dev = self.device
         err = error_map.detach().float()
-        pos = err[err > 0]
-        err = err + (pos.min() if pos.numel() else 0.0)           # uniform floor (trainer.py:884)
+        inf = torch.full_like(err, float("inf"))
+        pos_min = torch.where(err > 0, err, inf).min()
+        # (no positive entry at all: np.nanmin of an empty selection -- the reference fails there; sample the mask
+        # uniformly instead)
+        err = err + torch.where(torch.isinf(pos_min), torch.ones_like(pos_min), pos_min)      # uniform floor (:884)
         if mask is None:
             m = err > error_threshold
         else:
@@ -599,33 +615,66 @@ class SimpleGaussian:
             if m.dim() == 3:
                 m = m[..., 0] if m.shape[-1] in (1, 3) else m[0]
             m = m > 0
-        err = err * m[:, :err.shape[1]]
-        mask_ratio = float(m.sum().item()) / m.numel()
-        densify_num = int(self.num_points * mask_ratio * percent)
+        m = m[:, :err.shape[1]]
+        return err * m, m
+
+    def new_splats_at(self, ys, xs):
+        """Raw attributes of the splats densification creates at the pixels (ys, xs) (trainer.py:910-934): at the
+        ground-truth depth, isotropic scale depth / min(sampled depths) / num_points, the pixel's colour, identity
+        rotation, opacity 0.99."""
+        dev = self.device
+        k = ys.shape[0]
+        xys = torch.stack([xs, ys], dim=1).float()
+        depths = self.gt_depth[ys, xs].reshape(-1, 1).float()
+        scales = (depths / depths.min()).squeeze(1) * (1.0 / self.num_points)
+        new_xyz = geometry.pix2world(xys, depths, self.intr, self.get_extr().detach())
+        new_scale = torch.abs(scales.unsqueeze(1).repeat(1, 3))
+        new_rgb = torch.logit(torch.clamp(self.gt_image[ys, xs].contiguous(), 1e-15, 1 - 1e-15))
+        new_rot = torch.tensor([1.0, 0.0, 0.0, 0.0], device=dev).repeat(k, 1)
+        new_op = torch.logit(0.99 * torch.ones(k, 1, device=dev)) / 10.0
+        return new_xyz, new_scale, new_rot, new_op, new_rgb
+
+    def densify_by_pixels(self, error_map, error_threshold=1e-3, percent=0.1, mask=None):
+        """trainer.py:878-939 on the device.  ONE host read per call -- the number of masked pixels, which fixes how
+        many rows are appended (launch sizes and tensor shapes live on the host); the reference moves the whole error
+        map to the host and samples with numpy."""
+        W = self.W
+        err, m = self.densify_weights(error_map, error_threshold, mask)
+        n_masked = int(m.sum())                                            # the host read
+        densify_num = int(self.num_points * (n_masked / m.numel()) * percent)     # float64 like numpy (:896-901)
         num_before = self.current_pts_num()
-        if densify_num > 0 and float(err.sum()) > 0:
-            # densify_num independent draws from the error map (the reference's multinomial with
-            # replacement) by inverse-CDF lookup: torch.multinomial over 4e5 categories took ~25 ms
-            cdf = torch.cumsum(err.flatten().double(), 0)
-            u = torch.rand(densify_num, generator=self.gen, device=dev, dtype=torch.float64) * cdf[-1]
-            idx = torch.searchsorted(cdf, u, right=True).clamp_(max=cdf.numel() - 1)
-            ys, xs = idx // W, idx % W
-            xys = torch.stack([xs, ys], dim=1).float()
-            depths = self.gt_depth[ys, xs].reshape(-1, 1).float()
-            scales = torch.ones(densify_num, device=dev) * (1.0 / self.num_points)
-            scales = scales * (depths / depths.min()).squeeze(1)
-            new_xyz = geometry.pix2world(xys, depths, self.intr, self.get_extr().detach())
-            new_scale = torch.abs(scales.unsqueeze(1).repeat(1, 3))
-            new_rgb = torch.logit(torch.clamp(self.gt_image[ys, xs].contiguous(), 1e-15, 1 - 1e-15))
-            new_rot = torch.tensor([1.0, 0.0, 0.0, 0.0], device=dev).repeat(densify_num, 1)
-            new_op = torch.logit(0.99 * torch.ones(densify_num, 1, device=dev)) / 10.0
-            self.densification_postfix(new_xyz, new_scale, new_rot, new_op, new_rgb)
+        if densify_num > 0:
+            idx = self.sample_pixels(err, densify_num)
+            self.last_densify_idx = idx
+            self.densification_postfix(*self.new_splats_at(idx // W, idx % W))
         return num_before, self.current_pts_num()
 
+    def sample_pixels(self, weights, count):
+        """``count`` independent draws (with replacement) of flat pixel indices with probability weights / sum --
+        np.random.choice(H*W, size, p) of trainer.py:905 -- by inverse-CDF lookup on the device (torch.multinomial
+        over 4e5 categories took ~25 ms)."""
+        cdf = torch.cumsum(weights.flatten().double(), 0)
+        u = torch.rand(count, generator=self.gen, device=self.device, dtype=torch.float64) * cdf[-1]
+        return torch.searchsorted(cdf, u, right=True).clamp_(max=cdf.numel() - 1)
+
     def densification_postfix(self, new_xyz, new_scale, new_rotate, new_opacity, new_rgb):
-        """trainer.py:941-951 -- including the quirk that the new optimiser covers only the
-        attributes, with a constant lr and fresh moments."""
+        """trainer.py:941-951 -- including the quirk that the new optimiser covers only the attributes, with a
+        constant lr and fresh moments (the fused stepper turns that into flags, make_stepper).  On the fused path
+        the rows are appended IN PLACE behind the engine's live rows (capacity-based buffers: no concatenation, no
+        re-packing, the parameter views are simply re-cut)."""
         new = {"xyz": new_xyz, "scale": new_scale, "rotate": new_rotate, "opacity": new_opacity, "rgb": new_rgb}
+        eng = self.engine
+        if self.fused and eng is not None and getattr(self, "_engine_live", False):
+            from .fused import COLS
+            n0, k = eng.N, new_xyz.shape[0]
+            eng.ensure_capacity(n0 + k)
+            rows = eng.params[n0:n0 + k]
+            for name, (a, b) in COLS.items():
+                rows[:, a:b] = new[name].detach().reshape(k, b - a)
+            rows[:, 14:] = 0
+            eng.set_count(n0 + k)
+            self._attributes = eng.views()
+            return
         for k in self._attributes:
             cat = torch.cat((self._attributes[k].detach(), new[k]), dim=0).contiguous()
             self._attributes[k] = nn.Parameter(cat).requires_grad_(True)
@@ -634,10 +683,14 @@ class SimpleGaussian:
     # -------------------------------------------------------------- checkpoint
     def save_checkpoint(self, ckpt_name=None):
         """Same dict keys as trainer.py:252-272."""
+        if self.dir is None:
+            raise RuntimeError("save_checkpoint: this trainer was built without log_dir")
         ckpt = {
-            "attributes": {k: v.detach() for k, v in self._attributes.items()},
+            # contiguous clones: on the fused path the attributes are column views of the engine's
+            # [capacity][16] buffer, and torch.save would serialise the whole storage
+            "attributes": {k: v.detach().clone().contiguous() for k, v in self._attributes.items()},
             "intr": self.intr,
-            "extr": self.get_extr().detach(),
+            "extr": self.get_extr().detach().clone(),
             "still_mask": getattr(self, "still_mask", None),
             "move_seg": self.move_seg,
             "last_uv": getattr(self, "last_uv", None),
@@ -656,6 +709,60 @@ class SimpleGaussian:
         for k in ("still_mask", "move_seg", "last_uv"):
             if ckpt.get(k) is not None:
                 setattr(self, k, ckpt[k])
+
+    # -------------------------------------------------------- trajectory render
+    def eval(self, traj_index=None, line_scale=0.1, point_scale=0.3, alpha=0.5, split_interval=None):
+        """trainer.py:713-811: render the current splats (rgb, center, depth_map_color) and the trajectories of the
+        splats ``traj_index`` (poly-lines from their previous to their current positions, older segments fading by
+        ``alpha`` per frame), plus the screen blend of both.  Returns five (H,W,3) uint8 images:
+        (rgb, center, depth_colour, trajectories, rgb with the trajectories on top)."""
+        from .color import apply_float_colormap
+        from .trajectory import gen_line_set
+        dev = self.device
+        traj_index = torch.as_tensor(traj_index, device=dev).long()
+        num_traj = traj_index.shape[0]
+        op_inv = self._activations_inv["opacity"]
+        if not hasattr(self, "traj_xyz"):                                  # the first frame
+            self.traj_xyz = self.get_attribute("xyz")[traj_index].detach().float()
+            self.traj_scale = torch.ones((num_traj, 3), device=dev)
+            self.traj_rotate = torch.tensor([1.0, 0.0, 0.0, 0.0], device=dev).repeat(num_traj, 1)
+            self.traj_opacity = op_inv(0.99 * torch.ones((num_traj, 1), device=dev))
+            if split_interval is None or num_traj == split_interval:
+                traj_rgb = torch.arange(0, 1, 1 / num_traj, device=dev).float().unsqueeze(1)
+            else:
+                still = torch.arange(0, 1, 1 / split_interval, device=dev).float().unsqueeze(1)
+                move = torch.arange(0, 1, 1 / (num_traj - split_interval), device=dev).float().unsqueeze(1)
+                traj_rgb = torch.cat([still, move], dim=0)
+            traj_rgb = apply_float_colormap(traj_rgb, colormap="gist_rainbow")
+            self.traj_rgb = self._activations_inv["rgb"](traj_rgb)
+            self.last_traj_xyz = self.traj_xyz
+            self.last_traj_rgb = self.traj_rgb
+        else:                                                              # the following frames
+            current_xyz = self.get_attribute("xyz")[traj_index].detach().float()
+            line_xyz, line_rgb = gen_line_set(self.last_traj_xyz, current_xyz, self.last_traj_rgb, device=dev)
+            num_in_line = line_xyz.shape[0]
+            self.traj_xyz = torch.cat([self.traj_xyz, line_xyz], dim=0)
+            num_total = self.traj_xyz.shape[0]
+            self.traj_scale = torch.ones((num_total, 3), device=dev) * 1e-6
+            self.traj_rotate = torch.tensor([1.0, 0.0, 0.0, 0.0], device=dev).repeat(num_total, 1)
+            self.traj_opacity = torch.cat([self.traj_opacity * alpha,       # gradually fade out (raw values, :761)
+                                           op_inv(0.99 * torch.ones((num_in_line, 1), device=dev))], dim=0)
+            self.traj_rgb = torch.cat([self.traj_rgb, line_rgb], dim=0)
+            self.last_traj_xyz = current_xyz
+        with torch.no_grad():
+            out = render_mod.render_multiple(self._input_group(detach=True), ["rgb", "center", "depth_map_color"])
+            # (the reference hands the RAW trajectory opacity / colour to the rasteriser, :784-790)
+            traj_group = [self.traj_xyz, self.traj_scale, self.traj_rotate, self.traj_opacity, self.traj_rgb, self.intr,
+                          self.get_extr().detach(), self.bg, self.W, self.H]
+            out_traj = render_mod.render_traj(traj_group, num_traj, line_scale, point_scale)
+            self.rasterisations_done += 2
+        out_img = render_mod.render2img(out["rgb"])
+        out_img_center = render_mod.render2img(out["center"])
+        out_img_depth = render_mod.render2img(out["depth_map_color"])
+        out_img_traj = render_mod.render2img(out_traj)
+        # screen blending
+        result = 1 - (1 - np.array(out_img) / 255.0) * (1 - np.array(out_img_traj) / 255.0)
+        return out_img, out_img_center, out_img_depth, out_img_traj, (result * 255).astype(np.uint8)
 
     def project_points(self, points):
         return msplat.project_point(points, self.intr, self.get_extr(), self.W, self.H)

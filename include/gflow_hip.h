@@ -196,8 +196,9 @@ int gfl_step_increment(int32_t* d_step, gfl_stream_t stream);
  *   d_rec [cap][12]: dL/d(rec[:,0:10])
  * Optional per-splat inputs (NULL = term absent): flow_target[cap][2] + flow_w[cap]
  * (weight = mask/(2 count), trainer.py:511-528), still_target[cap][3] + still_w[cap]
- * (weight = mask/count, trainer.py:505-509), row_flags[cap] (bit0: xyz gradient
- * frozen, trainer.py:543-546).
+ * (weight = mask/count, trainer.py:505-509), row_flags[cap] (bit0: still splat -- xyz gradient
+ * frozen, trainer.py:543-546; bit1: the row carries a still/moving label, i.e. it existed when the
+ * labels were made: the scale term and nothing else looks at it).
  * workspace: gfl_fit_workspace_bytes(...) bytes, ZERO-INITIALISED ONCE by the host and then left
  * alone between calls: besides scratch it holds the tile scheduler's feedback (the work the
  * backward blend measured per tile, used to balance the next iteration's blend launches over the
@@ -218,13 +219,15 @@ typedef struct gfl_fit_state {
     int32_t* step;                              /* device step counter (Adam t-1, LinearLR epoch) */
     const float* gt_rgb;                        /* [H][W][3] */
     const float* gt_depth;                      /* [H][W] or NULL */
-    uint8_t* keep;                              /* [H][W] or NULL (0 = masked-out pixel); an OUTPUT of
+    uint8_t* keep;                              /* [H][W] or NULL (0 = masked-out pixel); IN/OUT of
                                                  * gfl_fit_forward when foot_flags is set */
-    const uint8_t* move_mask;                   /* [H][W] or NULL: the frame's move mask (camera-only stage) */
-    const uint8_t* foot_flags;                  /* [cap] or NULL.  Non-NULL: every forward rebuilds
-                                                 * keep = !(move_mask | footprint of the flagged splats), the
-                                                 * mask GFlow gets from an extra render of the tentative moving
-                                                 * splats with "grey > 0" (trainer.py:426-451) */
+    const uint8_t* move_mask;                   /* [H][W] or NULL: the frame's move mask (informational; the
+                                                 * caller initialises keep = !move_mask for the camera-only stage) */
+    const uint8_t* foot_flags;                  /* [cap] or NULL.  Non-NULL: every forward clears from keep the
+                                                 * footprint of the flagged splats -- the mask GFlow gets from an
+                                                 * extra render of the tentative moving splats with "grey > 0",
+                                                 * accumulated over the iterations as trainer.py:426-451 does
+                                                 * (move_mask = move_gs_mask | move_mask inside the loop) */
     float *render, *final_T;                    /* [4][H][W], [H][W] */
     int32_t* n_contrib;                         /* [H][W] */
     float *d_render, *err_px, *sums;            /* [4][H][W], [H][W], [8] as gfl_loss_fwd_bwd */
@@ -236,6 +239,8 @@ typedef struct gfl_fit_state {
 typedef struct gfl_fit_hyper {
     float bg, nearest, extent;
     float lambda_rgb, lambda_depth, lambda_var, lambda_flow, lambda_still;
+    float lambda_scale;        /* trainer.py:495-502: mean over the rows inside the image (still rows in the
+                                * camera-only stage, moving rows in the joint stage, by row_flags) of |scale| / depth */
     float lr, lr_camera, beta1, beta2, eps, lr_end_factor;
     int32_t total_iters;       /* LinearLR total_iters, 0 = constant lr */
     int32_t freeze_rgb;        /* trainer.py:537-540 */
@@ -249,6 +254,20 @@ int gfl_fit_forward(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream
 /* loss + backward + optimiser step on the state gfl_fit_forward left behind */
 int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream);
 int gfl_fit_iteration(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream);
+/* ---- the fused rasteriser as a differentiable operator (no loss, no optimiser) ------------------------
+ * render(gaussians, camera) -> {rgb, depth_map, uv, depth} = render_multiple(input_group, ["rgb", "uv", "depth",
+ * "depth_map"]) of render.py:6-108 in ONE call (last row), and its backward.
+ * Same state struct as the fit iteration, read differently:
+ *   params [cap][16] hold the ACTIVATED attributes the reference passes to msplat (xyz | scale | unit quaternion
+ *   wxyz | opacity | rgb | pad pad), st->extr is an INPUT (world->camera, 12 floats), pose / Adam / target / loss
+ *   fields are ignored (may be NULL); hp supplies bg, nearest, extent only.
+ * gfl_render_fwd fills rec (uv = rec[:,0:2], depth = rec[:,9]), render[4][H][W] (rgb planes + depth_map),
+ * final_T, n_contrib, ids, tile_range.  gfl_render_bwd takes dL/d render [4][H][W] and, optionally (NULL = 0),
+ * dL/d uv [N][2] and dL/d depth [N] and returns d_params [N][16] (same column layout as params, the two pad
+ * columns zero) and d_extr[12]; it must follow the gfl_render_fwd whose state it differentiates. */
+int gfl_render_fwd(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream);
+int gfl_render_bwd(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float* d_render, const float* d_uv,
+                   const float* d_depth, float* d_params, float* d_extr, gfl_stream_t stream);
 /* once per ground-truth image / keep mask: SSIM statistics of the target into the workspace; set
  * st->gt_cached = 1 afterwards (0 is always valid: everything is then recomputed per iteration) */
 int gfl_fit_prepare_targets(const gfl_fit_state* st, gfl_stream_t stream);

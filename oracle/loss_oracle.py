@@ -71,6 +71,21 @@ def var_loss(scale):
     return torch.std(scale, dim=1).mean()
 
 
+def scale_loss(scale, uv, depth, W, H, still_mask=None, camera_only=False):
+    """gflow/trainer.py:495-502 with the index sets of :424-425 and :467-471.  The reference stores
+    ``self.within_index = valid_uv_index`` -- the SAME tensor it then narrows in place to the still rows (camera-only
+    stage) or the moving rows (joint stage) -- so ``scale[self.within_index]`` and ``depth_point = depth[valid_uv_index]``
+    select one and the same set of rows.  scale (N,3) activated; uv (N,2), depth (N,1) of this iteration;
+    still_mask (M,) bool with M <= N or None."""
+    valid = (uv[:, 0] > 0) & (uv[:, 0] < W - 1) & (uv[:, 1] > 0) & (uv[:, 1] < H - 1)
+    if still_mask is not None:
+        valid = valid.clone()
+        n = still_mask.shape[0]
+        valid[:n] = (still_mask if camera_only else ~still_mask) & valid[:n]
+    valid = valid.detach()
+    return (torch.norm(scale[valid], dim=1) * (1.0 / depth[valid]).squeeze(-1)).mean()
+
+
 def flow_loss(uv, last_uv, gt_flow, mask):
     """gflow/trainer.py:511-528.  uv (N,2) current; last_uv (M,2) with M<=N; gt_flow
     (H,W,2); mask (M,) bool.  GT flow is sampled at trunc(last_uv)."""

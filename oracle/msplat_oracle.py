@@ -325,6 +325,21 @@ def render_multiple(input_group, return_type=("rgb", "uv", "depth", "depth_map",
     return out
 
 
+def render_traj(input_group, point_num, line_scale=1.0, point_scale=2.0):
+    """gflow/utils/render.py:110-156: every splat drawn as an isotropic blob -- conic [1,0,1] * line_scale for the
+    last ``point_num`` rows, * point_scale for the others (:144-146) -- over the lists of the real footprints."""
+    xyz, scale, rotate, opacity, rgb, intr, extr, bg, W, H = input_group
+    uv, depth = project_point(xyz, intr, extr, W, H)
+    visible = depth != 0
+    cov3d = compute_cov3d(scale, rotate, visible)
+    conic, radius, tiles = ewa_project(xyz, cov3d, intr, extr, uv, W, H, visible)
+    ids, tile_range = sort_gaussian(uv, depth, W, H, radius, tiles)
+    unit = torch.tensor([1.0, 0.0, 1.0], dtype=conic.dtype)
+    conic = torch.ones_like(conic) * unit * line_scale
+    conic[:-point_num] = torch.ones_like(conic[:-point_num]) * unit * point_scale
+    return alpha_blending(uv, conic, opacity, rgb, ids, tile_range, bg, W, H)
+
+
 def alpha_blending_loops(uv, conic, opacity, feature, gaussian_ids_sorted, tile_range, bg, W, H):
     """Literal per-pixel restatement of the compositing loop (pure python, small
     cases only); an independent check on the vectorised alpha_blending above.

@@ -8,7 +8,7 @@ Only input/output DATA is written (small .npz files); no reference source is
 copied.  The GPU box has no /root/reference, so nothing at test time runs this.
 
 What the reference lets us import: utils/pytorch_ssim.py,
-utils/geometry.py, utils/color.py.  The rasteriser (msplat) cannot be imported.
+utils/geometry.py, utils/color.py, utils/trainer_functions.py.  The rasteriser (msplat) cannot be imported.
 """
 import importlib.util
 import os
@@ -90,6 +90,17 @@ def main():
                         ramp=ramp.numpy(), rainbow_ramp=full.numpy())
     os.makedirs(DATA, exist_ok=True)
     np.savez_compressed(os.path.join(DATA, "colormaps.npz"), turbo=turbo, gist_rainbow=rainbow)
+
+    # ---- trajectory poly-lines (gflow/utils/trainer_functions.py:5-40)
+    tf = load("trainer_functions")
+    g2 = torch.Generator().manual_seed(77)
+    x1 = torch.rand(9, 3, generator=g2)
+    x2 = x1 + torch.tensor([[0.0, 0.0, 0.0], [0.005, 0.0, 0.0], [0.02, 0.01, 0.0], [0.1, -0.05, 0.02], [0.0, 0.3, 0.0],
+                            [0.019999, 0.0, 0.0], [0.03, 0.0, 0.0], [-0.25, 0.1, 0.4], [1e-4, 1e-4, 1e-4]])
+    col = torch.rand(9, 3, generator=g2)
+    lx, lc = tf.gen_line_set(x1, x2, col, device="cpu")
+    np.savez_compressed(os.path.join(HERE, "line_set.npz"), xyz1=x1.numpy(), xyz2=x2.numpy(), rgb=col.numpy(),
+                        line_xyz=lx.numpy(), line_rgb=lc.numpy())
     print("golden fixtures written to", HERE)
 
 

@@ -119,3 +119,71 @@ def test_clip_read_back_from_disk_fits_like_the_in_memory_clip(tmp_path):
     b = fit_clip(disk, DEV, SMALL, seed=0)
     assert b["frames"] == 3 and b["iterations"] == a["iterations"]
     assert abs(a["psnr_sum"] - b["psnr_sum"]) / 3 < 1.0, (a, b)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_static_scene_keeps_every_parameter_finite(fused):
+    """A clip without any moving region (all-zero move mask, which io.load_sequence builds when a
+    sequence has no epipolar masks): every splat is "still", so the flow rows of the full fit and
+    the still rows are empty selections.  The reference then reports a NaN loss VALUE but its
+    gradients stay finite (mean / mse over an empty gather); 0/0 row weights must not reach the
+    splats or the pose here either (lambda_flow = 0.01 is the default)."""
+    from gflow_amd.fit_video import fit_clip
+    from gflow_amd.trainer import SimpleGaussian
+    frames = _clip(2)
+    for fr in frames:
+        fr["move_mask"] = torch.zeros_like(fr["move_mask"])
+        fr["occ_mask"] = torch.zeros_like(fr["occ_mask"])
+    f0, f1 = frames
+    tr = SimpleGaussian(f0["image"], f0["depth"], num_points=1500, device=DEV, seed=0, fused=fused)
+    tr.load_camera(focal=f0["focal"], pp=f0["pp"])
+    tr.init_gaussians_from_image(f0["image"], f0["depth"], num_points=1500)
+    kw = dict(lambda_rgb=1.0, lambda_depth=1e-2, densify_interval=0, snapshot_interval=0)
+    tr.train(iterations=20, lr=4e-3, lambda_var=10.0, move_mask=f0["move_mask"], **kw)
+    assert bool(tr.still_mask.all())
+    tr.set_gt_image(f1["image"]); tr.set_gt_depth(f1["depth"]); tr.set_gt_flow(f0["flow"])
+    tr.train(iterations=10, lr_camera=5e-4, lambda_flow=0.01, camera_only=True, move_mask=f1["move_mask"], **kw)
+    tr.train(iterations=10, lr=1e-3, lr_camera=0.0, lambda_var=10.0, lambda_still=10.0, lambda_flow=0.01,
+             move_mask=f1["move_mask"], **kw)
+    for k, v in tr._attributes.items():
+        # (a saturated pixel initialises rgb to logit(1) = +inf in float32, here as in the reference,
+        # trainer.py:229-232; sigmoid(inf) = 1 with zero gradient: harmless.  NaN is what must not appear)
+        assert not torch.isnan(v).any(), k
+        if k != "rgb":
+            assert torch.isfinite(v).all(), k
+    assert torch.isfinite(tr.pose).all() and torch.isfinite(tr.psnr())
+    # and the whole clip driver on the same frames
+    m = fit_clip(frames, DEV, SMALL, seed=0, fused=fused)
+    assert m["psnr_sum"] == m["psnr_sum"] and m["psnr_sum"] / 2 > 20.0
+
+
+def test_fit_clip_loads_the_per_frame_extrinsics():
+    """Frames that carry a camera pose (sequence folders: io.load_sequence) load it before they are
+    fitted, as the reference does with load_extr=True (fit_video.py:115-116, 252-253)."""
+    from gflow_amd import fit_video as FV
+    from gflow_amd import trainer as TR
+    frames = _clip(2)
+    a, b = 0.02, -0.015
+    Ry = torch.tensor([[torch.cos(torch.tensor(a)), 0, torch.sin(torch.tensor(a))], [0, 1, 0],
+                       [-torch.sin(torch.tensor(a)), 0, torch.cos(torch.tensor(a))]])
+    e0 = torch.cat([torch.eye(3), torch.tensor([[0.0], [0.0], [0.0]])], dim=1)
+    e1 = torch.cat([Ry, torch.tensor([[0.01], [b], [0.0]])], dim=1)
+    frames[0]["extr"], frames[1]["extr"] = e0, e1
+    seen = []
+    orig = TR.SimpleGaussian.load_camera
+
+    def spy(self, focal=None, pp=None, extr=None, scale=None, show=False):
+        if extr is not None:
+            seen.append(torch.as_tensor(extr).clone())
+        return orig(self, focal=focal, pp=pp, extr=extr, scale=scale, show=show)
+
+    TR.SimpleGaussian.load_camera = spy
+    try:
+        cfg = dict(SMALL, iterations_first=5, iterations_after=3, iterations_camera=0, camera_first=False)
+        FV.fit_clip(frames, DEV, cfg, seed=0)
+        assert len(seen) == 2 and torch.allclose(seen[0], e0) and torch.allclose(seen[1], e1)
+        seen.clear()
+        FV.fit_clip(frames, DEV, cfg, seed=0, load_extr=False)
+        assert not seen
+    finally:
+        TR.SimpleGaussian.load_camera = orig

@@ -213,6 +213,58 @@ def test_fused_regularisers_and_masks(setup):
     assert torch.equal(before, eng2.params[:n]) and eng2.pose_m.abs().sum() > 0
 
 
+@pytest.mark.parametrize("stage", ["first_frame", "joint", "camera_only"])
+def test_fused_scale_term_matches_oracle(setup, stage):
+    """lambda_scale (trainer.py:495-502) inside the fused iteration: mean of |scale| / depth over the rows inside the
+    image -- narrowed to the moving rows in the joint stage and to the still rows in the camera-only stage for the rows
+    that carry a label (the reference's within_index aliases valid_uv_index)."""
+    s, raw, img, dep = setup
+    n = raw["xyz"].shape[0]
+    lam_scale = 0.5
+    g = torch.Generator().manual_seed(4)
+    still = None
+    hyper = dict(lr=1e-3, lr_camera=1e-3, lambda_rgb=1.0, lambda_scale=lam_scale)
+    if stage != "first_frame":
+        still = torch.rand(n - 300, generator=g) > 0.4            # the last 300 rows were appended later: no label
+    if stage == "camera_only":
+        hyper["freeze_all_splats"] = 1
+    eng = _engine(raw, s, img, dep, pose=POSE, **hyper)
+    if still is not None:
+        flags = torch.zeros(n, dtype=torch.uint8)
+        flags[:still.shape[0]] = still.to(torch.uint8) | 2
+        eng.set_regularisers(row_flags=flags)
+    eng.iteration()
+    rc = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
+    pose = POSE.clone().requires_grad_(True)
+    ab = torch.tensor([1.0, 0.0])
+    loss, info = FO.fit_loss(rc, pose, ab, s["intr"], dict(image=img, depth=dep), 0.0, 1.0, 0.0, 0.0)
+    l_scale = LO.scale_loss(torch.abs(rc["scale"]), info["uv"], info["depth"], s["W"], s["H"], still,
+                            camera_only=(stage == "camera_only"))
+    # the term alone first: its gradient is what the test is about, the render's is checked elsewhere
+    g_scale_only = torch.autograd.grad(lam_scale * l_scale, [rc["scale"], rc["xyz"], pose], retain_graph=True)
+    assert g_scale_only[0].abs().sum() > 0 and g_scale_only[1].abs().sum() > 0
+    (loss + lam_scale * l_scale).backward()
+    gp = (eng.pose_m / 0.1).cpu()
+    rel = (gp - pose.grad).norm() / pose.grad.norm()
+    assert rel < 2e-3, f"d_pose with the scale term: {rel:.2e}"
+    if stage == "camera_only":
+        return                                                    # splat gradients are zeroed in this stage
+    from gflow_amd.fused import COLS
+    g_all = (eng.adam_m[:n] / 0.1).cpu()
+    ref_xyz = rc["xyz"].grad.clone()
+    if still is not None:
+        ref_xyz[:still.shape[0]][still] = 0
+    for k, ref in (("scale", rc["scale"].grad), ("xyz", ref_xyz)):
+        a, b = COLS[k]
+        rel = (g_all[:, a:b] - ref).norm() / ref.norm()
+        assert rel < 2e-3, f"d_{k} with the scale term: {rel:.2e}"
+    # and the term is really in there: without it the scale gradient is measurably different
+    eng0 = _engine(raw, s, img, dep, pose=POSE, lr=1e-3, lr_camera=1e-3, lambda_rgb=1.0)
+    eng0.iteration()
+    a, b = COLS["scale"]
+    assert ((eng0.adam_m[:n, a:b] - eng.adam_m[:n, a:b]).norm() / eng.adam_m[:n, a:b].norm()).item() > 1e-3
+
+
 def test_trainer_fused_and_operator_paths_agree():
     """Short first-frame fit with densification through both trainer paths."""
     from gflow_amd import synthetic as S
@@ -321,8 +373,15 @@ def test_footprint_mask_matches_the_extra_render(setup):
     mismatch = (keep != ref_keep).float().mean().item()
     assert mismatch <= 2e-4, f"footprint mask differs on {mismatch:.2e} of the pixels"
     assert 0.05 < (~ref_keep).float().mean().item() < 0.95          # the case is not degenerate
+    # the mask is the running union over the iterations of the stage (trainer.py:451 rebinds move_mask inside
+    # its loop): after a second forward with a shifted camera nothing that was masked comes back
+    eng.pose[4] += 0.05
+    eng.forward()
+    keep2 = eng.keep.bool().cpu()
+    assert not (keep2 & ~keep).any() and (keep & ~keep2).any()
     # a non-black background lights every pixel of the extra render: everything is masked
     eng.hp.bg = 0.5
+    eng.set_footprint_mask(move_mask, moving)
     eng.forward()
     assert int(eng.keep.sum().item()) == 0
 

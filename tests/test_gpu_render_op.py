@@ -1,0 +1,154 @@
+"""The fused rasteriser as ONE differentiable operator -- gflow_amd.render.render(gaussians, camera), i.e.
+gfl_render_fwd / gfl_render_bwd of include/gflow_hip.h -- against the CPU oracle's render_multiple and against the
+operator-by-operator HIP path (``-m gpu``).  This is what a GFlow user gets after the one-line ``import msplat`` swap:
+gflow/utils/render.py:6-108 asks for exactly {"rgb", "uv", "depth", "depth_map"} in the training call."""
+import pytest
+import torch
+
+from oracle import msplat_oracle as MO
+from tests.scenes import random_scene, scene_group
+from tests.test_gpu_parity import close_frac, to_dev
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+NAMES = ("xyz", "scale", "rotate", "opacity", "rgb")
+
+
+def _weights(H, W, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(3, H, W, generator=g), torch.randn(1, H, W, generator=g), 1e-2 * torch.randn(n, 2, generator=g),
+            1e-1 * torch.randn(n, 1, generator=g))
+
+
+def _loss(out, w):
+    return (out["rgb"] * w[0]).sum() + (out["depth_map"] * w[1]).sum() + (out["uv"] * w[2]).sum() + (out["depth"] * w[3]).sum()
+
+
+@pytest.mark.parametrize("bg", [0.0, 0.33])
+def test_render_operator_values_and_gradients_match_oracle(bg):
+    import gflow_amd.render as R
+    s = random_scene(3000, 200, 136, seed=11, sigma_px=2.5)
+    n, W, H = s["xyz"].shape[0], s["W"], s["H"]
+    w = _weights(H, W, n, 5)
+    # oracle
+    leaves_c = {k: s[k].clone().requires_grad_(True) for k in NAMES}
+    extr_c = s["extr"].clone().requires_grad_(True)
+    oc = MO.render_multiple([*[leaves_c[k] for k in NAMES], s["intr"], extr_c, bg, W, H], ["rgb", "uv", "depth", "depth_map"])
+    _loss(oc, w).backward()
+    # fused operator
+    leaves_g = {k: s[k].clone().to(DEV).requires_grad_(True) for k in NAMES}
+    extr_g = s["extr"].clone().to(DEV).requires_grad_(True)
+    og = R.render(leaves_g, dict(intr=s["intr"].to(DEV), extr=extr_g, W=W, H=H), bg)
+    for k in ("rgb", "depth_map"):
+        close_frac(og[k], oc[k], 1e-4, 1e-5, bad_frac=3e-4, hard=2e-2, what=k)
+    close_frac(og["uv"], oc["uv"], 1e-5, 1e-3, what="uv")
+    close_frac(og["depth"], oc["depth"], 1e-6, 1e-6, what="depth")
+    _loss(og, [t.to(DEV) for t in w]).backward()
+    for k in NAMES:
+        ref = leaves_c[k].grad
+        got = leaves_g[k].grad.cpu()
+        rel = (got - ref).norm() / ref.norm()
+        assert rel < 2e-3, f"d_{k}: relative L2 error {rel:.2e}"
+    rel = (extr_g.grad.cpu() - extr_c.grad).norm() / extr_c.grad.norm()
+    assert rel < 2e-3, f"d_extr: relative L2 error {rel:.2e}"
+
+
+def test_render_multiple_routes_the_training_call_through_the_fused_operator():
+    """Same numbers from render_multiple whether it composes the five msplat operators or calls the fused one; and
+    the fused one is really what runs for the training call's output set."""
+    import gflow_amd.render as R
+    s = random_scene(2500, 168, 120, seed=3, sigma_px=2.0)
+    d = to_dev(s)
+    want = ["rgb", "uv", "depth", "depth_map"]
+    calls = []
+    orig = R._FusedRender.apply
+    R._FusedRender.apply = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
+    try:
+        fused = R.render_multiple(scene_group(d, 0.0), want)
+        assert calls, "render_multiple did not use the fused operator"
+        calls.clear()
+        R.render_multiple(scene_group(d, 0.0), want + ["center"])          # snapshot images: operator path
+        assert not calls
+    finally:
+        R._FusedRender.apply = orig
+    R.USE_FUSED = False
+    try:
+        ops = R.render_multiple(scene_group(d, 0.0), want)
+    finally:
+        R.USE_FUSED = True
+    close_frac(fused["rgb"], ops["rgb"], 2e-5, 2e-6, bad_frac=1e-4, hard=2e-2, what="rgb fused vs operators")
+    close_frac(fused["depth_map"], ops["depth_map"], 2e-5, 2e-6, bad_frac=1e-4, hard=2e-2, what="depth_map")
+    close_frac(fused["uv"], ops["uv"], 1e-6, 1e-4, what="uv")            # (same formulas, separately compiled kernels)
+    close_frac(fused["depth"], ops["depth"], 1e-6, 1e-6, what="depth")
+
+
+def test_two_forwards_before_their_backwards_and_empty_input():
+    """An engine stays with its graph from forward to backward: a second forward in between gets another one, and
+    both backwards give what they give alone.  N = 0 (a boolean-mask gather that selected nothing,
+    trainer.py:430,658) renders the background."""
+    import gflow_amd.render as R
+    sa = to_dev(random_scene(1200, 96, 80, seed=1, sigma_px=2.0))
+    sb = to_dev(random_scene(900, 96, 80, seed=2, sigma_px=3.0))
+
+    def run(s, together_with=None):
+        leaves = {k: s[k].clone().requires_grad_(True) for k in NAMES}
+        out = R.render(leaves, dict(intr=s["intr"], extr=s["extr"], W=s["W"], H=s["H"]), 0.0)
+        other = together_with() if together_with else None
+        (out["rgb"].sum() + out["depth_map"].sum()).backward()
+        return {k: leaves[k].grad.clone() for k in NAMES}, other
+
+    alone_a, _ = run(sa)
+    alone_b, _ = run(sb)
+    nested_a, nested_b = run(sa, together_with=lambda: run(sb)[0])
+    for k in NAMES:
+        assert torch.allclose(alone_a[k], nested_a[k], rtol=1e-4, atol=1e-7), k
+        assert torch.allclose(alone_b[k], nested_b[k], rtol=1e-4, atol=1e-7), k
+    # N = 0
+    e = {k: sa[k][:0] for k in NAMES}
+    out = R.render(e, dict(intr=sa["intr"], extr=sa["extr"], W=96, H=80), 0.33)
+    assert out["rgb"].shape == (3, 80, 96) and torch.allclose(out["rgb"], torch.full_like(out["rgb"], 0.33))
+    assert out["uv"].shape == (0, 2) and out["depth"].shape == (0, 1)
+
+
+def test_operator_costs_about_one_fused_iteration():
+    """the one-line swap runs forward + backward of the rasteriser in two library calls.  Bound its
+    cost against the fused fit iteration (which does the same rasterisation plus loss and Adam) on a 480p / 60k frame."""
+    import time
+    import gflow_amd.render as R
+    from gflow_amd import synthetic as S
+    from gflow_amd.fused import FitEngine
+    H, W, N = 480, 854, 60000
+    frame = S.make_frame(H, W, seed=0)
+    raw = S.init_splats(frame, N, seed=0, grown=True)
+    act = dict(xyz=raw["xyz"], scale=raw["scale"].abs(), rotate=torch.nn.functional.normalize(raw["rotate"]),
+               opacity=torch.sigmoid(10 * raw["opacity"]), rgb=torch.sigmoid(raw["rgb"]))
+    leaves = {k: v.to(DEV).requires_grad_(True) for k, v in act.items()}
+    cam = dict(intr=raw["intr"].to(DEV), extr=raw["extr"].to(DEV), W=W, H=H)
+    gt = frame["image"].to(DEV).permute(2, 0, 1)
+
+    grad = ((torch.rand(3, H, W, device=DEV) - 0.5) / (H * W)).contiguous()
+
+    def op_step():
+        out = R.render(leaves, cam, 0.0)
+        out["rgb"].backward(grad)                    # the operator alone: the caller's loss is the caller's
+
+    eng = FitEngine(W, H, 2 * N, DEV)
+    eng.set_splats({k: raw[k] for k in NAMES})
+    eng.intr.copy_(raw["intr"].to(DEV))
+    eng.set_targets(frame["image"], frame["depth"])
+    eng.hp.lr, eng.hp.lambda_depth, eng.hp.lambda_var = 0.0, 0.1, 10.0
+    eng.reset_optimizer()
+
+    def timed(fn, n=30):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    t_op, t_fit = timed(op_step), timed(eng.iteration)
+    print(f"operator fwd+bwd {t_op * 1e3:.3f} ms, fused fit iteration {t_fit * 1e3:.3f} ms")
+    assert t_op < 1.3 * t_fit, (t_op, t_fit)
