@@ -734,7 +734,10 @@ class SimpleGaussian:
                 move = torch.arange(0, 1, 1 / (num_traj - split_interval), device=dev).float().unsqueeze(1)
                 traj_rgb = torch.cat([still, move], dim=0)
             traj_rgb = apply_float_colormap(traj_rgb, colormap="gist_rainbow")
-            self.traj_rgb = self._activations_inv["rgb"](traj_rgb)
+            # The reference keeps logit(colour) and hands it to the rasteriser RAW (:735, :784-790): table entries that
+            # are exactly 0 or 1 become -inf / +inf, i.e. "saturate wherever the blob has any weight".  A branch-free
+            # compositor multiplies skipped splats by weight 0, and 0 * inf is NaN: keep the saturation, finite.
+            self.traj_rgb = torch.nan_to_num(self._activations_inv["rgb"](traj_rgb), posinf=1e6, neginf=-1e6)
             self.last_traj_xyz = self.traj_xyz
             self.last_traj_rgb = self.traj_rgb
         else:                                                              # the following frames

@@ -131,3 +131,83 @@ def test_sequence_readers_round_trip(tmp_path):
     half = gio.load_sequence(seq, resize=24, frame_range=3)
     assert half[0]["image"].shape == (24, 40, 3) and half[0]["flow"].shape == (24, 40, 2)
     assert half[0]["move_mask"].shape == (24, 40) and half[0]["depth"].shape == (24, 40, 1)
+
+
+# ---------------------------------------------------------------- hand-worked fixtures (cv2 / torchvision are absent)
+def test_sobel_of_the_init_sampler_on_hand_worked_images():
+    """cv2.Sobel(gray, CV_64F, 1, 0, ksize=3) / (0, 1) with OpenCV's default BORDER_REFLECT_101
+    (complex_texture_sampling.py:13-14), worked out by hand:
+    * a ramp g[y][x] = 10 x: away from the left / right border gx = (1 + 2 + 1) * (g[x+1] - g[x-1]) = 4 * 20 = 80;
+      in the first and last column the mirrored neighbour is the inner one itself (REFLECT_101), so gx = 0; gy = 0;
+    * a single bright pixel of height 1: gx is the kernel mirrored around it, [[1,0,-1],[2,0,-2],[1,0,-1]], and gy
+      [[1,2,1],[0,0,0],[-1,-2,-1]]."""
+    import numpy as np
+    from gflow_amd.sampling import _sobel
+    ramp = np.tile(10.0 * np.arange(6), (5, 1))
+    gx, gy = _sobel(ramp)
+    want = np.full((5, 6), 80.0)
+    want[:, 0] = 0.0
+    want[:, -1] = 0.0
+    assert np.array_equal(gx, want) and np.array_equal(gy, np.zeros((5, 6)))
+    gx, gy = _sobel(ramp.T.copy())
+    assert np.array_equal(gy, want.T) and np.array_equal(gx, np.zeros((6, 5)))
+    imp = np.zeros((5, 5))
+    imp[2, 2] = 1.0
+    gx, gy = _sobel(imp)
+    assert np.array_equal(gx[1:4, 1:4], np.array([[1, 0, -1], [2, 0, -2], [1, 0, -1]], dtype=float))
+    assert np.array_equal(gy[1:4, 1:4], np.array([[1, 2, 1], [0, 0, 0], [-1, -2, -1]], dtype=float))
+    assert gx[0].sum() == 0 and gx[:, 0].sum() == 0
+
+
+def test_init_sampler_weights_and_outputs_on_a_hand_worked_image():
+    """complex_texture_sampling.py:6-47 on a 4x6 image whose grey level is the ramp above (R = G = B = x / 25.5, so
+    gray * 255 = 10 x up to rounding): probability = (|grad| + min positive) / sum = 160 in the interior columns,
+    80 in the border columns (the floor alone); scales_norm = 100 / p / sum(1 / p) over the samples; xys are (x, y)."""
+    import numpy as np
+    import torch
+    from gflow_amd.sampling import complex_texture_sampling
+    x = torch.arange(6).float() / 25.5
+    img = x.reshape(1, 6, 1).repeat(4, 1, 3)
+    depth = (1.0 + torch.arange(24).float().reshape(4, 6, 1) / 10.0)
+    xys, depths, scales_norm, rgbs, _ = complex_texture_sampling(img, depth, num_points=4000, rng=np.random.default_rng(0))
+    assert xys.shape == (4000, 2) and xys[:, 0].max() <= 5 and xys[:, 1].max() <= 3
+    # interior columns are drawn twice as often as border columns: 4 x 160 : 2 x 80 per row
+    border = np.isin(xys[:, 0], (0, 5)).mean()
+    assert abs(border - 160.0 / 800.0) < 0.03
+    inv_p = np.where(np.isin(xys[:, 0], (0, 5)), 1.0 / 80.0, 1.0 / 160.0)
+    np.testing.assert_allclose(scales_norm, 100.0 * inv_p / inv_p.sum(), rtol=1e-4)
+    np.testing.assert_allclose(depths.squeeze(-1).numpy(), 1.0 + (xys[:, 1] * 6 + xys[:, 0]) / 10.0, rtol=1e-6)
+    np.testing.assert_allclose(rgbs[:, 0], xys[:, 0] / 25.5, rtol=1e-5)
+
+
+def test_resize_antialias_on_a_hand_worked_row():
+    """transforms.Resize(n, antialias=True) on a tensor is bilinear interpolation with a triangle filter widened by
+    the scale factor (conversion.py:11-12).  Halving a row of 8 pixels: output i is centred at 2 i + 1, its filter
+    max(0, 1 - |j + 0.5 - c| / 2) covers the inputs j = 2i-1 .. 2i+2 with weights 0.25, 0.75, 0.75, 0.25, renormalised
+    where the window leaves the image (first / last output: 0.75, 0.75, 0.25 over 1.75)."""
+    import torch
+    from gflow_amd.io import _resize_chw
+    row = torch.tensor([0.0, 1.0, 4.0, 9.0, 16.0, 25.0, 36.0, 49.0])
+    img = row.reshape(1, 1, 8).repeat(1, 8, 1)                         # (C=1, H=8, W=8), constant along y
+    out = _resize_chw(img, 4)
+    assert out.shape == (1, 4, 4)
+    w_edge, w_mid = torch.tensor([0.75, 0.75, 0.25]) / 1.75, torch.tensor([0.25, 0.75, 0.75, 0.25]) / 2.0
+    want = torch.stack([(w_edge * row[0:3]).sum(), (w_mid * row[1:5]).sum(), (w_mid * row[3:7]).sum(),
+                        (w_edge.flip(0) * row[5:8]).sum()])
+    for y in range(4):
+        assert torch.allclose(out[0, y], want, atol=1e-5), (out[0, y], want)
+    # the shorter side goes to n, the longer keeps the aspect ratio with int() truncation (torchvision's rule)
+    assert _resize_chw(torch.zeros(3, 10, 25), 4).shape == (3, 4, 10)
+    assert _resize_chw(torch.zeros(3, 25, 10), 4).shape == (3, 10, 4)
+    assert _resize_chw(torch.zeros(3, 480, 854), 480).shape == (3, 480, 854)      # DAVIS 480p: a no-op
+
+
+def test_gen_line_set_equals_the_reference_function(golden_dir):
+    """tests/golden/line_set.npz was captured from gflow/utils/trainer_functions.py:5-40 (make_golden.py)."""
+    import os
+    import numpy as np
+    import torch
+    from gflow_amd.trajectory import gen_line_set
+    d = np.load(os.path.join(golden_dir, "line_set.npz"))
+    lx, lc = gen_line_set(torch.from_numpy(d["xyz1"]), torch.from_numpy(d["xyz2"]), torch.from_numpy(d["rgb"]))
+    assert np.array_equal(lx.numpy(), d["line_xyz"]) and np.array_equal(lc.numpy(), d["line_rgb"])
