@@ -119,6 +119,9 @@ __device__ __forceinline__ bool scale_row(float u, float v, int W, int H, unsign
 }
 
 // ------------------------------------------------------------------ preprocess fwd
+// EWA_MFMA: the J Sigma J^T contraction on the matrix cores (cov2d_mfma, gfl_math.hpp) instead of 30 FMAs in the lane
+// -- the variant north_star names; selected with GFL_EWA_MFMA=1, measured in DESIGN.md section 4, off by default.
+template <bool EWA_MFMA>
 __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
     const float* __restrict__ params, const float* __restrict__ intr, const float* __restrict__ pose, int N, int W, int H,
     float nearest, float extent, int gx, int gy, float* __restrict__ rec, int32_t* __restrict__ slot_inv,
@@ -142,16 +145,22 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
     int wx0 = 0, wy0 = 0, wnx = 0, wnt = 0;      // rectangle of a "wide" splat (walked by the wave below)
     int woff = -1;                               // its offset in the slot pool (more than SLOT_MAX tiles)
     bool in_scale_rows = false;
+    Splat s = {};
+    Proj p = {};
+    float cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (i < N) {
-        const Splat s = load_splat(params, i, op_mode != 0);
-        const Proj p = project_fwd(c, s.x, s.y, s.z, W, H, nearest, extent);
+        s = load_splat(params, i, op_mode != 0);
+        p = project_fwd(c, s.x, s.y, s.z, W, H, nearest, extent);
+        if (p.vis) cov3d_fwd(s.s, s.q, cov);
+    }
+    Ewa e = {};
+    if (EWA_MFMA) e = ewa_fwd_mfma(c, p.vis, p.px, p.py, p.pz, cov, W, H);       // (the whole wave: no divergence here)
+    if (i < N) {
         float depth = 0.f, A = 0.f, B = 0.f, C = 0.f;
         int rad = 0, nt_slots = 0;
         if (p.vis) {
             u = p.u; v = p.v; depth = p.pz;
-            float cov[6];
-            cov3d_fwd(s.s, s.q, cov);
-            const Ewa e = ewa_fwd(c, p.px, p.py, p.pz, cov, W, H);
+            if (!EWA_MFMA) e = ewa_fwd(c, p.px, p.py, p.pz, cov, W, H);
             if (e.ok) {
                 const int r = ewa_radius(e);
                 int x0, x1, y0, y1;
@@ -1199,6 +1208,16 @@ size_t gfl_loss_workspace_bytes(int W, int H);
 
 static inline int fit_nblk(int N) { return (N + BIN_BLOCK - 1) / BIN_BLOCK; }
 
+// GFL_EWA_MFMA=1: the measured alternative for the J Sigma J^T contraction (fused_preprocess_fwd_kernel<true>)
+static bool ewa_on_mfma() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GFL_EWA_MFMA");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+
 // one tile queue per CU (the dispatcher places workgroup b on CU b % CUs, tools/placement_probe.hip)
 static int blend_queues() {
     static int nq = 0;
@@ -1319,7 +1338,8 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
     if (lds > 64 * 1024) return GFL_ERR_INVALID;   // tile grid too large for the LDS histogram
     {
         StageScope p(ST_PREPROCESS, s);
-        fused_preprocess_fwd_kernel<<<nblk, BIN_BLOCK, lds, s>>>(st->params, st->intr, st->pose, st->N, st->W, st->H,
+        auto kern = ewa_on_mfma() ? fused_preprocess_fwd_kernel<true> : fused_preprocess_fwd_kernel<false>;
+        kern<<<nblk, BIN_BLOCK, lds, s>>>(st->params, st->intr, st->pose, st->N, st->W, st->H,
                                                                 hp->nearest, hp->extent, gx, gy, st->rec, w.slot_inv,
                                                                 w.hist, st->extr, st->overflow, w.slot_pool,
                                                                 w.pool_counter, st->K_cap, op_mode, st->row_flags,

@@ -97,6 +97,7 @@ __device__ __forceinline__ void cov3d_bwd(const float (&s)[3], const float (&q)[
 }
 
 // --------------------------------------------------------------------- EWA (A6)
+
 struct Ewa {
     float a, b, c, det;          // 2-D covariance (+ low-pass) and determinant
     float m0[3], m1[3];          // rows of J*W
@@ -107,9 +108,91 @@ struct Ewa {
     float lam;                   // larger eigenvalue (floored discriminant)
 };
 
-__device__ __forceinline__ Ewa ewa_fwd(const Cam& c, float px, float py, float pz, const float (&cov)[6], int W,
-                                       int H) {
-    Ewa e;
+// ---- the 2x3 . 3x3 . 3x2 contraction Sigma2 = M Sigma M^T (before the low-pass), two ways --------------------
+// VALU: 30 multiply-adds per splat in the lane that owns the splat.
+__device__ __forceinline__ void cov2d_valu(const float (&m0)[3], const float (&m1)[3], const float (&cov)[6], float& a,
+                                           float& b, float& c) {
+    const float s00 = cov[0] * m0[0] + cov[1] * m0[1] + cov[2] * m0[2];
+    const float s01 = cov[1] * m0[0] + cov[3] * m0[1] + cov[4] * m0[2];
+    const float s02 = cov[2] * m0[0] + cov[4] * m0[1] + cov[5] * m0[2];
+    const float s10 = cov[0] * m1[0] + cov[1] * m1[1] + cov[2] * m1[2];
+    const float s11 = cov[1] * m1[0] + cov[3] * m1[1] + cov[4] * m1[2];
+    const float s12 = cov[2] * m1[0] + cov[4] * m1[1] + cov[5] * m1[2];
+    a = m0[0] * s00 + m0[1] * s01 + m0[2] * s02;
+    b = m0[0] * s10 + m0[1] * s11 + m0[2] * s12;
+    c = m1[0] * s10 + m1[1] * s11 + m1[2] * s12;
+}
+
+// MFMA (north_star: "MFMA only for the 3x3 covariance J Sigma J^T contraction"): v_mfma_f32_4x4x1_16b_f32 multiplies
+// sixteen independent 4x4 blocks per instruction -- block q = lanes 4q..4q+3, lane 4q+i supplies A[i], lane 4q+j
+// supplies B[j], lane 4q+j receives D[i][j] in register i.  A lane owns ONE splat here, so the sixteen splats of a pass
+// (those in lane 4q+P of every quad, P = 0..3) first have to be spread over their quads: one DPP quad broadcast plus
+// one select per operand element.  Per wave: 4 passes x (6 MFMA + ~45 DPP / select) against 30 FMAs per lane.
+// Must be called by all 64 lanes (lanes without a splat pass zeros).  Exact f32 (an fmaf chain per element).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <int P>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), P | (P << 2) | (P << 4) | (P << 6),
+                                                                 0xF, 0xF, true));
+}
+template <int P>
+__device__ __forceinline__ void cov2d_mfma_pass(const float (&m0)[3], const float (&m1)[3], const float (&cov)[6], int r,
+                                                float& a, float& b, float& c) {
+    // rows of the 4x4-padded M of the quad's splat P: lane r holds row r (rows 2, 3 are zero)
+    float Mk[3], Sk[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float x0 = quad_bcast<P>(m0[k]), x1 = quad_bcast<P>(m1[k]);
+        Mk[k] = r == 0 ? x0 : (r == 1 ? x1 : 0.f);
+    }
+    // Sigma row k, column r: (c0 c1 c2 | c1 c3 c4 | c2 c4 c5)
+    const float c0 = quad_bcast<P>(cov[0]), c1 = quad_bcast<P>(cov[1]), c2 = quad_bcast<P>(cov[2]), c3 = quad_bcast<P>(cov[3]),
+                c4 = quad_bcast<P>(cov[4]), c5 = quad_bcast<P>(cov[5]);
+    Sk[0] = r == 0 ? c0 : (r == 1 ? c1 : (r == 2 ? c2 : 0.f));
+    Sk[1] = r == 0 ? c1 : (r == 1 ? c3 : (r == 2 ? c4 : 0.f));
+    Sk[2] = r == 0 ? c2 : (r == 1 ? c4 : (r == 2 ? c5 : 0.f));
+    f32x4_t T = {0.f, 0.f, 0.f, 0.f};                       // T = M Sigma: T[i][j] in register i of lane 4q+j
+#pragma unroll
+    for (int k = 0; k < 3; ++k) T = __builtin_amdgcn_mfma_f32_4x4x1f32(Mk[k], Sk[k], T, 0, 0, 0);
+    f32x4_t D = {0.f, 0.f, 0.f, 0.f};                       // D = T M^T: A[i] = T[i][k] lives in register i of lane 4q+k
+    {
+        const float t0 = quad_bcast<0>(T[0]), t1 = quad_bcast<0>(T[1]);
+        D = __builtin_amdgcn_mfma_f32_4x4x1f32(r == 0 ? t0 : (r == 1 ? t1 : 0.f), Mk[0], D, 0, 0, 0);
+    }
+    {
+        const float t0 = quad_bcast<1>(T[0]), t1 = quad_bcast<1>(T[1]);
+        D = __builtin_amdgcn_mfma_f32_4x4x1f32(r == 0 ? t0 : (r == 1 ? t1 : 0.f), Mk[1], D, 0, 0, 0);
+    }
+    {
+        const float t0 = quad_bcast<2>(T[0]), t1 = quad_bcast<2>(T[1]);
+        D = __builtin_amdgcn_mfma_f32_4x4x1f32(r == 0 ? t0 : (r == 1 ? t1 : 0.f), Mk[2], D, 0, 0, 0);
+    }
+    // Sigma2 = [[D00, D01], [., D11]]: D[0][0] in lane 4q+0 register 0, D[0][1] in lane 4q+1 register 0, D[1][1] in
+    // lane 4q+1 register 1 -> back to the lane that owns the splat
+    const float ra = quad_bcast<0>(D[0]), rb = quad_bcast<1>(D[0]), rc = quad_bcast<1>(D[1]);
+    if (r == P) { a = ra; b = rb; c = rc; }
+}
+__device__ __forceinline__ void cov2d_mfma(const float (&m0)[3], const float (&m1)[3], const float (&cov)[6], float& a,
+                                           float& b, float& c) {
+    const int r = threadIdx.x & 3;
+    a = b = c = 0.f;
+    cov2d_mfma_pass<0>(m0, m1, cov, r, a, b, c);
+    cov2d_mfma_pass<1>(m0, m1, cov, r, a, b, c);
+    cov2d_mfma_pass<2>(m0, m1, cov, r, a, b, c);
+    cov2d_mfma_pass<3>(m0, m1, cov, r, a, b, c);
+}
+
+__device__ __forceinline__ void ewa_finish(Ewa& e, float a, float b, float c) {
+    e.a = a + GFL_LOWPASS;
+    e.b = b;
+    e.c = c + GFL_LOWPASS;
+    e.det = e.a * e.c - e.b * e.b;
+    e.ok = e.det != 0.0f;
+    const float mid = 0.5f * (e.a + e.c);
+    e.lam = mid + sqrtf(fmaxf(mid * mid - e.det, GFL_EIG_FLOOR));
+}
+
+__device__ __forceinline__ void ewa_jacobian(const Cam& c, float px, float py, float pz, int W, int H, Ewa& e) {
     e.z = pz;
     const float limx = GFL_FOV_CLAMP * (float)W / (2.0f * c.fx);
     const float limy = GFL_FOV_CLAMP * (float)H / (2.0f * c.fy);
@@ -124,19 +207,31 @@ __device__ __forceinline__ Ewa ewa_fwd(const Cam& c, float px, float py, float p
     e.j12 = -c.fy * ty / (pz * pz);
     e.m0[0] = e.j00 * c.r00 + e.j02 * c.r20; e.m0[1] = e.j00 * c.r01 + e.j02 * c.r21; e.m0[2] = e.j00 * c.r02 + e.j02 * c.r22;
     e.m1[0] = e.j11 * c.r10 + e.j12 * c.r20; e.m1[1] = e.j11 * c.r11 + e.j12 * c.r21; e.m1[2] = e.j11 * c.r12 + e.j12 * c.r22;
-    const float s00 = cov[0] * e.m0[0] + cov[1] * e.m0[1] + cov[2] * e.m0[2];
-    const float s01 = cov[1] * e.m0[0] + cov[3] * e.m0[1] + cov[4] * e.m0[2];
-    const float s02 = cov[2] * e.m0[0] + cov[4] * e.m0[1] + cov[5] * e.m0[2];
-    const float s10 = cov[0] * e.m1[0] + cov[1] * e.m1[1] + cov[2] * e.m1[2];
-    const float s11 = cov[1] * e.m1[0] + cov[3] * e.m1[1] + cov[4] * e.m1[2];
-    const float s12 = cov[2] * e.m1[0] + cov[4] * e.m1[1] + cov[5] * e.m1[2];
-    e.a = e.m0[0] * s00 + e.m0[1] * s01 + e.m0[2] * s02 + GFL_LOWPASS;
-    e.b = e.m0[0] * s10 + e.m0[1] * s11 + e.m0[2] * s12;
-    e.c = e.m1[0] * s10 + e.m1[1] * s11 + e.m1[2] * s12 + GFL_LOWPASS;
-    e.det = e.a * e.c - e.b * e.b;
-    e.ok = e.det != 0.0f;
-    const float mid = 0.5f * (e.a + e.c);
-    e.lam = mid + sqrtf(fmaxf(mid * mid - e.det, GFL_EIG_FLOOR));
+}
+
+__device__ __forceinline__ Ewa ewa_fwd(const Cam& c, float px, float py, float pz, const float (&cov)[6], int W,
+                                       int H) {
+    Ewa e;
+    ewa_jacobian(c, px, py, pz, W, H, e);
+    float a, b, cc;
+    cov2d_valu(e.m0, e.m1, cov, a, b, cc);
+    ewa_finish(e, a, b, cc);
+    return e;
+}
+
+// the same with the contraction on the matrix cores; ALL 64 lanes of the wave must call it (vis = the lane has a splat)
+__device__ __forceinline__ Ewa ewa_fwd_mfma(const Cam& c, bool vis, float px, float py, float pz, const float (&cov_in)[6],
+                                            int W, int H) {
+    Ewa e;
+    ewa_jacobian(c, px, py, vis ? pz : 1.f, W, H, e);
+    float m0[3], m1[3], cov[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { m0[k] = vis ? e.m0[k] : 0.f; m1[k] = vis ? e.m1[k] : 0.f; }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cov[k] = vis ? cov_in[k] : 0.f;
+    float a, b, cc;
+    cov2d_mfma(m0, m1, cov, a, b, cc);
+    ewa_finish(e, a, b, cc);
     return e;
 }
 

@@ -1,6 +1,6 @@
 // Device self-tests of wave-level primitives, exported so the GPU test-suite can pin
 // them independently of the kernels that use them.
-#include "gfl_common.hpp"
+#include "gfl_math.hpp"
 
 namespace gfl {
 
@@ -21,7 +21,35 @@ __global__ void __launch_bounds__(64) selftest_reduce10_kernel(const float* __re
     }
 }
 
+// Sigma2 = M Sigma M^T of n splats both ways: m [n][6] = rows m0 | m1 of M, cov [n][6]; out_* [n][3] = a b c
+__global__ void __launch_bounds__(256) selftest_cov2d_kernel(const float* __restrict__ m, const float* __restrict__ cov, int n,
+                                                             float* __restrict__ out_valu, float* __restrict__ out_mfma) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float m0[3] = {0.f, 0.f, 0.f}, m1[3] = {0.f, 0.f, 0.f}, cv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (i < n) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { m0[k] = m[i * 6 + k]; m1[k] = m[i * 6 + 3 + k]; }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cv[k] = cov[i * 6 + k];
+    }
+    float a, b, c, a2, b2, c2;
+    cov2d_valu(m0, m1, cv, a, b, c);
+    cov2d_mfma(m0, m1, cv, a2, b2, c2);                 // all lanes
+    if (i < n) {
+        out_valu[i * 3] = a; out_valu[i * 3 + 1] = b; out_valu[i * 3 + 2] = c;
+        out_mfma[i * 3] = a2; out_mfma[i * 3 + 1] = b2; out_mfma[i * 3 + 2] = c2;
+    }
+}
+
 }  // namespace gfl
+
+extern "C" int gfl_selftest_cov2d(const float* m, const float* cov, int n, float* out_valu, float* out_mfma,
+                                  gfl_stream_t stream) {
+    if (!m || !cov || !out_valu || !out_mfma || n < 0) return GFL_ERR_INVALID;
+    if (n == 0) return GFL_OK;
+    gfl::selftest_cov2d_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(m, cov, n, out_valu, out_mfma);
+    return gfl::check_launch();
+}
 
 extern "C" int gfl_selftest_reduce10(const float* in, float* out_scatter, float* out_dpp, gfl_stream_t stream) {
     if (!in || !out_scatter || !out_dpp) return GFL_ERR_INVALID;

@@ -296,6 +296,11 @@ int gfl_tile_sort_with_slots(const int32_t* tile_offsets, int W, int H, int K_ca
 /* device self-test of the wave64 reduce-scatter used by the blend backward: in[64][10] ->
  * out_scatter[10] (permlane-swap reduce-scatter) and out_dpp[10] (plain DPP sums) */
 int gfl_selftest_reduce10(const float* in, float* out_scatter, float* out_dpp, gfl_stream_t stream);
+/* device self-test of the EWA contraction Sigma2 = M Sigma M^T (gfl_math.hpp) both ways: m[n][6] = the two rows of
+ * M = J W, cov[n][6] = xx xy xz yy yz zz -> out_valu[n][3], out_mfma[n][3] = (a, b, c) before the low-pass.  The
+ * MFMA form (v_mfma_f32_4x4x1_16b_f32, sixteen splats per instruction) is what GFL_EWA_MFMA=1 puts into the fused
+ * preprocess kernel; the VALU form is the default. */
+int gfl_selftest_cov2d(const float* m, const float* cov, int n, float* out_valu, float* out_mfma, gfl_stream_t stream);
 
 /* sizeof(gfl_fit_state), sizeof(gfl_fit_hyper): lets an FFI binding verify its struct mirrors */
 int gfl_abi_sizes(int* sizeof_fit_state, int* sizeof_fit_hyper);
