@@ -418,13 +418,32 @@ __device__ __forceinline__ unsigned block_mask(float u, float v, float cutoff, i
 __device__ long long g_fwd_trace[16384 * 8];     // analysis build: per-tile timeline of the forward blend
 #endif
 
+// apply_float_colormap(depth, "turbo", non_zero=True) for one value (color.py:24-44): mm = ordered-uint encodings of
+// min over the non-zero values and max over all (cmap_range_kernel, gfl_loss.hip)
+__device__ __forceinline__ float3 cmap_nonzero_lookup(float v, const unsigned* __restrict__ mm, const float* __restrict__ lut) {
+    const unsigned k0 = mm[0], k1 = mm[1];
+    const float lo = (k0 == 0xffffffffu) ? 0.f : __uint_as_float((k0 & 0x80000000u) ? (k0 & 0x7fffffffu) : ~k0);
+    const float hi = __uint_as_float((k1 & 0x80000000u) ? (k1 & 0x7fffffffu) : ~k1) - lo;
+    float x = (v - lo) / (hi + 1e-5f);
+    x = fminf(fmaxf(x, 0.f), 1.f);
+    if (x != x) x = 0.f;
+    const int idx = (int)(x * 255.f);
+    return make_float3(lut[3 * idx], lut[3 * idx + 1], lut[3 * idx + 2]);
+}
+
 __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(const float* __restrict__ rec,
                                                               const int32_t* __restrict__ ids,
                                                               const int32_t* __restrict__ tile_range, float bg, int W,
                                                               int H, int gx, float* __restrict__ out,
                                                               float* __restrict__ final_T,
                                                               int32_t* __restrict__ n_contrib, TileQueue queue,
-                                                              float* __restrict__ ckpt) {
+                                                              float* __restrict__ ckpt, int mode,
+                                                              const unsigned* __restrict__ cmap_mm,
+                                                              const float* __restrict__ cmap_lut) {
+    // mode 0: the records as they are.  The two snapshot-only images of render.py:76-106 are composites of the SAME
+    // lists with other per-splat values, made while a record is staged: mode 1 = colour := turbo map of the splat's
+    // depth (apply_float_colormap(non_zero=True), range in cmap_mm), mode 2 = unit blob at the centre (conic 1 0 1,
+    // opacity 1).
     __shared__ RecLDS recs[FB + 1];          // recs[FB]: an all-zero record (opacity 0: never blends)
     __shared__ unsigned char s_mask[FB];
     __shared__ int32_t s_ticket;
@@ -466,7 +485,14 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
         if (idx < end) {
             const int g = ids[idx];
             const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g * REC);
-            const float4 p0 = r4[0], p1 = r4[1], p2 = r4[2];
+            float4 p0 = r4[0], p1 = r4[1], p2 = r4[2];
+            if (mode == 1) {
+                const float3 col = cmap_nonzero_lookup(p2.y, cmap_mm, cmap_lut);
+                p1.z = col.x; p1.w = col.y; p2.x = col.z;
+            } else if (mode == 2) {
+                p0.z = 1.f; p0.w = 0.f; p1.x = 1.f; p1.y = 1.f;
+                p2.z = p2.z < 0.f ? p2.z : alpha_cutoff(1.f, 1.f);
+            }
             recs[tid].p0 = p0; recs[tid].p1 = p1; recs[tid].p2 = p2;
             s_mask[tid] = (unsigned char)block_mask(p0.x, p0.y, p2.z, tx * GFL_TILE, ty * GFL_TILE);
         }
@@ -1366,7 +1392,8 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
         StageScope p(ST_BLEND_FWD, s);
         const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters, w.sched.nq, w.sched.cap_q};
         fused_blend_fwd_kernel<<<blend_grid(T, FWD_WG_PER_CU), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx,
-                                                             st->render, st->final_T, st->n_contrib, q, w.ckpt);
+                                                             st->render, st->final_T, st->n_contrib, q, w.ckpt, 0, nullptr,
+                                                             nullptr);
         if (st->foot_flags) {
             // keep is in/out here: the footprint of this iteration's flagged splats is cleared from it, so it
             // carries the running union over the iterations of the stage exactly like the reference, which
@@ -1384,6 +1411,103 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
 
 int gfl_fit_forward(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream) {
     return fit_forward_impl(st, hp, stream, 0);
+}
+
+int gfl_fit_blend_records(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float* rec_alt, float* out4,
+                          float* final_T_scratch, int32_t* n_contrib_scratch, gfl_stream_t stream) {
+    int rc = fit_check(st, hp);
+    if (rc) return rc;
+    if (!rec_alt || !out4 || !final_T_scratch || !n_contrib_scratch) return GFL_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int gx = (st->W + GFL_TILE - 1) / GFL_TILE, gy = (st->H + GFL_TILE - 1) / GFL_TILE, T = gx * gy;
+    const FitWs w = carve(st);
+    // the forward launch of this iteration used up the queues' pull counters: a fresh set for this launch
+    rc = check(hipMemsetAsync(w.sched.counters, 0, (size_t)w.sched.nq * sizeof(int32_t), s));
+    if (rc) return rc;
+    const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters, w.sched.nq, w.sched.cap_q};
+    fused_blend_fwd_kernel<<<blend_grid(T, FWD_WG_PER_CU), 256, 0, s>>>(rec_alt, st->ids, st->tile_range, hp->bg, st->W, st->H, gx,
+                                                                        out4, final_T_scratch, n_contrib_scratch, q, w.ckpt,
+                                                                        0, nullptr, nullptr);
+    return check_launch();
+}
+
+namespace gfl {
+// min over the non-zero / max over all depths of the records, as ordered-uint keys (the range of
+// apply_float_colormap(non_zero=True), color.py:28-31; same encoding as cmap_range_kernel of gfl_loss.hip)
+__global__ void __launch_bounds__(256) rec_depth_range_kernel(const float* __restrict__ rec, int N, unsigned* __restrict__ mm) {
+    unsigned lo = 0xffffffffu, hi = 0u;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const float x = rec[(size_t)i * REC + 9];
+        const unsigned b = __float_as_uint(x);
+        const unsigned k = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+        if (x != 0.f) lo = min(lo, k);
+        hi = max(hi, k);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        lo = min(lo, (unsigned)__shfl_xor((int)lo, off));
+        hi = max(hi, (unsigned)__shfl_xor((int)hi, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&mm[0], lo);
+        atomicMax(&mm[1], hi);
+    }
+}
+
+// three float images [3][H][W] -> uint8 [3 images][H][W][3]: clamp to [0,1], x 255, truncate (render.py:158-166)
+__global__ void __launch_bounds__(256) snapshot_u8_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          const float* __restrict__ c, int P, uint8_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float* src[3] = {a, b, c};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float x = fminf(fmaxf(src[k][(size_t)ch * P + i], 0.f), 1.f) * 255.f;
+            out[((size_t)k * P + i) * 3 + ch] = (uint8_t)(x != x ? 0.f : x);
+        }
+    }
+}
+}  // namespace gfl
+
+size_t gfl_fit_snapshot_workspace_bytes(int N, int W, int H) {
+    if (N < 0 || W <= 0 || H <= 0) return 0;
+    return 256 + 2 * up256((size_t)4 * W * H * sizeof(float)) +
+           up256((size_t)W * H * sizeof(float)) + up256((size_t)W * H * sizeof(int32_t));
+}
+
+int gfl_fit_snapshot(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float* lut, uint8_t* out_u8, void* workspace,
+                     size_t workspace_bytes, gfl_stream_t stream) {
+    int rc = fit_check(st, hp);
+    if (rc) return rc;
+    if (!lut || !out_u8 || !workspace) return GFL_ERR_INVALID;
+    if (workspace_bytes < gfl_fit_snapshot_workspace_bytes(st->N, st->W, st->H)) return GFL_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int gx = (st->W + GFL_TILE - 1) / GFL_TILE, gy = (st->H + GFL_TILE - 1) / GFL_TILE, T = gx * gy;
+    const int P = st->W * st->H;
+    const FitWs w = carve(st);
+    char* p = (char*)workspace;
+    unsigned* mm = (unsigned*)p;                 p += 256;
+    float* img_dc = (float*)p;                   p += up256((size_t)4 * P * sizeof(float));
+    float* img_c = (float*)p;                    p += up256((size_t)4 * P * sizeof(float));
+    float* fT = (float*)p;                       p += up256((size_t)P * sizeof(float));
+    int32_t* nc = (int32_t*)p;
+    rc = check(hipMemsetAsync(mm, 0xff, 4, s));
+    if (!rc) rc = check(hipMemsetAsync(mm + 1, 0, 4, s));
+    if (rc) return rc;
+    if (st->N > 0) rec_depth_range_kernel<<<min((st->N + 255) / 256, 1024), 256, 0, s>>>(st->rec, st->N, mm);
+    const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters, w.sched.nq, w.sched.cap_q};
+    for (int mode = 1; mode <= 2; ++mode) {
+        // the forward launch of the iteration (and the first pass here) used up the queues' pull counters
+        rc = check(hipMemsetAsync(w.sched.counters, 0, (size_t)w.sched.nq * sizeof(int32_t), s));
+        if (rc) return rc;
+        fused_blend_fwd_kernel<<<blend_grid(T, FWD_WG_PER_CU), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H,
+                                                                            gx, mode == 1 ? img_dc : img_c, fT, nc, q, w.ckpt,
+                                                                            mode, mm, lut);
+    }
+    snapshot_u8_kernel<<<(P + 255) / 256, 256, 0, s>>>(st->render, img_dc, img_c, P, out_u8);
+    return check_launch();
 }
 
 int gfl_render_fwd(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream) {

@@ -53,6 +53,10 @@ def _declare(lib):
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(FitState), ctypes.POINTER(FitHyper), _P]
+    lib.gfl_fit_blend_records.restype = ctypes.c_int
+    lib.gfl_fit_blend_records.argtypes = [ctypes.POINTER(FitState), ctypes.POINTER(FitHyper), _P, _P, _P, _P, _P]
+    lib.gfl_fit_snapshot.restype = ctypes.c_int
+    lib.gfl_fit_snapshot.argtypes = [ctypes.POINTER(FitState), ctypes.POINTER(FitHyper), _P, _P, _P, ctypes.c_size_t, _P]
     lib.gfl_render_bwd.restype = ctypes.c_int
     lib.gfl_render_bwd.argtypes = [ctypes.POINTER(FitState), ctypes.POINTER(FitHyper), _P, _P, _P, _P, _P, _P]
     lib._fit_declared = True
@@ -125,7 +129,7 @@ class FitEngine:
         self.d_rec = torch.zeros(cap, REC, **f32)
         if old is not None and n:
             self.params[:n] = old[:n]
-        self.K_cap = int(self.K_cap_req) if self.K_cap_req else max(4_000_000, 16 * cap)
+        self.K_cap = int(self.K_cap_req) if self.K_cap_req else max(2_000_000, 4 * cap)
         self.ids = torch.zeros(self.K_cap, dtype=torch.int32, device=self.dev)
         nbytes = self.lib.gfl_fit_workspace_bytes(cap, self.K_cap, self.W, self.H)
         self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.dev)   # the pool counter must start at 0
@@ -272,6 +276,30 @@ class FitEngine:
         L.check(self.lib.gfl_fit_iteration(ctypes.byref(self.state()), ctypes.byref(self.hp), L.stream()),
                 "fit iteration")
         self._launched = True          # every kernel is loaded now: capture is safe from here on
+
+    def blend_records(self, rec_alt, out4=None):
+        """Composite other records (layout of ``rec``) over the lists of the last forward (gfl_fit_blend_records).
+        Only AFTER the iteration's backward."""
+        if out4 is None:
+            out4 = torch.empty(4, self.H, self.W, dtype=torch.float32, device=self.dev)
+        if getattr(self, "_scratch_T", None) is None:
+            self._scratch_T = torch.empty(self.H, self.W, dtype=torch.float32, device=self.dev)
+            self._scratch_n = torch.empty(self.H, self.W, dtype=torch.int32, device=self.dev)
+        L.check(self.lib.gfl_fit_blend_records(ctypes.byref(self.state()), ctypes.byref(self.hp), L.ptr(rec_alt), L.ptr(out4),
+                                               L.ptr(self._scratch_T), L.ptr(self._scratch_n), L.stream()), "blend records")
+        return out4
+
+    def snapshot(self):
+        """(3, H, W, 3) uint8 on the device: rgb, depth_map_color, center of the last forward (gfl_fit_snapshot).
+        Only AFTER the iteration's backward."""
+        from .color import lut
+        need = self.lib.gfl_fit_snapshot_workspace_bytes(self.N, self.W, self.H)
+        if getattr(self, "_snap_ws", None) is None or self._snap_ws.numel() < need:
+            self._snap_ws = torch.empty(int(need * 1.5), dtype=torch.uint8, device=self.dev)
+        out = torch.empty(3, self.H, self.W, 3, dtype=torch.uint8, device=self.dev)
+        L.check(self.lib.gfl_fit_snapshot(ctypes.byref(self.state()), ctypes.byref(self.hp), L.ptr(lut("turbo", self.dev)),
+                                          L.ptr(out), L.ptr(self._snap_ws), self._snap_ws.numel(), L.stream()), "snapshot")
+        return out
 
     # ------------------------------------------------------------------ outputs
     @property

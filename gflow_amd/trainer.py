@@ -457,6 +457,7 @@ class SimpleGaussian:
 
         st = _Stepper()
         st.frames, st.frames_depth, st.frames_center, st.log = [], [], [], []
+        st.pin = st.copy_stream = None
         st.iteration = 0
         st.move_mask, st.camera_only = move_mask, camera_only
         tentative = hasattr(self, "still_mask_tentative") and camera_only
@@ -466,18 +467,20 @@ class SimpleGaussian:
             eng.set_footprint_mask(move_mask if move_mask is not None else torch.zeros(H, W, dtype=torch.bool),
                                    ~self.still_mask_tentative)
 
-        unit = torch.tensor([1.0, 0.0, 1.0], device=dev)
+        # cutoff of a unit blob with opacity 1 (alpha >= 1/255 inside r^2 = 2 ln 255, with the kernels' margin)
+        blob = torch.tensor([1.0, 0.0, 1.0, 1.0], device=dev)
+        blob_cutoff = 2.0 * math.log(255.0) * 1.002 + 0.01
 
         def extras_from_engine():
-            """depth_map_color and center snapshots from the engine's records (render.py:76-106)."""
+            """depth_map_color and center snapshots (render.py:76-106) with the fused compositor: two copies of the
+            engine's records -- colour := turbo(depth), and conic / opacity := unit blob -- over the same lists."""
             rec = eng.rec[:eng.N]
-            uv, conic = rec[:, 0:2].contiguous(), rec[:, 2:5].contiguous()
-            op, rgb, depth = rec[:, 5:6].contiguous(), rec[:, 6:9].contiguous(), rec[:, 9:10].contiguous()
-            dc = render_mod.apply_float_colormap(depth, "turbo", non_zero=True)
-            depth_color = msplat.alpha_blending(uv, conic, op, dc, eng.ids, eng.tile_range, self.bg, W, H)
-            center = msplat.alpha_blending(uv, torch.ones_like(conic) * unit, torch.ones_like(op), rgb, eng.ids,
-                                           eng.tile_range, self.bg, W, H)
-            return depth_color, center
+            rec_dc = rec.clone()
+            rec_dc[:, 6:9] = render_mod.apply_float_colormap(rec[:, 9:10].contiguous(), "turbo", non_zero=True)
+            rec_c = rec.clone()
+            rec_c[:, 2:6] = blob
+            rec_c[:, 10] = torch.where(rec[:, 10] < 0, rec[:, 10], torch.full_like(rec[:, 10], blob_cutoff))
+            return eng.blend_records(rec_dc)[:3], eng.blend_records(rec_c)[:3]
 
         def one_iteration():
             iteration = st.iteration
@@ -485,16 +488,25 @@ class SimpleGaussian:
             snap = bool(snapshot_interval) and iteration % snapshot_interval == 0
             if tentative:
                 self.rasterisations_done += 1                # the reference's extra render of the moving set
+            eng.iteration(use_graph=self.use_graph)          # one call (or one hipGraph replay)
             if snap:
-                eng.forward()
-                with torch.no_grad():
-                    extras = extras_from_engine()
-                st.frames.append(render_mod.render2img_device(eng.render[:3]))
-                st.frames_depth.append(render_mod.render2img_device(extras[0]))
-                st.frames_center.append(render_mod.render2img_device(extras[1]))
-                eng.backward_step()
-            else:
-                eng.iteration(use_graph=self.use_graph)      # one call (or one hipGraph replay)
+                # the three images of THIS iteration's forward (render, records and lists are untouched by the
+                # backward) in one library call; after the backward because it reuses the forward's workspace
+                imgs = eng.snapshot()
+                # ... and on their way to the host at once, on a copy stream into pinned memory: the reference blocks
+                # on three device-to-host copies here; 150 images per first-frame fit cost ~40 ms as one pageable copy
+                if st.pin is None:
+                    n_snaps = (iterations + snapshot_interval - 1) // snapshot_interval
+                    st.pin = torch.empty((n_snaps, 3, H, W, 3), dtype=torch.uint8, pin_memory=True)
+                    st.copy_stream = torch.cuda.Stream(device=dev)
+                k = len(st.frames)
+                st.copy_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st.copy_stream):
+                    st.pin[k].copy_(imgs, non_blocking=True)
+                imgs.record_stream(st.copy_stream)
+                st.frames.append(st.pin[k, 0])
+                st.frames_depth.append(st.pin[k, 1])
+                st.frames_center.append(st.pin[k, 2])
             self.rasterisations_done += 1
             self.iterations_done += 1
             rec_now = eng.rec                        # (densification may re-allocate the engine's buffers below)
@@ -593,7 +605,11 @@ class SimpleGaussian:
             self.save_checkpoint(ckpt_name=ckpt_name)
         # the snapshots stayed on the device as uint8 images: ONE copy to the host per list here, not three
         # blocking copies every 10th iteration (trainer.py:573-582)
-        to_host = lambda lst: [f for f in torch.stack(lst).cpu().numpy()] if lst else []
+        if getattr(st, "copy_stream", None) is not None:
+            st.copy_stream.synchronize()             # fused path: the images are already in pinned host memory
+            to_host = lambda lst: [f.numpy() for f in lst]
+        else:
+            to_host = lambda lst: [f for f in torch.stack(lst).cpu().numpy()] if lst else []
         return (to_host(st.frames), to_host(st.frames_center), to_host(st.frames_depth), still_rgb, still_center,
                 move_rgb, move_center, self.move_seg)
 

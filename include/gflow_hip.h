@@ -268,6 +268,22 @@ int gfl_fit_iteration(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stre
 int gfl_render_fwd(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream);
 int gfl_render_bwd(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float* d_render, const float* d_uv,
                    const float* d_depth, float* d_params, float* d_extr, gfl_stream_t stream);
+/* Composite OTHER per-splat records over the tile lists of the last forward with the fused 4-channel kernel:
+ * rec_alt [N][12] in the layout of rec (u v A B | C opacity f0 f1 | f2 f3 cutoff radius) -> out4[4][H][W].  This is
+ * how the two snapshot-only images of render.py:76-106 are made every 10th iteration (trainer.py:573-582): the
+ * turbo-coloured depth map (f0..f2 = colour of the splat's depth) and the centre blobs (A B C = 1 0 1, opacity 1).
+ * Call it AFTER the iteration's backward: it overwrites the forward's heavy-tile checkpoints in the workspace.
+ * final_T_scratch [H][W] and n_contrib_scratch [H][W] receive what nobody needs. */
+int gfl_fit_blend_records(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float* rec_alt, float* out4,
+                          float* final_T_scratch, int32_t* n_contrib_scratch, gfl_stream_t stream);
+/* The three snapshot images GFlow keeps every 10th iteration (trainer.py:573-582) in one call, entirely on the
+ * device: rgb of the last forward, the turbo-coloured depth map and the centre blobs (render.py:76-106; both composites
+ * of the same lists, the per-splat values are derived while the records are staged), each clamped, scaled by 255 and
+ * truncated like render2img (render.py:158-166).  out_u8 [3 images][H][W][3] uint8; lut [256][3] = the turbo table.
+ * Call it AFTER the iteration's backward (it reuses the forward's workspace). */
+size_t gfl_fit_snapshot_workspace_bytes(int N, int W, int H);
+int gfl_fit_snapshot(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float* lut, uint8_t* out_u8, void* workspace,
+                     size_t workspace_bytes, gfl_stream_t stream);
 /* once per ground-truth image / keep mask: SSIM statistics of the target into the workspace; set
  * st->gt_cached = 1 afterwards (0 is always valid: everything is then recomputed per iteration) */
 int gfl_fit_prepare_targets(const gfl_fit_state* st, gfl_stream_t stream);

@@ -265,6 +265,32 @@ def test_fused_scale_term_matches_oracle(setup, stage):
     assert ((eng0.adam_m[:n, a:b] - eng.adam_m[:n, a:b]).norm() / eng.adam_m[:n, a:b].norm()).item() > 1e-3
 
 
+def test_snapshot_images_match_the_oracle(setup):
+    """gfl_fit_snapshot: rgb, depth_map_color and center of the last forward as uint8 images, made on the device after
+    the backward (trainer.py:573-582 takes them every 10th iteration) -- against the oracle's render_multiple and
+    render2img (render.py:76-106,158-166).  The two extra images are composites over the lists of the REAL footprints
+    (exact-disc culled): a unit blob may reach a tile its nearly transparent splat does not, hence the small allowance."""
+    s, raw, img, dep = setup
+    eng = _engine(raw, s, img, dep, pose=POSE, lr=0.0, lr_camera=0.0, lambda_rgb=1.0, lambda_depth=0.1)
+    eng.iteration()
+    got = eng.snapshot().cpu().numpy()
+    assert got.shape == (3, s["H"], s["W"], 3) and got.dtype == np.uint8
+    act = FO.activate(raw)
+    oc = MO.render_multiple([*act, s["intr"], LO.pose_to_extr(POSE), 0.0, s["W"], s["H"]], ["rgb", "depth_map_color", "center"])
+    for k, name in enumerate(("rgb", "depth_map_color", "center")):
+        want = (torch.clamp(oc[name].permute(1, 2, 0), 0.0, 1.0).numpy() * 255).astype(np.uint8)
+        d = np.abs(got[k].astype(np.int32) - want.astype(np.int32))
+        assert (d > 1).mean() < (1e-3 if name == "rgb" else 4e-3), f"{name}: {(d > 1).mean():.2e} of the values off"
+    # the iteration after a snapshot is not disturbed by it (the snapshot reuses the forward's workspace)
+    eng2 = _engine(raw, s, img, dep, pose=POSE, lr=1e-3, lambda_rgb=1.0, lambda_depth=0.1)
+    eng3 = _engine(raw, s, img, dep, pose=POSE, lr=1e-3, lambda_rgb=1.0, lambda_depth=0.1)
+    for _ in range(3):
+        eng2.iteration(); eng2.snapshot()
+        eng3.iteration()
+    n = raw["xyz"].shape[0]
+    assert (eng2.params[:n, :14] - eng3.params[:n, :14]).abs().max().item() < 1e-5
+
+
 def test_trainer_fused_and_operator_paths_agree():
     """Short first-frame fit with densification through both trainer paths."""
     from gflow_amd import synthetic as S
