@@ -3,6 +3,8 @@
 #   pass 1  rocprofv3 --kernel-trace --stats      -> per-kernel durations
 #   pass 2  rocprofv3 --pmc FETCH_SIZE            -> HBM read bytes per launch   (own pass)
 #   pass 3  rocprofv3 --pmc WRITE_SIZE            -> HBM write bytes per launch  (own pass)
+#   pass 4  rocprofv3 --pmc SQ_*                  -> VALU instructions / busy cycles per launch (own pass)
+#   pass 5  rocprofv3 --kernel-trace --stats      -> per-kernel durations of a real 3-frame clip fit
 # then tools/summarise_profile.py folds the three into gpurun_out/<tag>_summary.json.
 #   gpurun --timeout 900 -- 'bash tools/profile_round.sh r01b'
 # Copy the summary + kernel stats into profiles/ afterwards (gpurun_out/ is scratch).
@@ -17,6 +19,10 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o r -- $BENCH > "$OUT/bench_trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o r -- $BENCH > "$OUT/bench_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o r -- $BENCH > "$OUT/bench_write.log" 2>&1
+# pass 4: issue counters of the kernels (own pass, counters only)
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/sq" -o r -- $BENCH > "$OUT/bench_sq.log" 2>&1
+# pass 5: kernel durations of an actual clip fit (image-driven start, densification, camera-only stages, snapshots)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/clip" -o r -- python $ROOT/tools/profile_clip.py 3 10 > "$OUT/clip.log" 2>&1
 cd "$ROOT"
 python tools/summarise_profile.py "$OUT" > "$OUT/../${TAG}_summary.json"
 cat "$OUT/../${TAG}_summary.json"

@@ -67,6 +67,13 @@ def main():
         kernels[k] = dict(s, hbm_read_bytes=rd, hbm_write_bytes=wr, hbm_bytes=rd + wr,
                           hbm_GBps=(rd + wr) / (s["avg_us"] * 1e-6) / 1e9)
         stage_bytes[STAGE_OF[k]] += rd + wr
+    sq = {}
+    for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY",
+              "SQ_ACTIVE_INST_LDS", "SQ_WAVES", "GRBM_GUI_ACTIVE"):
+        for k, v in counter_avg(os.path.join(root, "sq"), c).items():
+            if k in STAGE_OF:
+                sq.setdefault(k, {})[c] = v
+    clip = {k: v for k, v in kernel_stats(os.path.join(root, "clip")).items() if k in STAGE_OF or "blend" in k}
     print(json.dumps({
         "tag": os.path.basename(os.path.normpath(root)),
         "command": "python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-stage-pass --no-clip",
@@ -74,6 +81,12 @@ def main():
                   "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B), both counters in KB",
         "kernels": kernels,
         "hbm_bytes_per_launch": dict(stage_bytes),
+        "sq_counters_per_launch": sq,
+        "sq_note": "SQ_* summed over the chip per launch; SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES / SQ_WAIT_INST_ANY count "
+                   "quad-cycles, GRBM_GUI_ACTIVE cycles summed over the 8 XCDs (MI355X_MICROARCH.md)",
+        "clip_fit_kernels": clip,
+        "clip_fit_note": "kernel durations inside an actual 3-frame clip fit (python tools/profile_clip.py 3 10): heavy "
+                         "tiles after densification make the blend kernels and the tile sort slower than on the bench scene",
     }, indent=1))
 
 
