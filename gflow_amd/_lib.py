@@ -24,6 +24,7 @@ c_void_p, c_int, c_float, c_size_t, c_int64 = ctypes.c_void_p, ctypes.c_int, cty
 _P = c_void_p
 SIGNATURES = {
     "gfl_version": (c_int, []),
+    "gfl_constants": (c_int, [_P]),
     "gfl_status_string": (ctypes.c_char_p, [c_int]),
     "gfl_last_hip_error": (c_int, []),
     "gfl_reduce_workspace_bytes": (c_size_t, [c_int]),
@@ -55,7 +56,6 @@ SIGNATURES = {
     "gfl_fit_forward": (c_int, [_P, _P, _P]),          # struct pointers; typed in gflow_amd/fused.py
     "gfl_fit_backward_step": (c_int, [_P, _P, _P]),
     "gfl_fit_iteration": (c_int, [_P, _P, _P]),
-    "gfl_fit_blend_records": (c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "gfl_fit_snapshot_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gfl_fit_snapshot": (c_int, [_P, _P, _P, _P, _P, c_size_t, _P]),
     "gfl_render_fwd": (c_int, [_P, _P, _P]),

@@ -478,6 +478,8 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     // the pixel stopped at.  (Lanes outside the image start stopped.)
     float T = 1.f, Tw = inside ? 1.f : 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int last = 0;
+    const unsigned long long alive0 = __ballot(inside);            // every pixel of the block that is in the image
+    const int px0w = tx * GFL_TILE + (wave & 1) * 8, py0w = ty * GFL_TILE + (wave >> 1) * 8;
 
     for (int base = start; base < end; base += FB) {
         if (__syncthreads_and(Tw == 0.f)) break;
@@ -507,7 +509,33 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                 ++ck_next;
             }
             const int slot = c0 + lane;
-            const bool hit = slot < cnt && ((s_mask[slot] >> wave) & 1);
+            bool hit = slot < cnt && ((s_mask[slot] >> wave) & 1);
+            {
+                // Once pixels have stopped, only splats that reach a pixel that is still ALIVE matter.  In a tile
+                // where densification piled up a thousand small splats the pile's own pixels stop early and the rest
+                // of the pile reaches no one else -- yet the wave used to walk the whole list for the few pixels
+                // beside it (the launch lasted as long as that one chain).  Test each slot's alpha >= 1/255 disc
+                // against the bounding box of the alive pixels (the exact test of block_mask, on a smaller box):
+                // drops only work that contributes exactly nothing.
+                const unsigned long long alive = __ballot(Tw != 0.f);           // lane = (y << 3) | x of the 8x8 block
+                if (alive != alive0) {
+                    unsigned long long a = alive | (alive >> 32);
+                    a |= a >> 16;
+                    a |= a >> 8;
+                    const unsigned cols = (unsigned)a & 0xffu;                   // columns with an alive pixel
+                    const int xl = __builtin_ctz(cols), xh = 31 - __builtin_clz(cols);
+                    const int yl = (int)__builtin_ctzll(alive) >> 3, yh = (63 - (int)__builtin_clzll(alive)) >> 3;
+                    if (hit) {
+                        const float4 q0 = recs[slot].p0;
+                        const float cutoff = recs[slot].p2.z;
+                        const float x_lo = (float)(px0w + xl), x_hi = (float)(px0w + xh);
+                        const float y_lo = (float)(py0w + yl), y_hi = (float)(py0w + yh);
+                        const float ddx = fmaxf(fmaxf(x_lo - q0.x, q0.x - x_hi), 0.f);
+                        const float ddy = fmaxf(fmaxf(y_lo - q0.y, q0.y - y_hi), 0.f);
+                        hit = ddx * ddx + ddy * ddy <= cutoff;
+                    }
+                }
+            }
             unsigned long long bits = __ballot(hit);
             // FWD_UNITS (4) hit splats per trip: their records are fetched and their alphas
             // evaluated together; only the T recurrence is serial.  The body is branch-free: a lane
@@ -679,6 +707,8 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
     }
     if (tid == 0) { s_max_last = 0; s_units = 0; }
     __syncthreads();
+    const unsigned long long alive0 = __ballot(inside);
+    const int px0w = tx * GFL_TILE + (wave & 1) * 8, py0w = ty * GFL_TILE + (wave >> 1) * 8;
     int wave_last = last;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, off));
@@ -717,7 +747,30 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
         for (int c0 = 0; c0 < cnt; c0 += 64) {
             const int slot = c0 + lane;
             const int spos = hi - 1 - r0 - slot;
-            const bool hit = slot < cnt && spos < wave_last && ((s_mask[slot] >> wave) & 1);
+            bool hit = slot < cnt && spos < wave_last && ((s_mask[slot] >> wave) & 1);
+            {
+                // as in the forward pass: only the pixels whose last contributor lies at or behind this group of 64
+                // positions can receive anything from it; splats that do not reach their bounding box are skipped
+                // before their alpha is evaluated (the test of block_mask on a smaller box: exact)
+                const unsigned long long alive = __ballot(last > hi - 1 - r0 - c0 - 63);
+                if (alive != alive0 && alive != 0ull) {
+                    unsigned long long a = alive | (alive >> 32);
+                    a |= a >> 16;
+                    a |= a >> 8;
+                    const unsigned cols = (unsigned)a & 0xffu;
+                    const int xl = __builtin_ctz(cols), xh = 31 - __builtin_clz(cols);
+                    const int yl = (int)__builtin_ctzll(alive) >> 3, yh = (63 - (int)__builtin_clzll(alive)) >> 3;
+                    if (hit) {
+                        const float4 q0 = recs[slot].p0;
+                        const float cutoff = recs[slot].p2.z;
+                        const float x_lo = (float)(px0w + xl), x_hi = (float)(px0w + xh);
+                        const float y_lo = (float)(py0w + yl), y_hi = (float)(py0w + yh);
+                        const float ddx = fmaxf(fmaxf(x_lo - q0.x, q0.x - x_hi), 0.f);
+                        const float ddy = fmaxf(fmaxf(y_lo - q0.y, q0.y - y_hi), 0.f);
+                        hit = ddx * ddx + ddy * ddy <= cutoff;
+                    }
+                }
+            }
             unsigned long long bits = __ballot(hit);
             while (bits) {
                 const int j = c0 + (int)__builtin_ctzll(bits);
@@ -1413,24 +1466,6 @@ int gfl_fit_forward(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream
     return fit_forward_impl(st, hp, stream, 0);
 }
 
-int gfl_fit_blend_records(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float* rec_alt, float* out4,
-                          float* final_T_scratch, int32_t* n_contrib_scratch, gfl_stream_t stream) {
-    int rc = fit_check(st, hp);
-    if (rc) return rc;
-    if (!rec_alt || !out4 || !final_T_scratch || !n_contrib_scratch) return GFL_ERR_INVALID;
-    hipStream_t s = (hipStream_t)stream;
-    const int gx = (st->W + GFL_TILE - 1) / GFL_TILE, gy = (st->H + GFL_TILE - 1) / GFL_TILE, T = gx * gy;
-    const FitWs w = carve(st);
-    // the forward launch of this iteration used up the queues' pull counters: a fresh set for this launch
-    rc = check(hipMemsetAsync(w.sched.counters, 0, (size_t)w.sched.nq * sizeof(int32_t), s));
-    if (rc) return rc;
-    const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters, w.sched.nq, w.sched.cap_q};
-    fused_blend_fwd_kernel<<<blend_grid(T, FWD_WG_PER_CU), 256, 0, s>>>(rec_alt, st->ids, st->tile_range, hp->bg, st->W, st->H, gx,
-                                                                        out4, final_T_scratch, n_contrib_scratch, q, w.ckpt,
-                                                                        0, nullptr, nullptr);
-    return check_launch();
-}
-
 namespace gfl {
 // min over the non-zero / max over all depths of the records, as ordered-uint keys (the range of
 // apply_float_colormap(non_zero=True), color.py:28-31; same encoding as cmap_range_kernel of gfl_loss.hip)
@@ -1496,7 +1531,8 @@ int gfl_fit_snapshot(const gfl_fit_state* st, const gfl_fit_hyper* hp, const flo
     rc = check(hipMemsetAsync(mm, 0xff, 4, s));
     if (!rc) rc = check(hipMemsetAsync(mm + 1, 0, 4, s));
     if (rc) return rc;
-    if (st->N > 0) rec_depth_range_kernel<<<min((st->N + 255) / 256, 1024), 256, 0, s>>>(st->rec, st->N, mm);
+    // (few blocks: a thousand waves hitting the two result words with atomics took 23 us)
+    if (st->N > 0) rec_depth_range_kernel<<<min((st->N + 255) / 256, 32), 256, 0, s>>>(st->rec, st->N, mm);
     const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters, w.sched.nq, w.sched.cap_q};
     for (int mode = 1; mode <= 2; ++mode) {
         // the forward launch of the iteration (and the first pass here) used up the queues' pull counters

@@ -163,7 +163,15 @@ using namespace gfl;
 
 extern "C" {
 
-int gfl_version(void) { return 100; }
+int gfl_version(void) { return 200; }
+
+int gfl_constants(float* out10) {
+    if (!out10) return GFL_ERR_INVALID;
+    const float c[10] = {(float)GFL_TILE, GFL_NEAREST, GFL_EXTENT, GFL_FOV_CLAMP, GFL_LOWPASS, GFL_EIG_FLOOR,
+                         GFL_RADIUS_SIGMA, GFL_ALPHA_MIN, GFL_ALPHA_MAX, GFL_T_MIN};
+    for (int k = 0; k < 10; ++k) out10[k] = c[k];
+    return GFL_OK;
+}
 
 const char* gfl_status_string(int status) {
     switch (status) {

@@ -53,8 +53,6 @@ def _declare(lib):
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(FitState), ctypes.POINTER(FitHyper), _P]
-    lib.gfl_fit_blend_records.restype = ctypes.c_int
-    lib.gfl_fit_blend_records.argtypes = [ctypes.POINTER(FitState), ctypes.POINTER(FitHyper), _P, _P, _P, _P, _P]
     lib.gfl_fit_snapshot.restype = ctypes.c_int
     lib.gfl_fit_snapshot.argtypes = [ctypes.POINTER(FitState), ctypes.POINTER(FitHyper), _P, _P, _P, ctypes.c_size_t, _P]
     lib.gfl_render_bwd.restype = ctypes.c_int
@@ -276,18 +274,6 @@ class FitEngine:
         L.check(self.lib.gfl_fit_iteration(ctypes.byref(self.state()), ctypes.byref(self.hp), L.stream()),
                 "fit iteration")
         self._launched = True          # every kernel is loaded now: capture is safe from here on
-
-    def blend_records(self, rec_alt, out4=None):
-        """Composite other records (layout of ``rec``) over the lists of the last forward (gfl_fit_blend_records).
-        Only AFTER the iteration's backward."""
-        if out4 is None:
-            out4 = torch.empty(4, self.H, self.W, dtype=torch.float32, device=self.dev)
-        if getattr(self, "_scratch_T", None) is None:
-            self._scratch_T = torch.empty(self.H, self.W, dtype=torch.float32, device=self.dev)
-            self._scratch_n = torch.empty(self.H, self.W, dtype=torch.int32, device=self.dev)
-        L.check(self.lib.gfl_fit_blend_records(ctypes.byref(self.state()), ctypes.byref(self.hp), L.ptr(rec_alt), L.ptr(out4),
-                                               L.ptr(self._scratch_T), L.ptr(self._scratch_n), L.stream()), "blend records")
-        return out4
 
     def snapshot(self):
         """(3, H, W, 3) uint8 on the device: rgb, depth_map_color, center of the last forward (gfl_fit_snapshot).

@@ -467,21 +467,6 @@ class SimpleGaussian:
             eng.set_footprint_mask(move_mask if move_mask is not None else torch.zeros(H, W, dtype=torch.bool),
                                    ~self.still_mask_tentative)
 
-        # cutoff of a unit blob with opacity 1 (alpha >= 1/255 inside r^2 = 2 ln 255, with the kernels' margin)
-        blob = torch.tensor([1.0, 0.0, 1.0, 1.0], device=dev)
-        blob_cutoff = 2.0 * math.log(255.0) * 1.002 + 0.01
-
-        def extras_from_engine():
-            """depth_map_color and center snapshots (render.py:76-106) with the fused compositor: two copies of the
-            engine's records -- colour := turbo(depth), and conic / opacity := unit blob -- over the same lists."""
-            rec = eng.rec[:eng.N]
-            rec_dc = rec.clone()
-            rec_dc[:, 6:9] = render_mod.apply_float_colormap(rec[:, 9:10].contiguous(), "turbo", non_zero=True)
-            rec_c = rec.clone()
-            rec_c[:, 2:6] = blob
-            rec_c[:, 10] = torch.where(rec[:, 10] < 0, rec[:, 10], torch.full_like(rec[:, 10], blob_cutoff))
-            return eng.blend_records(rec_dc)[:3], eng.blend_records(rec_c)[:3]
-
         def one_iteration():
             iteration = st.iteration
             n_rendered = eng.N                       # rows this iteration projects (densification appends afterwards)

@@ -11,9 +11,11 @@
  * Conventions
  *   - every pointer is a DEVICE pointer unless named h_*; tensors are dense,
  *     row-major, float32 unless stated; `stream` is a hipStream_t (NULL = default);
- *   - no allocation, no host synchronisation and no global state inside: the
- *     caller supplies outputs and workspaces, all work is enqueued on `stream`
- *     (graph-capturable);
+ *   - no allocation and no host synchronisation inside: the caller supplies outputs and
+ *     workspaces, all work is enqueued on `stream` (graph-capturable).  Process-wide state
+ *     is limited to: the thread-local last HIP error (gfl_last_hip_error), the cached
+ *     CU count of the device, the optional stage profiler (gfl_profile_*) and two
+ *     environment switches read once (GFL_EWA_MFMA; nothing else changes results);
  *   - return value: GFL_OK or a negative gfl_status; HIP launch errors are
  *     returned as GFL_ERR_HIP and the hipError_t is kept in gfl_last_hip_error();
  *   - *_bwd functions OVERWRITE their gradient outputs (they zero what they
@@ -40,20 +42,45 @@ typedef enum gfl_status {
 
 /* Rasteriser constants.  They are internal to msplat and NOT observable from the
  * reference: every one is an assumption taken from the published
- * 3DGS/EWA formulation, kept here and mirrored by oracle/msplat_oracle.py. */
+ * 3DGS/EWA formulation, kept here and mirrored by oracle/msplat_oracle.py.
+ * A maintainer who can read the real msplat sources overrides any of them at build time
+ * (make -C gflow_amd/csrc CONSTS="-DGFL_NEAREST=0.01f -DGFL_LOWPASS=0.0f") and sets the oracle's
+ * copies to match; gfl_constants() reports what a built library uses and
+ * tests/test_abi.py::test_library_and_oracle_use_the_same_constants compares the two.
+ * GFL_TILE is structural (8x8 pixels per wave, four waves per tile) and stays 16. */
 #define GFL_TILE 16
+#ifndef GFL_NEAREST
 #define GFL_NEAREST 0.2f
+#endif
+#ifndef GFL_EXTENT
 #define GFL_EXTENT 1.3f
+#endif
+#ifndef GFL_FOV_CLAMP
 #define GFL_FOV_CLAMP 1.3f
+#endif
+#ifndef GFL_LOWPASS
 #define GFL_LOWPASS 0.3f
+#endif
+#ifndef GFL_EIG_FLOOR
 #define GFL_EIG_FLOOR 0.1f
+#endif
+#ifndef GFL_RADIUS_SIGMA
 #define GFL_RADIUS_SIGMA 3.0f
+#endif
+#ifndef GFL_ALPHA_MIN
 #define GFL_ALPHA_MIN (1.0f / 255.0f)
+#endif
+#ifndef GFL_ALPHA_MAX
 #define GFL_ALPHA_MAX 0.99f
+#endif
+#ifndef GFL_T_MIN
 #define GFL_T_MIN 1e-4f
+#endif
 #define GFL_MAX_BLEND_CHANNELS 4 /* per launch; the host splits wider features */
 
 int gfl_version(void);
+/* out[10] = TILE, NEAREST, EXTENT, FOV_CLAMP, LOWPASS, EIG_FLOOR, RADIUS_SIGMA, ALPHA_MIN, ALPHA_MAX, T_MIN of this build */
+int gfl_constants(float* out10);
 const char* gfl_status_string(int status);
 int gfl_last_hip_error(void);
 /* bytes of scratch any *_bwd that reduces camera gradients needs for N splats */
@@ -268,14 +295,6 @@ int gfl_fit_iteration(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stre
 int gfl_render_fwd(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream);
 int gfl_render_bwd(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float* d_render, const float* d_uv,
                    const float* d_depth, float* d_params, float* d_extr, gfl_stream_t stream);
-/* Composite OTHER per-splat records over the tile lists of the last forward with the fused 4-channel kernel:
- * rec_alt [N][12] in the layout of rec (u v A B | C opacity f0 f1 | f2 f3 cutoff radius) -> out4[4][H][W].  This is
- * how the two snapshot-only images of render.py:76-106 are made every 10th iteration (trainer.py:573-582): the
- * turbo-coloured depth map (f0..f2 = colour of the splat's depth) and the centre blobs (A B C = 1 0 1, opacity 1).
- * Call it AFTER the iteration's backward: it overwrites the forward's heavy-tile checkpoints in the workspace.
- * final_T_scratch [H][W] and n_contrib_scratch [H][W] receive what nobody needs. */
-int gfl_fit_blend_records(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float* rec_alt, float* out4,
-                          float* final_T_scratch, int32_t* n_contrib_scratch, gfl_stream_t stream);
 /* The three snapshot images GFlow keeps every 10th iteration (trainer.py:573-582) in one call, entirely on the
  * device: rgb of the last forward, the turbo-coloured depth map and the centre blobs (render.py:76-106; both composites
  * of the same lists, the per-splat values are derived while the records are staged), each clamped, scaled by 255 and

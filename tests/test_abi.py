@@ -71,3 +71,17 @@ def test_product_does_not_import_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_library_and_oracle_use_the_same_constants():
+    """The rasteriser constants are assumptions about msplat's internals, kept in ONE place per side:
+    include/gflow_hip.h (overridable at build time) and the top of oracle/msplat_oracle.py.  They must agree."""
+    import ctypes
+    from gflow_amd import _lib
+    from oracle import msplat_oracle as MO
+    out = (ctypes.c_float * 10)()
+    assert _lib.load().gfl_constants(out) == 0
+    want = [MO.TILE, MO.NEAREST, MO.EXTENT, MO.FOV_CLAMP, MO.LOWPASS, MO.EIG_FLOOR, MO.RADIUS_SIGMA, MO.ALPHA_MIN,
+            MO.ALPHA_MAX, MO.T_MIN]
+    for got, ref in zip(out, want):
+        assert abs(got - ref) <= 1e-7 * max(1.0, abs(ref)), (list(out), want)
