@@ -63,6 +63,59 @@ def rotmat_to_unitquat_xyzw(R):
     return (q / torch.linalg.norm(q)).to(R.dtype)
 
 
+class _PinnedPool:
+    """Page-locked staging blocks for the snapshots, re-used across train() calls.  Pinning costs ~0.15 ms per MB
+    (hipHostMalloc of the 110-180 MB a stage's snapshots need: 16-43 ms, five times per later frame in a HIP API
+    trace of a clip fit), so a block goes back to the pool as soon as the arrays handed out of it are gone."""
+
+    def __init__(self):
+        self.blocks = []                                # [uint8 pinned tensor, arrays still alive]
+
+    def take(self, nbytes):
+        for b in self.blocks:
+            if b[1] == 0 and b[0].numel() >= nbytes:
+                return b
+        step = 32 << 20
+        b = [torch.empty((nbytes + step - 1) // step * step, dtype=torch.uint8, pin_memory=True), 0]
+        self.blocks.append(b)
+        return b
+
+    def hold(self, block, owner):
+        """the block stays taken while ``owner`` is alive"""
+        import weakref
+
+        def gone():
+            block[1] -= 1
+        block[1] += 1
+        return weakref.finalize(owner, gone)             # call it to let go early
+
+    def hand_out(self, block, tensors):
+        """numpy views of ``tensors`` (views of the block); the block is free again when all of them are collected."""
+        import weakref
+
+        def gone():
+            block[1] -= 1
+        out = []
+        for t in tensors:
+            a = t.numpy()
+            block[1] += 1
+            weakref.finalize(a, gone)
+            out.append(a)
+        return out
+
+
+_PINNED = _PinnedPool()
+_COPY_STREAMS = {}
+
+
+def _copy_stream(dev):
+    """one side stream per device for the snapshot copies (creating a stream per train() call cost 1.4 ms each)"""
+    key = (dev.type, dev.index)
+    if key not in _COPY_STREAMS:
+        _COPY_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _COPY_STREAMS[key]
+
+
 class _Stepper:
     """State of one ``train`` call; calling it runs one iteration."""
 
@@ -457,7 +510,7 @@ class SimpleGaussian:
 
         st = _Stepper()
         st.frames, st.frames_depth, st.frames_center, st.log = [], [], [], []
-        st.pin = st.copy_stream = None
+        st.pin = st.copy_stream = st.pin_hold = None
         st.iteration = 0
         st.move_mask, st.camera_only = move_mask, camera_only
         tentative = hasattr(self, "still_mask_tentative") and camera_only
@@ -482,8 +535,10 @@ class SimpleGaussian:
                 # on three device-to-host copies here; 150 images per first-frame fit cost ~40 ms as one pageable copy
                 if st.pin is None:
                     n_snaps = (iterations + snapshot_interval - 1) // snapshot_interval
-                    st.pin = torch.empty((n_snaps, 3, H, W, 3), dtype=torch.uint8, pin_memory=True)
-                    st.copy_stream = torch.cuda.Stream(device=dev)
+                    st.pin_block = _PINNED.take(n_snaps * 3 * H * W * 3)
+                    st.pin_hold = _PINNED.hold(st.pin_block, st)     # ... while this stepper lives
+                    st.pin = st.pin_block[0][:n_snaps * 3 * H * W * 3].view(n_snaps, 3, H, W, 3)
+                    st.copy_stream = _copy_stream(dev)
                 k = len(st.frames)
                 st.copy_stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(st.copy_stream):
@@ -592,11 +647,15 @@ class SimpleGaussian:
         # blocking copies every 10th iteration (trainer.py:573-582)
         if getattr(st, "copy_stream", None) is not None:
             st.copy_stream.synchronize()             # fused path: the images are already in pinned host memory
-            to_host = lambda lst: [f.numpy() for f in lst]
+            to_host = lambda lst: _PINNED.hand_out(st.pin_block, lst)
         else:
             to_host = lambda lst: [f for f in torch.stack(lst).cpu().numpy()] if lst else []
-        return (to_host(st.frames), to_host(st.frames_center), to_host(st.frames_depth), still_rgb, still_center,
-                move_rgb, move_center, self.move_seg)
+        out = (to_host(st.frames), to_host(st.frames_center), to_host(st.frames_depth), still_rgb, still_center,
+               move_rgb, move_center, self.move_seg)
+        if getattr(st, "pin_hold", None) is not None:
+            st.frames, st.frames_depth, st.frames_center, st.pin = [], [], [], None
+            st.pin_hold()                            # (the stepper and its closure are a cycle: do not wait for the GC)
+        return out
 
     # ------------------------------------------------------------ densification
     def densify_weights(self, error_map, error_threshold=1e-3, mask=None):
