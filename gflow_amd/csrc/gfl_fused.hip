@@ -379,6 +379,7 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* _
 constexpr int BLEND_WG_PER_CU = 8;
 constexpr int FWD_WG_PER_CU = 6;       // the forward blend trades two workgroups per CU for 72 VGPRs (FWD_UNITS)
 constexpr int FWD_UNITS = 4;
+constexpr int FWD_SPLIT_MIN = 512;     // forward: a queue's first tile is walked as four blocks on four CUs when its list is longer
 constexpr int FB = 256;   // staged splats per batch (forward)
 constexpr int FBB = 192;  // backward: 18.6 KB of LDS per workgroup -> 8 workgroups per CU (the tile queues of
                           // gfl_sched.hpp assume that all workgroups of a blend launch are resident)
@@ -430,13 +431,14 @@ __device__ __forceinline__ bool box_hit(const BlockTest& t, float x_lo, float x_
     const float q2 = fmaf(t.B2 * Xs, Yc, a2 + c2) - 1e-6f * (a2 + c2);
     return fminf(q1, q2) <= t.tau;
 }
-__device__ __forceinline__ unsigned block_mask(const float4& p0, const float4& p1, float cutoff, int px0, int py0) {
+// the four bs x bs boxes at (px0, py0): bs = 8, the blocks of a tile; bs = 4, the quarters of a block
+__device__ __forceinline__ unsigned block_mask(const float4& p0, const float4& p1, float cutoff, int px0, int py0, int bs = 8) {
     const BlockTest t = block_test(p0, p1, cutoff);
     unsigned m = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-        const float x_lo = (float)(px0 + (w & 1) * 8), y_lo = (float)(py0 + (w >> 1) * 8);
-        if (box_hit(t, x_lo, x_lo + 7.f, y_lo, y_lo + 7.f)) m |= 1u << w;
+        const float x_lo = (float)(px0 + (w & 1) * bs), y_lo = (float)(py0 + (w >> 1) * bs);
+        if (box_hit(t, x_lo, x_lo + (float)(bs - 1), y_lo, y_lo + (float)(bs - 1))) m |= 1u << w;
     }
     return m;
 }
@@ -466,7 +468,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                                                               int32_t* __restrict__ n_contrib, TileQueue queue,
                                                               float* __restrict__ ckpt, int mode,
                                                               const unsigned* __restrict__ cmap_mm,
-                                                              const float* __restrict__ cmap_lut) {
+                                                              const float* __restrict__ cmap_lut, int split_min) {
     // mode 0: the records as they are.  The two snapshot-only images of render.py:76-106 are composites of the SAME
     // lists with other per-splat values, made while a record is staged: mode 1 = colour := turbo map of the splat's
     // depth (apply_float_colormap(non_zero=True), range in cmap_mm), mode 2 = unit blob at the centre (conic 1 0 1,
@@ -480,20 +482,43 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
         recs[FB].p0 = z; recs[FB].p1 = z; recs[FB].p2 = z;
     }
   for (bool first = true;; first = false) {
-    const TileItem item = next_item(queue, &s_ticket, first, false);
-    const int tile = item.tile;
-    if (tile < 0) break;
+    const TileItem item = next_item(queue, &s_ticket, first, true);
+    if (item.tile < 0) {
+        if (item.part < 0) break;                    // the queue is empty
+        if (item.part == 0) continue;                // ... but its items 1..3 may have to help other queues
+    }
+    // The first (heaviest) tile of every queue comes as four items, like in the backward pass.  When its list is
+    // long, the forward pass walks it as four 8x8 BLOCKS: item 0 on the tile's own CU, items 1..3 of THIS queue
+    // as helpers for the first tiles of three OTHER queues (side by side on one CU the four would share its SIMDs,
+    // and a long tile's waves are bound by their own issue rate: ~8 cycles per instruction alone, ~14 with three
+    // others).  A block's workgroup gives its waves the block's four 4x4 quarters, sixteen lanes each: a quarter is
+    // reached by less than half of the splats that reach the block, and the launch lasts as long as the longest chain of
+    // one wave (real fits pile ~1 000 splats into single tiles: their waves finished at 50-73 us, the mean CU at 29 us).
+    int tile = item.tile, owner = item.queue;
+    if (item.part > 0) {
+        owner = (item.queue + item.part * (queue.nq / 4)) % queue.nq;
+        tile = queue.count[owner] > 0 ? (queue.list[(size_t)owner * queue.cap_q] & 0x0fffffff) : -1;
+        if (tile < 0) continue;
+    }
     const int tx = tile % gx, ty = tile / gx;
-    const int px = tx * GFL_TILE + (wave & 1) * 8 + (lane & 7);
-    const int py = ty * GFL_TILE + (wave >> 1) * 8 + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const float fx = (float)px, fy = (float)py;
     const int start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
-    // the queue's heavy tile: leave the per-pixel state at the split position for the backward pass
-    const bool heavy = first && blockIdx.x < (unsigned)queue.nq;
+    const bool first_tile = item.part >= 0;
+    const int blk = (first_tile && end - start > split_min) ? item.part : -1;
+    if (first_tile && blk < 0 && item.part > 0) continue;                     // not long enough: its own CU walks it whole
+    const int bs = blk < 0 ? 8 : 4;                                           // edge of a wave's pixel box
+    const int org_x = tx * GFL_TILE + (blk < 0 ? 0 : (blk & 1) * 8), org_y = ty * GFL_TILE + (blk < 0 ? 0 : (blk >> 1) * 8);
+    const int px0w = org_x + (wave & 1) * bs, py0w = org_y + (wave >> 1) * bs;
+    const int px = px0w + (blk < 0 ? (lane & 7) : (lane & 3)), py = py0w + (blk < 0 ? (lane >> 3) : ((lane >> 2) & 3));
+    const bool inside = px < W && py < H && (blk < 0 || lane < 16);
+    const float fx = (float)px, fy = (float)py;
+    // leave the per-pixel state at the split positions for the backward pass (which walks this tile in segments),
+    // at the place of the thread that owns the pixel in the whole-tile layout
+    const bool heavy = first_tile;
     const int parts = heavy ? heavy_parts(end - start) : 1;
     const int seg = heavy_seg(end - start, parts);
-    float* ck = ckpt + (size_t)item.queue * (HEAVY_PARTS - 1) * 5 * 256 + tid;
+    const bool ck_lane = blk < 0 || lane < 16;
+    const int ftid = blk < 0 ? tid : blk * 64 + ((py - org_y) << 3) + (px - org_x);
+    float* ck = ckpt + (size_t)owner * (HEAVY_PARTS - 1) * 5 * 256 + ftid;
     int ck_next = 1;                                 // next boundary to checkpoint: position ck_next * seg
 #ifdef GFL_TRACE
     const long long trace_t0 = wall_clock64();
@@ -505,8 +530,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     // the pixel stopped at.  (Lanes outside the image start stopped.)
     float T = 1.f, Tw = inside ? 1.f : 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int last = 0;
-    const unsigned long long alive0 = __ballot(inside);            // every pixel of the block that is in the image
-    const int px0w = tx * GFL_TILE + (wave & 1) * 8, py0w = ty * GFL_TILE + (wave >> 1) * 8;
+    const unsigned long long alive0 = __ballot(inside);            // every pixel of the box that is in the image
 
     for (int base = start; base < end; base += FB) {
         if (__syncthreads_and(Tw == 0.f)) break;
@@ -523,7 +547,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                 p2.z = p2.z < 0.f ? p2.z : alpha_cutoff(1.f, 1.f);
             }
             recs[tid].p0 = p0; recs[tid].p1 = p1; recs[tid].p2 = p2;
-            s_mask[tid] = (unsigned char)block_mask(p0, p1, p2.z, tx * GFL_TILE, ty * GFL_TILE);
+            s_mask[tid] = (unsigned char)block_mask(p0, p1, p2.z, org_x, org_y, bs);
         }
         __syncthreads();
         const int cnt = min(FB, end - base);
@@ -532,7 +556,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
             if (__all(Tw == 0.f)) break;
             if (ck_next < parts && base - start + c0 == ck_next * seg) {
                 float* c5 = ck + (size_t)(ck_next - 1) * 5 * 256;
-                c5[0] = T; c5[256] = a0; c5[512] = a1; c5[768] = a2; c5[1024] = a3;
+                if (ck_lane) { c5[0] = T; c5[256] = a0; c5[512] = a1; c5[768] = a2; c5[1024] = a3; }
                 ++ck_next;
             }
             const int slot = c0 + lane;
@@ -544,14 +568,22 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                 // beside it (the launch lasted as long as that one chain).  Test each slot's alpha >= 1/255 disc
                 // against the bounding box of the alive pixels (the test of block_mask, on a smaller box):
                 // drops only work that contributes exactly nothing.
-                const unsigned long long alive = __ballot(Tw != 0.f);           // lane = (y << 3) | x of the 8x8 block
+                const unsigned long long alive = __ballot(Tw != 0.f);   // lane = (y << 3) | x of the 8x8 block, (y << 2) | x of a quarter
                 if (alive != alive0) {
-                    unsigned long long a = alive | (alive >> 32);
-                    a |= a >> 16;
-                    a |= a >> 8;
-                    const unsigned cols = (unsigned)a & 0xffu;                   // columns with an alive pixel
-                    const int xl = __builtin_ctz(cols), xh = 31 - __builtin_clz(cols);
-                    const int yl = (int)__builtin_ctzll(alive) >> 3, yh = (63 - (int)__builtin_clzll(alive)) >> 3;
+                    int xl, xh, yl, yh;
+                    if (blk < 0) {
+                        unsigned long long a = alive | (alive >> 32);
+                        a |= a >> 16;
+                        a |= a >> 8;
+                        const unsigned cols = (unsigned)a & 0xffu;               // columns with an alive pixel
+                        xl = __builtin_ctz(cols); xh = 31 - __builtin_clz(cols);
+                        yl = (int)__builtin_ctzll(alive) >> 3; yh = (63 - (int)__builtin_clzll(alive)) >> 3;
+                    } else {
+                        const unsigned a16 = (unsigned)alive & 0xffffu;
+                        const unsigned cols = (a16 | (a16 >> 4) | (a16 >> 8) | (a16 >> 12)) & 0xfu;
+                        xl = __builtin_ctz(cols); xh = 31 - __builtin_clz(cols);
+                        yl = __builtin_ctz(a16) >> 2; yh = (31 - __builtin_clz(a16)) >> 2;
+                    }
                     if (hit) {
                         const BlockTest t = block_test(recs[slot].p0, recs[slot].p1, recs[slot].p2.z);
                         hit = box_hit(t, (float)(px0w + xl), (float)(px0w + xh), (float)(py0w + yl), (float)(py0w + yh));
@@ -615,7 +647,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     // the wave stopped before the split position: every pixel's state is frozen, final = checkpoint
     for (; ck_next < parts; ++ck_next) {
         float* c5 = ck + (size_t)(ck_next - 1) * 5 * 256;
-        c5[0] = T; c5[256] = a0; c5[512] = a1; c5[768] = a2; c5[1024] = a3;
+        if (ck_lane) { c5[0] = T; c5[256] = a0; c5[512] = a1; c5[768] = a2; c5[1024] = a3; }
     }
 #ifdef GFL_TRACE
     const int trace_done = __popcll(__ballot(Tw == 0.f && inside));
@@ -1314,6 +1346,16 @@ static bool ewa_on_mfma() {
     return v == 1;
 }
 
+// list length from which the forward blend walks a queue's first tile as four blocks (GFL_FWD_SPLIT_MIN overrides)
+static int fwd_split_min() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GFL_FWD_SPLIT_MIN");
+        v = e ? atoi(e) : FWD_SPLIT_MIN;
+    }
+    return v;
+}
+
 // one tile queue per CU (the dispatcher places workgroup b on CU b % CUs, tools/placement_probe.hip)
 static int blend_queues() {
     static int nq = 0;
@@ -1463,7 +1505,7 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
         const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters, w.sched.nq, w.sched.cap_q};
         fused_blend_fwd_kernel<<<blend_grid(T, FWD_WG_PER_CU), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx,
                                                              st->render, st->final_T, st->n_contrib, q, w.ckpt, 0, nullptr,
-                                                             nullptr);
+                                                             nullptr, fwd_split_min());
         if (st->foot_flags) {
             // keep is in/out here: the footprint of this iteration's flagged splats is cleared from it, so it
             // carries the running union over the iterations of the stage exactly like the reference, which
@@ -1557,7 +1599,7 @@ int gfl_fit_snapshot(const gfl_fit_state* st, const gfl_fit_hyper* hp, const flo
         if (rc) return rc;
         fused_blend_fwd_kernel<<<blend_grid(T, FWD_WG_PER_CU), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H,
                                                                             gx, mode == 1 ? img_dc : img_c, fT, nc, q, w.ckpt,
-                                                                            mode, mm, lut);
+                                                                            mode, mm, lut, fwd_split_min());
     }
     snapshot_u8_kernel<<<(P + 255) / 256, 256, 0, s>>>(st->render, img_dc, img_c, P, out_u8);
     return check_launch();

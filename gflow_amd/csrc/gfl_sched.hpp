@@ -215,10 +215,10 @@ __device__ __forceinline__ TileItem next_item(const TileQueue& q, int32_t* s_tic
     }
     // backward: the first tile of the queue is HEAVY_PARTS items
     const int k = split ? max(idx - (HEAVY_PARTS - 1), 0) : idx;
+    if (split && idx < HEAVY_PARTS) it.part = idx;   // (also when this queue is empty: the forward pass helps other queues)
     if (k >= q.count[it.queue]) return it;
     const int item = q.list[(size_t)it.queue * q.cap_q + k];
     it.tile = item & 0x0fffffff;
-    if (split && idx < HEAVY_PARTS) it.part = idx;
     const int prio = item >> 28;
     if (prio == 3) __builtin_amdgcn_s_setprio(3);
     else if (prio == 2) __builtin_amdgcn_s_setprio(2);

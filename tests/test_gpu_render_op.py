@@ -142,12 +142,15 @@ def test_operator_costs_about_one_fused_iteration():
     def timed(fn, n=30):
         for _ in range(5):
             fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n
+        best = float("inf")
+        for _ in range(3):                           # (a one-off allocator / driver stall of 100 ms has landed in here)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / n)
+        return best
 
     t_op, t_fit = timed(op_step), timed(eng.iteration)
     print(f"operator fwd+bwd {t_op * 1e3:.3f} ms, fused fit iteration {t_fit * 1e3:.3f} ms")
