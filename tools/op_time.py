@@ -40,3 +40,8 @@ for _ in range(10): both()
 torch.cuda.synchronize()
 lib.gfl_profile_enable(0)
 print({k: round(v * 1e3, 1) for k, v in bench.profile_read(lib).items()})
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for _ in range(200): both()
+torch.cuda.synchronize(); pr.disable()
+pstats.Stats(pr).sort_stats("tottime").print_stats(18)
