@@ -35,8 +35,12 @@ def kernel_stats(root):
     out = {}
     if path:
         for r in csv.DictReader(open(path)):
-            out[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
-                                     "pct": float(r["Percentage"])}
+            # template instances of one kernel (ssim_stats_kernel<0> / <1> / <2>) are folded into one entry
+            k, calls, tot = short(r["Name"]), int(r["Calls"]), float(r["TotalDurationNs"])
+            e = out.setdefault(k, {"calls": 0, "avg_us": 0.0, "pct": 0.0})
+            e["avg_us"] = (e["avg_us"] * e["calls"] + tot / 1e3) / (e["calls"] + calls)
+            e["calls"] += calls
+            e["pct"] += float(r["Percentage"])
     return out
 
 
