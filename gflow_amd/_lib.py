@@ -64,6 +64,7 @@ SIGNATURES = {
     "gfl_fit_schedule_info": (c_int, [_P, _P, _P, _P, _P]),
     "gfl_selftest_reduce10": (c_int, [_P, _P, _P, _P]),
     "gfl_selftest_cov2d": (c_int, [_P, _P, c_int, _P, _P, _P]),
+    "gfl_selftest_block_mask": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "gfl_abi_sizes": (c_int, [_P, _P]),
     "gfl_profile_enable": (c_int, [ctypes.c_uint]),
     "gfl_profile_read": (c_int, [_P, _P, c_int]),

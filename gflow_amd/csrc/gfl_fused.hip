@@ -401,47 +401,7 @@ __device__ __forceinline__ bool splat_alpha2(const float4& p0, const float4& p1,
     return (power <= 0.f) & (alpha >= GFL_ALPHA_MIN);
 }
 
-// which of the tile's four 8x8 pixel blocks a splat reaches with alpha >= 1/255.  Exact up to a safety margin: the
-// smallest q = A X^2 + 2 B X Y + C Y^2 over the block's box of pixel centres against 2 ln(255 o).  (Round 1 tested the
-// bounding DISC of that ellipse, radius^2 = 2 ln(255 o) lambda_max: 16 % of the (splat, block) units it let through
-// had no visible pixel at all, tools/lane_efficiency.py.)  q is convex with its minimum at the splat centre, so its
-// minimum over a box that does not contain the centre lies on one of the (at most two) faces that look at the centre:
-// X = clamp(0) with the best Y, or Y = clamp(0) with the best X.
-struct BlockTest {
-    float u, v, A, B2, C, bA, bC, tau;        // B2 = 2 B, bA = B / A, bC = B / C
-};
-__device__ __forceinline__ BlockTest block_test(const float4& p0, const float4& p1, float cutoff) {
-    BlockTest t;
-    t.u = p0.x; t.v = p0.y; t.A = p0.z; t.B2 = 2.f * p0.w; t.C = p1.x;
-    t.bA = p0.w * __builtin_amdgcn_rcpf(p0.z);
-    t.bC = p0.w * __builtin_amdgcn_rcpf(p1.x);
-    const float r = 255.f * p1.y;
-    // cutoff < 0: never visible; r < 1.05: too close to the threshold, no culling (as alpha_cutoff)
-    t.tau = cutoff < 0.f ? -1.f : (r < 1.05f ? 3.0e38f : fmaf(2.004f, __logf(r), 1e-3f));
-    return t;
-}
-__device__ __forceinline__ bool box_hit(const BlockTest& t, float x_lo, float x_hi, float y_lo, float y_hi) {
-    const float x0 = x_lo - t.u, x1 = x_hi - t.u, y0 = y_lo - t.v, y1 = y_hi - t.v;      // the box about the centre
-    const float Xc = __builtin_amdgcn_fmed3f(0.f, x0, x1), Yc = __builtin_amdgcn_fmed3f(0.f, y0, y1);
-    const float Ys = __builtin_amdgcn_fmed3f(-t.bC * Xc, y0, y1);
-    const float Xs = __builtin_amdgcn_fmed3f(-t.bA * Yc, x0, x1);
-    const float a1 = t.A * Xc * Xc, c1 = t.C * Ys * Ys, a2 = t.A * Xs * Xs, c2 = t.C * Yc * Yc;
-    // rounding of the three terms (|2 B X Y| <= A X^2 + C Y^2 for a positive definite conic): 1e-6 of their size
-    const float q1 = fmaf(t.B2 * Xc, Ys, a1 + c1) - 1e-6f * (a1 + c1);
-    const float q2 = fmaf(t.B2 * Xs, Yc, a2 + c2) - 1e-6f * (a2 + c2);
-    return fminf(q1, q2) <= t.tau;
-}
-// the four bs x bs boxes at (px0, py0): bs = 8, the blocks of a tile; bs = 4, the quarters of a block
-__device__ __forceinline__ unsigned block_mask(const float4& p0, const float4& p1, float cutoff, int px0, int py0, int bs = 8) {
-    const BlockTest t = block_test(p0, p1, cutoff);
-    unsigned m = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const float x_lo = (float)(px0 + (w & 1) * bs), y_lo = (float)(py0 + (w >> 1) * bs);
-        if (box_hit(t, x_lo, x_lo + (float)(bs - 1), y_lo, y_lo + (float)(bs - 1))) m |= 1u << w;
-    }
-    return m;
-}
+// (block_test / box_hit / block_mask: gfl_math.hpp)
 
 #ifdef GFL_TRACE
 __device__ long long g_fwd_trace[16384 * 8];     // analysis build: per-tile timeline of the forward blend

@@ -41,7 +41,39 @@ __global__ void __launch_bounds__(256) selftest_cov2d_kernel(const float* __rest
     }
 }
 
+// block_mask of n records (u v A B | C o - - | - - cutoff -) against the four bs x bs boxes at (x0, y0), and, by brute
+// force over the boxes' pixels with the blend kernels' own alpha test, which boxes really hold a visible pixel
+__global__ void __launch_bounds__(256) selftest_block_mask_kernel(const float* __restrict__ rec, int n, int x0, int y0, int bs,
+                                                                  int32_t* __restrict__ mask, int32_t* __restrict__ truth) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)i * 12);
+    const float4 p0 = r4[0], p1 = r4[1], p2 = r4[2];
+    mask[i] = (int32_t)block_mask(p0, p1, p2.z, x0, y0, bs);
+    int t = 0;
+    for (int w = 0; w < 4; ++w)
+        for (int y = 0; y < bs; ++y)
+            for (int x = 0; x < bs; ++x) {
+#pragma clang fp contract(off)
+                const float fx = (float)(x0 + (w & 1) * bs + x), fy = (float)(y0 + (w >> 1) * bs + y);
+                const float dx = p0.x - fx, dy = p0.y - fy;
+                const float q = __builtin_fmaf(p0.z * dx, dx, (p1.x * dy) * dy);
+                const float power = __builtin_fmaf(-0.5f, q, -((p0.w * dx) * dy));
+                const float alpha = fminf(GFL_ALPHA_MAX, p1.y * __expf(fminf(power, 0.f)));
+                if (power <= 0.f && alpha >= GFL_ALPHA_MIN) t |= 1 << w;
+            }
+    truth[i] = t;
+}
+
 }  // namespace gfl
+
+extern "C" int gfl_selftest_block_mask(const float* rec, int n, int x0, int y0, int box, int32_t* mask, int32_t* truth,
+                                       gfl_stream_t stream) {
+    if (!rec || !mask || !truth || n < 0 || (box != 8 && box != 4)) return GFL_ERR_INVALID;
+    if (n == 0) return GFL_OK;
+    gfl::selftest_block_mask_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(rec, n, x0, y0, box, mask, truth);
+    return gfl::check_launch();
+}
 
 extern "C" int gfl_selftest_cov2d(const float* m, const float* cov, int n, float* out_valu, float* out_mfma,
                                   gfl_stream_t stream) {

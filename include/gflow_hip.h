@@ -336,6 +336,11 @@ int gfl_selftest_reduce10(const float* in, float* out_scatter, float* out_dpp, g
  * MFMA form (v_mfma_f32_4x4x1_16b_f32, sixteen splats per instruction) is what GFL_EWA_MFMA=1 puts into the fused
  * preprocess kernel; the VALU form is the default. */
 int gfl_selftest_cov2d(const float* m, const float* cov, int n, float* out_valu, float* out_mfma, gfl_stream_t stream);
+/* The blend kernels' culling test on its own: for n records (rows of 12 floats as in gfl_fit_state.rec; columns
+ * u v A B | C o . . | . . cutoff .) the 4-bit mask of the four box x box pixel boxes at (x0, y0) the splat can reach
+ * with alpha >= 1/255 (box = 8: the blocks of a tile, 4: the quarters of a block), and `truth`: the boxes that hold a
+ * visible pixel by brute force with the kernels' own alpha test.  The mask must contain the truth. */
+int gfl_selftest_block_mask(const float* rec, int n, int x0, int y0, int box, int32_t* mask, int32_t* truth, gfl_stream_t stream);
 
 /* sizeof(gfl_fit_state), sizeof(gfl_fit_hyper): lets an FFI binding verify its struct mirrors */
 int gfl_abi_sizes(int* sizeof_fit_state, int* sizeof_fit_hyper);

@@ -3,6 +3,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+DEV = "cuda"
 
 
 def test_wave_reduce_scatter10_sums_every_component():
@@ -44,3 +45,54 @@ def test_ewa_contraction_on_the_matrix_cores_equals_the_valu_form():
     assert ((a.cpu().double() - ref).abs() / scale).max() < 1e-5
     assert ((b.cpu().double() - ref).abs() / scale).max() < 1e-5
     assert ((a - b).abs().cpu().double() / scale).max() < 1e-6
+
+
+@pytest.mark.parametrize("box", [8, 4])
+def test_block_culling_never_drops_a_visible_pixel(box):
+    """The blend kernels skip a (splat, pixel box) unit when `block_mask` says the splat cannot reach the box with
+    alpha >= 1/255 (an ellipse-vs-box test with a safety margin).  Against brute force over the boxes' pixels with the
+    kernels' own alpha arithmetic: the mask must CONTAIN every box that holds a visible pixel, for round, elongated,
+    rotated, huge, tiny, barely visible and far-away splats; and it should not be much larger (the bounding-disc test
+    of round 1 let 16 % empty units through on the bench scene)."""
+    from gflow_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(box)
+    n = 200_000
+    # covariance = R diag(s1^2, s2^2) R^T + 0.3 I (the EWA blur), conic = its inverse
+    s1 = torch.exp(torch.empty(n).uniform_(-2.5, 4.5, generator=g))        # 0.08 .. 90 px
+    ratio = torch.exp(torch.empty(n).uniform_(0.0, 4.0, generator=g))      # up to 55 : 1
+    s2 = s1 / ratio
+    th = torch.empty(n).uniform_(0, 3.14159, generator=g)
+    c, s = torch.cos(th), torch.sin(th)
+    a = c * c * s1 ** 2 + s * s * s2 ** 2 + 0.3
+    b = c * s * (s1 ** 2 - s2 ** 2)
+    d = s * s * s1 ** 2 + c * c * s2 ** 2 + 0.3
+    det = a * d - b * b
+    A, B, C = d / det, -b / det, a / det
+    o = torch.empty(n).uniform_(0.0, 1.0, generator=g)
+    o[: n // 10] = torch.empty(n // 10).uniform_(0.8 / 255, 3.0 / 255, generator=g)   # around the visibility threshold
+    x0, y0 = 160, 96
+    u = x0 + torch.empty(n).uniform_(-40, 56, generator=g)
+    v = y0 + torch.empty(n).uniform_(-40, 56, generator=g)
+    far = slice(n // 2, n // 2 + n // 10)                                   # centres hundreds of pixels away, long axis anywhere
+    u[far] = x0 + torch.empty(n // 10).uniform_(-600, 600, generator=g)
+    v[far] = y0 + torch.empty(n // 10).uniform_(-600, 600, generator=g)
+    lam = 0.5 * (a + d) + torch.sqrt(torch.clamp(0.25 * (a - d) ** 2 + b * b, min=0))
+    r = 255.0 * o
+    cutoff = torch.where(o < 1 / 255, torch.full_like(o, -1.0),
+                         torch.where(r < 1.05, torch.full_like(o, 3e38), 2.0 * torch.log(r) * lam * 1.002 + 0.01))
+    rec = torch.zeros(n, 12)
+    rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3], rec[:, 4], rec[:, 5], rec[:, 10] = u, v, A, B, C, o, cutoff
+    rec_d = rec.to(DEV)
+    mask = torch.zeros(n, dtype=torch.int32, device=DEV)
+    truth = torch.zeros(n, dtype=torch.int32, device=DEV)
+    L.check(lib.gfl_selftest_block_mask(L.ptr(rec_d), n, x0, y0, box, L.ptr(mask), L.ptr(truth), L.stream()), "selftest")
+    torch.cuda.synchronize()
+    mask, truth = mask.cpu(), truth.cpu()
+    missed = truth & ~mask
+    assert int((missed != 0).sum()) == 0, f"{int((missed != 0).sum())} splats lose a visible box; first: {rec[missed != 0][:3]}"
+    bits = lambda t: sum(((t >> k) & 1).sum().item() for k in range(4))
+    let_through, needed = bits(mask), bits(truth)
+    assert needed > 50_000                                                   # the sample does exercise visible boxes
+    print(f"box {box}: {let_through} boxes let through for {needed} with a visible pixel ({let_through / needed:.3f}x)")
+    assert let_through <= 1.06 * needed, (let_through, needed)               # measured 1.02x (continuous box, margins)
