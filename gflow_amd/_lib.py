@@ -62,6 +62,7 @@ SIGNATURES = {
     "gfl_render_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "gfl_fit_prepare_targets": (c_int, [_P, _P]),
     "gfl_fit_schedule_info": (c_int, [_P, _P, _P, _P, _P]),
+    "gfl_fit_schedule_info_fwd": (c_int, [_P, _P, _P, _P, _P]),
     "gfl_selftest_reduce10": (c_int, [_P, _P, _P, _P]),
     "gfl_selftest_cov2d": (c_int, [_P, _P, c_int, _P, _P, _P]),
     "gfl_selftest_block_mask": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),

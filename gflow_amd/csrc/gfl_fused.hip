@@ -289,13 +289,13 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* _
                                                                   int32_t* __restrict__ tile_offsets, int K_cap,
                                                                   unsigned long long* __restrict__ keys,
                                                                   int32_t* __restrict__ overflow,
-                                                                  Sched sched) {
+                                                                  Sched sched_bwd, Sched sched_fwd) {
     extern __shared__ int32_t cursor[];
     __shared__ int32_t wsum[BIN_BLOCK / 64];
     const int T = gx * gy;
-    if (blockIdx.x == gridDim.x - 1) {
-        // one extra workgroup (the launch leaves CUs idle) builds the blend kernels' tile queues
-        schedule_tiles(tile_counts, T, sched, cursor, wsum);
+    if (blockIdx.x >= gridDim.x - 2) {
+        // two extra workgroups (the launch leaves CUs idle) build the blend kernels' tile queues
+        schedule_tiles(tile_counts, T, blockIdx.x == gridDim.x - 1 ? sched_bwd : sched_fwd, cursor, wsum);
         return;
     }
     const int32_t* base_row = hist_g + (size_t)blockIdx.x * T;
@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* _
 constexpr int BLEND_WG_PER_CU = 8;
 constexpr int FWD_WG_PER_CU = 6;       // the forward blend trades two workgroups per CU for 72 VGPRs (FWD_UNITS)
 constexpr int FWD_UNITS = 4;
-constexpr int FWD_SPLIT_MIN = 512;     // forward: a queue's first tile is walked as four blocks on four CUs when its list is longer
+constexpr int FWD_SPLIT_MIN = 256;     // forward: a queue's first tile is walked as four blocks on four CUs when its list is longer
 constexpr int FB = 256;   // staged splats per batch (forward)
 constexpr int FBB = 192;  // backward: 18.6 KB of LDS per workgroup -> 8 workgroups per CU (the tile queues of
                           // gfl_sched.hpp assume that all workgroups of a blend launch are resident)
@@ -420,6 +420,15 @@ __device__ __forceinline__ float3 cmap_nonzero_lookup(float v, const unsigned* _
     return make_float3(lut[3 * idx], lut[3 * idx + 1], lut[3 * idx + 2]);
 }
 
+// sum over the four 16-lane rows of the wave, in every lane
+__device__ __forceinline__ float rows_sum(float x) {
+    float lo = x, hi = x;
+    permlane32_swap(lo, hi);                 // rows {0, 1, 0, 1} / {2, 3, 2, 3}
+    float y0 = lo + hi, y1 = y0;
+    permlane16_swap(y0, y1);                 // rows {0+2} x 4 / {1+3} x 4
+    return y0 + y1;
+}
+
 __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(const float* __restrict__ rec,
                                                               const int32_t* __restrict__ ids,
                                                               const int32_t* __restrict__ tile_range, float bg, int W,
@@ -428,7 +437,9 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                                                               int32_t* __restrict__ n_contrib, TileQueue queue,
                                                               float* __restrict__ ckpt, int mode,
                                                               const unsigned* __restrict__ cmap_mm,
-                                                              const float* __restrict__ cmap_lut, int split_min) {
+                                                              const float* __restrict__ cmap_lut, int split_min,
+                                                              int32_t* __restrict__ tile_work,
+                                                              const int32_t* __restrict__ first_slot) {
     // mode 0: the records as they are.  The two snapshot-only images of render.py:76-106 are composites of the SAME
     // lists with other per-splat values, made while a record is staged: mode 1 = colour := turbo map of the splat's
     // depth (apply_float_colormap(non_zero=True), range in cmap_mm), mode 2 = unit blob at the centre (conic 1 0 1,
@@ -469,16 +480,22 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     const int org_x = tx * GFL_TILE + (blk < 0 ? 0 : (blk & 1) * 8), org_y = ty * GFL_TILE + (blk < 0 ? 0 : (blk >> 1) * 8);
     const int px0w = org_x + (wave & 1) * bs, py0w = org_y + (wave >> 1) * bs;
     const int px = px0w + (blk < 0 ? (lane & 7) : (lane & 3)), py = py0w + (blk < 0 ? (lane >> 3) : ((lane >> 2) & 3));
-    const bool inside = px < W && py < H && (blk < 0 || lane < 16);
+    // (a block's wave: all four 16-lane rows carry the quarter's sixteen pixels -- four splats per step below --
+    //  and row 0 writes)
+    const bool inside = px < W && py < H;
+    const bool writer = blk < 0 || lane < 16;
     const float fx = (float)px, fy = (float)py;
-    // leave the per-pixel state at the split positions for the backward pass (which walks this tile in segments),
-    // at the place of the thread that owns the pixel in the whole-tile layout
-    const bool heavy = first_tile;
+    // leave the per-pixel state at the split positions for the backward pass, which walks the first tile of each of
+    // ITS queues in segments (first_slot: that queue, -1 for every other tile), at the place of the thread that owns the
+    // pixel in the whole-tile layout
+    const int slot = first_slot[tile];
+    const bool heavy = slot >= 0;
     const int parts = heavy ? heavy_parts(end - start) : 1;
     const int seg = heavy_seg(end - start, parts);
     const bool ck_lane = blk < 0 || lane < 16;
     const int ftid = blk < 0 ? tid : blk * 64 + ((py - org_y) << 3) + (px - org_x);
-    float* ck = ckpt + (size_t)owner * (HEAVY_PARTS - 1) * 5 * 256 + ftid;
+    float* ck = ckpt + (size_t)max(slot, 0) * (HEAVY_PARTS - 1) * 5 * 256 + ftid;
+    int units = 0;                                   // work feedback for the forward schedule (wave-uniform)
     int ck_next = 1;                                 // next boundary to checkpoint: position ck_next * seg
 #ifdef GFL_TRACE
     const long long trace_t0 = wall_clock64();
@@ -516,7 +533,9 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
             if (__all(Tw == 0.f)) break;
             if (ck_next < parts && base - start + c0 == ck_next * seg) {
                 float* c5 = ck + (size_t)(ck_next - 1) * 5 * 256;
-                if (ck_lane) { c5[0] = T; c5[256] = a0; c5[512] = a1; c5[768] = a2; c5[1024] = a3; }
+                float c0_ = a0, c1_ = a1, c2_ = a2, c3_ = a3;
+                if (blk >= 0) { c0_ = rows_sum(a0); c1_ = rows_sum(a1); c2_ = rows_sum(a2); c3_ = rows_sum(a3); }
+                if (ck_lane) { c5[0] = T; c5[256] = c0_; c5[512] = c1_; c5[768] = c2_; c5[1024] = c3_; }
                 ++ck_next;
             }
             const int slot = c0 + lane;
@@ -551,6 +570,49 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                 }
             }
             unsigned long long bits = __ballot(hit);
+            if (blk >= 0) {
+                // A block's wave: FOUR hit splats per step, one per 16-lane row, each row the quarter's sixteen pixels.
+                // A row evaluates its splat's alpha; two permlane swaps hand every lane the four alphas of its pixel, and
+                // every row runs the SAME transmittance chain over them in list order (T, the stop rule and the last
+                // contributor are bit-identical to the one-splat-at-a-time walk); a row adds only its own splat's
+                // colour, the rows' sums are added up at the checkpoints and at the end.  ~22 instead of ~45 issue
+                // slots per (splat, quarter) unit: the chains of the longest tiles set the launch time.
+                const int row = lane >> 4;
+                while (bits) {
+                    units += min((int)__popcll(bits), 4);
+                    int j[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        j[u] = bits ? c0 + (int)__builtin_ctzll(bits) : FB;
+                        bits &= bits - 1;
+                    }
+                    const int js = row == 0 ? j[0] : (row == 1 ? j[1] : (row == 2 ? j[2] : j[3]));
+                    const float4 q0 = recs[js].p0, q1 = recs[js].p1, q2 = recs[js].p2;
+                    float al, G;
+                    const bool val = splat_alpha2(q0, q1, fx, fy, al, G);
+                    const float a_mine = val ? al : 0.f;
+                    float lo = a_mine, hi = a_mine;
+                    permlane32_swap(lo, hi);                 // lo = rows {0, 1, 0, 1}, hi = rows {2, 3, 2, 3}
+                    float av[4] = {lo, lo, hi, hi};
+                    permlane16_swap(av[0], av[1]);           // row 0 / row 1 in every row
+                    permlane16_swap(av[2], av[3]);
+                    float w_mine = 0.f;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float a = av[u];
+                        const float test_T = Tw * (1.f - a);
+                        const bool stop = test_T < GFL_T_MIN;
+                        const float w = stop ? 0.f : a * Tw;
+                        w_mine = row == u ? w : w_mine;
+                        T = stop ? T : test_T;
+                        Tw = stop ? 0.f : test_T;
+                        last = (a > 0.f && !stop) ? base - start + j[u] + 1 : last;
+                    }
+                    a0 = fmaf(q1.z, w_mine, a0); a1 = fmaf(q1.w, w_mine, a1); a2 = fmaf(q2.x, w_mine, a2); a3 = fmaf(q2.y, w_mine, a3);
+                    if (__all(Tw == 0.f)) break;
+                }
+                continue;
+            }
             // FWD_UNITS (4) hit splats per trip: their records are fetched and their alphas
             // evaluated together; only the T recurrence is serial.  The body is branch-free: a lane
             // that skips a splat contributes w = 0.  A wave issues one instruction at a time, so the
@@ -560,6 +622,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
             // 64-VGPR budget of eight workgroups spill and gain nothing; requesting the next
             // records a trip ahead was slower: LDS returns in order, the wait covers them too).
             while (bits) {
+                units += min((int)__popcll(bits), FWD_UNITS);
                 int j[FWD_UNITS];            // missing splats of the last trip: the null record
 #pragma unroll
                 for (int u = 0; u < FWD_UNITS; ++u) {
@@ -595,7 +658,8 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
             }
         }
     }
-    if (inside) {
+    if (blk >= 0) { a0 = rows_sum(a0); a1 = rows_sum(a1); a2 = rows_sum(a2); a3 = rows_sum(a3); }
+    if (inside && writer) {
         const size_t pix = (size_t)py * W + px, plane = (size_t)H * W;
         out[pix] = fmaf(T, bg, a0);
         out[plane + pix] = fmaf(T, bg, a1);
@@ -604,6 +668,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
         final_T[pix] = T;
         n_contrib[pix] = last;
     }
+    if (mode == 0 && lane == 0) atomicAdd(&tile_work[tile], units + 1);
     // the wave stopped before the split position: every pixel's state is frozen, final = checkpoint
     for (; ck_next < parts; ++ck_next) {
         float* c5 = ck + (size_t)(ck_next - 1) * 5 * 256;
@@ -1351,6 +1416,9 @@ size_t gfl_fit_workspace_bytes(int cap, int K_cap, int W, int H) {
            + up256((size_t)SCHED_MAX_QUEUES * sched_queue_capacity((int)T, 64) * sizeof(int32_t))   // queue items
            + 2 * up256(2 * SCHED_MAX_QUEUES * sizeof(int32_t))                      // queue lengths, pull counters
            + up256((size_t)SCHED_MAX_QUEUES * (HEAVY_PARTS - 1) * 5 * 256 * sizeof(float))                  // heavy-tile checkpoints
+           + 2 * up256(T * sizeof(int32_t))                                         // forward schedule: work feedback; first_slot
+           + up256((size_t)SCHED_MAX_QUEUES * sched_queue_capacity((int)T, 64) * sizeof(int32_t))   // ... queue items
+           + up256(2 * SCHED_MAX_QUEUES * sizeof(int32_t))                          // ... queue lengths
            + up256(gfl_loss_workspace_bytes(W, H)) + 256
            + up256((size_t)6 * W * H * sizeof(float))                                  // SSIM statistics of the target
            + up256((size_t)fit_nblk(cap > 0 ? cap : 1) * sizeof(int32_t));             // rows of the scale term per block
@@ -1365,7 +1433,8 @@ struct FitWs {
     int32_t* slot_inv;
     int32_t* slot_pool;
     int32_t* pool_counter;
-    Sched sched;             // tile queues of the blend kernels; sched.work persists between calls
+    Sched sched;             // tile queues of the backward blend; sched.work persists between calls
+    Sched sched_fwd;         // ... and of the forward blend (its own work feedback)
     float* ckpt;             // [queue][boundary][T a0 a1 a2 a3][256 pixels] forward state at the heavy tile's segment boundaries
     void* loss_ws;
     size_t loss_ws_bytes;
@@ -1405,6 +1474,18 @@ static FitWs carve(const gfl_fit_state* st) {
     p += up256((size_t)SCHED_MAX_QUEUES * (HEAVY_PARTS - 1) * 5 * 256 * sizeof(float));
     w.sched.nq = blend_queues();
     w.sched.cap_q = sched_queue_capacity((int)T, w.sched.nq);
+    w.sched.split_min = 0;
+    w.sched_fwd = w.sched;
+    w.sched_fwd.work = (int32_t*)p;
+    p += up256(T * sizeof(int32_t));
+    w.sched_fwd.list = (int32_t*)p;
+    p += up256((size_t)SCHED_MAX_QUEUES * sched_queue_capacity((int)T, 64) * sizeof(int32_t));
+    w.sched_fwd.count = (int32_t*)p;
+    p += up256(2 * SCHED_MAX_QUEUES * sizeof(int32_t));
+    w.sched.first_slot = (int32_t*)p;
+    p += up256(T * sizeof(int32_t));
+    w.sched_fwd.first_slot = nullptr;
+    w.sched_fwd.split_min = fwd_split_min();
     w.loss_ws = p;
     w.loss_ws_bytes = up256(gfl_loss_workspace_bytes(st->W, st->H));
     w.gt_stats = (float*)((char*)p + w.loss_ws_bytes + 256);
@@ -1451,8 +1532,8 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
     }
     {
         StageScope p(ST_SCATTER, s);
-        fused_scatter_kernel<<<nblk + 1, BIN_BLOCK, lds, s>>>(st->rec, st->N, gx, gy, w.hist, w.tile_counts,
-                                                              st->tile_offsets, st->K_cap, w.keys, st->overflow, w.sched);
+        fused_scatter_kernel<<<nblk + 2, BIN_BLOCK, lds, s>>>(st->rec, st->N, gx, gy, w.hist, w.tile_counts,
+                                                              st->tile_offsets, st->K_cap, w.keys, st->overflow, w.sched, w.sched_fwd);
     }
     {
         StageScope p(ST_TILE_SORT, s);
@@ -1462,10 +1543,10 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
     if (rc) return rc;
     {
         StageScope p(ST_BLEND_FWD, s);
-        const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters, w.sched.nq, w.sched.cap_q};
+        const TileQueue q = {w.sched_fwd.list, w.sched_fwd.count, w.sched.counters, w.sched.nq, w.sched.cap_q};
         fused_blend_fwd_kernel<<<blend_grid(T, FWD_WG_PER_CU), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx,
                                                              st->render, st->final_T, st->n_contrib, q, w.ckpt, 0, nullptr,
-                                                             nullptr, fwd_split_min());
+                                                             nullptr, fwd_split_min(), w.sched_fwd.work, w.sched.first_slot);
         if (st->foot_flags) {
             // keep is in/out here: the footprint of this iteration's flagged splats is cleared from it, so it
             // carries the running union over the iterations of the stage exactly like the reference, which
@@ -1552,14 +1633,15 @@ int gfl_fit_snapshot(const gfl_fit_state* st, const gfl_fit_hyper* hp, const flo
     if (rc) return rc;
     // (few blocks: a thousand waves hitting the two result words with atomics took 23 us)
     if (st->N > 0) rec_depth_range_kernel<<<min((st->N + 255) / 256, 32), 256, 0, s>>>(st->rec, st->N, mm);
-    const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters, w.sched.nq, w.sched.cap_q};
+    const TileQueue q = {w.sched_fwd.list, w.sched_fwd.count, w.sched.counters, w.sched.nq, w.sched.cap_q};
     for (int mode = 1; mode <= 2; ++mode) {
         // the forward launch of the iteration (and the first pass here) used up the queues' pull counters
         rc = check(hipMemsetAsync(w.sched.counters, 0, (size_t)w.sched.nq * sizeof(int32_t), s));
         if (rc) return rc;
         fused_blend_fwd_kernel<<<blend_grid(T, FWD_WG_PER_CU), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H,
                                                                             gx, mode == 1 ? img_dc : img_c, fT, nc, q, w.ckpt,
-                                                                            mode, mm, lut, fwd_split_min());
+                                                                            mode, mm, lut, fwd_split_min(), w.sched_fwd.work,
+                                                                            w.sched.first_slot);
     }
     snapshot_u8_kernel<<<(P + 255) / 256, 256, 0, s>>>(st->render, img_dc, img_c, P, out_u8);
     return check_launch();
@@ -1671,6 +1753,18 @@ int gfl_fit_schedule_info(const gfl_fit_state* st, int* n_queues, int* queue_cap
     *queue_capacity = w.sched.cap_q;
     *d_lists = w.sched.list;
     *d_counts = w.sched.count;
+    return GFL_OK;
+}
+
+int gfl_fit_schedule_info_fwd(const gfl_fit_state* st, int* n_queues, int* queue_capacity, const int32_t** d_lists,
+                              const int32_t** d_counts) {
+    if (!st || !n_queues || !queue_capacity || !d_lists || !d_counts || !st->workspace) return GFL_ERR_INVALID;
+    if (st->workspace_bytes < gfl_fit_workspace_bytes(st->cap, st->K_cap, st->W, st->H)) return GFL_ERR_WORKSPACE;
+    const FitWs w = carve(st);
+    *n_queues = w.sched_fwd.nq;
+    *queue_capacity = w.sched_fwd.cap_q;
+    *d_lists = w.sched_fwd.list;
+    *d_counts = w.sched_fwd.count;
     return GFL_OK;
 }
 

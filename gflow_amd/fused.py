@@ -300,12 +300,14 @@ class FitEngine:
     def K(self):
         return int(self.tile_offsets[self.T].item())
 
-    def schedule(self):
-        """The tile queues of the last forward as a list of 1-D int64 tensors (tile ids per queue)."""
+    def schedule(self, forward=False):
+        """The tile queues of the last forward as a list of 1-D int64 tensors (tile ids per queue): the backward
+        blend's, or (``forward=True``) the forward blend's."""
         nq, cap = ctypes.c_int(), ctypes.c_int()
         lists, counts = ctypes.c_void_p(), ctypes.c_void_p()
-        L.check(self.lib.gfl_fit_schedule_info(ctypes.byref(self.state()), ctypes.byref(nq), ctypes.byref(cap),
-                                               ctypes.byref(lists), ctypes.byref(counts)), "fit schedule info")
+        fn = self.lib.gfl_fit_schedule_info_fwd if forward else self.lib.gfl_fit_schedule_info
+        L.check(fn(ctypes.byref(self.state()), ctypes.byref(nq), ctypes.byref(cap),
+                   ctypes.byref(lists), ctypes.byref(counts)), "fit schedule info")
         off_l = lists.value - self.workspace.data_ptr()
         off_c = counts.value - self.workspace.data_ptr()
         torch.cuda.synchronize(self.dev)

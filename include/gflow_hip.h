@@ -306,11 +306,14 @@ int gfl_fit_snapshot(const gfl_fit_state* st, const gfl_fit_hyper* hp, const flo
 /* once per ground-truth image / keep mask: SSIM statistics of the target into the workspace; set
  * st->gt_cached = 1 afterwards (0 is always valid: everything is then recomputed per iteration) */
 int gfl_fit_prepare_targets(const gfl_fit_state* st, gfl_stream_t stream);
-/* where the last gfl_fit_forward's tile schedule lives in the workspace (device pointers): queue c
+/* where the last gfl_fit_forward's tile schedules live in the workspace (device pointers): queue c
  * holds d_counts[c] items d_lists[c * queue_capacity + k] = tile | priority << 28.  Every tile of the
- * frame appears in exactly one queue.  For tests and tools; nothing needs it to run. */
+ * frame appears in exactly one queue.  The backward blend's queues (weights: the units it counted per tile in the last
+ * iteration) and, _fwd, the forward blend's (its own counts).  For tests and tools; nothing needs them to run. */
 int gfl_fit_schedule_info(const gfl_fit_state* st, int* n_queues, int* queue_capacity, const int32_t** d_lists,
                           const int32_t** d_counts);
+int gfl_fit_schedule_info_fwd(const gfl_fit_state* st, int* n_queues, int* queue_capacity, const int32_t** d_lists,
+                              const int32_t** d_counts);
 /* the per-tile sort of gfl_bin_sort alone (keys already scattered into segments) */
 int gfl_tile_sort_only(const int32_t* tile_offsets, int T, int K_cap, void* keys, int32_t* ids,
                        int32_t* tile_range, gfl_stream_t stream);

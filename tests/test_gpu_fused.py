@@ -497,10 +497,11 @@ def test_tile_schedule_is_a_partition_of_the_tiles(H, W, N):
     T = eng.T
     for it in range(3):
         eng.iteration()
-        queues = eng.schedule()
-        tiles = torch.cat(queues)
-        assert tiles.numel() == T, f"iteration {it}: {tiles.numel()} scheduled items for {T} tiles"
-        assert torch.equal(torch.sort(tiles).values, torch.arange(T)), f"iteration {it}: not a partition"
+        for fwd in (True, False):                    # the forward and the backward blend have their own queues
+            queues = eng.schedule(forward=fwd)
+            tiles = torch.cat(queues)
+            assert tiles.numel() == T, f"iteration {it}: {tiles.numel()} scheduled items for {T} tiles"
+            assert torch.equal(torch.sort(tiles).values, torch.arange(T)), f"iteration {it}: not a partition"
     # with feedback the queues carry similar loads (weights = list lengths as a proxy here)
     if T >= 1024:
         lens = (eng.tile_range[:, 1] - eng.tile_range[:, 0]).cpu().float()
