@@ -117,10 +117,18 @@ def _copy_stream(dev):
 
 
 class _Stepper:
-    """State of one ``train`` call; calling it runs one iteration."""
+    """State of one ``train`` call; calling it runs one iteration, ``run(n)`` the next n."""
 
     def __call__(self):
         self.fn()
+
+    def run(self, n):
+        batch = getattr(self, "fn_batch", None)
+        if batch is None:
+            for _ in range(n):
+                self.fn()
+        else:
+            batch(n)
 
 
 def _within(uv, W, H):
@@ -584,7 +592,40 @@ class SimpleGaussian:
                 hp.step_camera = 0
             st.iteration += 1
 
+        def is_plain(i):
+            """nothing but the library's iteration happens in iteration i (no snapshot, log entry or densification)"""
+            if snapshot_interval and i % snapshot_interval == 0:
+                return False
+            if log_interval and i % log_interval == 0:
+                return False
+            if not camera_only and i == 0 and later_frame and mask is not None:
+                return False
+            if (not camera_only and densify_interval and (i + 1) % densify_interval == 0
+                    and (i + 1) // densify_interval <= densify_times):
+                return False
+            return True
+
+        def run(n):
+            """the next n iterations; runs of plain ones go into ONE graph launch, two or four at a time (6-7 us pass
+            between two graph launches, tools/graph_gap.py)"""
+            end = st.iteration + n
+            while st.iteration < end:
+                k = 0
+                while k < 4 and st.iteration + k < end and is_plain(st.iteration + k):
+                    k += 1
+                if k < 2 or not self.use_graph:
+                    one_iteration()
+                    continue
+                b = 4 if k == 4 else 2
+                n_rendered = eng.N
+                eng.iteration(use_graph=True, count=b)
+                self.rasterisations_done += (2 * b) if tentative else b
+                self.iterations_done += b
+                st.uv, st.depth, st.last_render = eng.rec[:n_rendered, 0:2], eng.rec[:n_rendered, 9:10], eng.render
+                st.iteration += b
+
         st.fn = one_iteration
+        st.fn_batch = run
         return st
 
     def train(self, iterations=500, save_ckpt=False, ckpt_name="ckpt", snapshot_interval=10, **kw):
@@ -594,8 +635,7 @@ class SimpleGaussian:
         hold (H,W,3) uint8 snapshots taken every ``snapshot_interval`` iterations (0 = none)."""
         W, H, dev = self.W, self.H, self.device
         st = self.make_stepper(iterations=iterations, snapshot_interval=snapshot_interval, **kw)
-        for _ in range(iterations):
-            st()
+        st.run(iterations)
         self.train_log = st.log
         if self.fused and self.engine is not None:
             self.engine.check_overflow()          # one host read per frame: dropped pairs must not go unnoticed
