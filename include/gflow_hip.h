@@ -15,7 +15,9 @@
  *     workspaces, all work is enqueued on `stream` (graph-capturable).  Process-wide state
  *     is limited to: the thread-local last HIP error (gfl_last_hip_error), the cached
  *     CU count of the device, the optional stage profiler (gfl_profile_*) and two
- *     environment switches read once (GFL_EWA_MFMA; nothing else changes results);
+ *     environment switches read once: GFL_EWA_MFMA=1 (J Sigma J^T on the matrix cores; same results to rounding) and
+ *     GFL_FWD_SPLIT_MIN=<n> (list length from which the forward blend walks a long tile on four CUs; scheduling only,
+ *     results do not depend on it);
  *   - return value: GFL_OK or a negative gfl_status; HIP launch errors are
  *     returned as GFL_ERR_HIP and the hipError_t is kept in gfl_last_hip_error();
  *   - *_bwd functions OVERWRITE their gradient outputs (they zero what they
