@@ -467,7 +467,8 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
         if (item.part < 0) break;                    // the queue is empty
         if (item.part == 0) continue;                // ... but its items 1..3 may have to help other queues
     }
-    // The first (heaviest) tile of every queue comes as four items, like in the backward pass.  When its list is
+    // The first (heaviest) tile of every queue comes as several items (the backward pass walks it in up to eight
+    // segments; the forward pass uses the first four).  When its list is
     // long, the forward pass walks it as four 8x8 BLOCKS: item 0 on the tile's own CU, items 1..3 of THIS queue
     // as helpers for the first tiles of three OTHER queues (side by side on one CU the four would share its SIMDs,
     // and a long tile's waves are bound by their own issue rate: ~8 cycles per instruction alone, ~14 with three
@@ -475,6 +476,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     // reached by less than half of the splats that reach the block, and the launch lasts as long as the longest chain of
     // one wave (real fits pile ~1 000 splats into single tiles: their waves finished at 50-73 us, the mean CU at 29 us).
     int tile = item.tile, owner = item.queue;
+    if (item.part >= 4) continue;                    // (the backward pass has more segments than the forward pass blocks)
     if (item.part > 0) {
         owner = (item.queue + item.part * (queue.nq / 4)) % queue.nq;
         tile = queue.count[owner] > 0 ? (queue.list[(size_t)owner * queue.cap_q] & 0x0fffffff) : -1;

@@ -23,7 +23,7 @@
 //             per round instead of 1620 sequential steps; a queue that already holds a 1000-unit
 //             tile sits out until the others have caught up);
 //   first     the first tile of every queue is one of the NQ heaviest.  Its waves raise their
-//             instruction priority, and in the backward pass it is walked as up to four segments
+//             instruction priority, and in the backward pass it is walked as up to eight segments
 //             of its list by as many workgroups of the CU side by side (the forward pass leaves
 //             a per-pixel checkpoint (T, C) at every segment boundary; a segment starts from
 //             T and S = sum_c g_c (out_c - C_c)).
@@ -214,9 +214,9 @@ struct TileItem {
 // The heaviest tile of a queue is walked in up to HEAVY_PARTS segments of its list by as many
 // workgroups of the CU (backward); the forward pass leaves a checkpoint at every segment boundary.
 // heavy_parts: number of segments; heavy_seg: their length, a multiple of 64 (the last is shorter).
-constexpr int HEAVY_PARTS = 4;
+constexpr int HEAVY_PARTS = 8;
 __device__ __forceinline__ int heavy_parts(int total) {
-    return total <= 128 ? 1 : min(HEAVY_PARTS, max(2, (total + 319) / 320));
+    return total <= 128 ? 1 : min(HEAVY_PARTS, max(2, (total + 159) / 160));
 }
 __device__ __forceinline__ int heavy_seg(int total, int parts) { return ((total + parts - 1) / parts + 63) & ~63; }
 
