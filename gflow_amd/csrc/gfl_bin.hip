@@ -223,7 +223,7 @@ int gfl_bin_sort(const float* uv, const float* depth, const int32_t* radius, con
             bin_scatter_kernel<false><<<(N + 255) / 256, 256, 0, s>>>(uv, depth, radius, cutoff, N, gx, gy, tile_offsets,
                                                                       cursor, K_cap, keys, overflow);
     }
-    bin_tile_sort_kernel<<<T, 256, 0, s>>>(tile_offsets, K_cap, keys, ids, tile_range, nullptr, nullptr, nullptr, gx, gy);
+    bin_tile_sort_kernel<<<T, SORT_THREADS, 0, s>>>(tile_offsets, K_cap, keys, ids, tile_range, nullptr, nullptr, nullptr, gx, gy);
     return check_launch();
 }
 
@@ -232,7 +232,7 @@ int gfl_tile_sort_only(const int32_t* tile_offsets, int T, int K_cap, void* keys
     if (T <= 0 || K_cap < 0 || !tile_offsets || !keys || !tile_range || (K_cap > 0 && !ids)) return GFL_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* k64 = (unsigned long long*)keys;
-    bin_tile_sort_kernel<<<T, 256, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, nullptr, nullptr, nullptr, 1, T);
+    bin_tile_sort_kernel<<<T, SORT_THREADS, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, nullptr, nullptr, nullptr, 1, T);
     return check_launch();
 }
 
@@ -245,7 +245,7 @@ int gfl_tile_sort_with_slots(const int32_t* tile_offsets, int W, int H, int K_ca
     const int gx = (W + GFL_TILE - 1) / GFL_TILE, gy = (H + GFL_TILE - 1) / GFL_TILE;
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* k64 = (unsigned long long*)keys;
-    bin_tile_sort_kernel<<<gx * gy, 256, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, rec, slot_inv, slot_pool, gx, gy);
+    bin_tile_sort_kernel<<<gx * gy, SORT_THREADS, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, rec, slot_inv, slot_pool, gx, gy);
     return check_launch();
 }
 

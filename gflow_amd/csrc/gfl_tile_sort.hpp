@@ -1,11 +1,15 @@
 // Per-tile sort of the 64-bit (depth bits << 32 | splat id) keys -- included by gfl_bin.hip.
 //
-// One workgroup of 256 lanes per tile, keys in REGISTERS: a lane holds E = 1, 2, 4 or 8
-// consecutive keys (E chosen per tile from its length, up to 2048 keys), padded with +inf.
+// One workgroup of up to SORT_THREADS (512) lanes per tile, keys in REGISTERS: a lane holds E = 1, 2, 4 or 8
+// consecutive keys (E chosen per tile from its length, up to 4096 keys), padded with +inf; the waves a tile does
+// not need (four of the eight for the typical 140-key list) leave before the first barrier.  Round 1 ran 256 lanes:
+// a 1 200-key tile then sat on four lone waves with 8 keys per lane (24 us, the launch's duration on real fits);
+// with eight waves it has 4 keys per lane and two waves per SIMD: 24 -> 18 us there, 13.2 -> 12.5 us on the bench scene
+// (sixteen waves: 21 and 17 us -- every tile then pays for the wider workgroup).
 // Bitonic network; a compare-exchange partner is
 //   - in the same lane            when the stride is below E        (register swap),
 //   - in the same wave            when it is below 64 E             (DPP / permlane swap, no LDS),
-//   - in another wave otherwise   (three steps per sort)            (2 KB LDS exchange buffer).
+//   - in another wave otherwise   (a few steps per sort)            (4 KB LDS exchange buffer).
 // A first version sorted in LDS with a barrier per pass: a single 300-key tile then cost ~25 us
 // of barrier latency and set the duration of the whole launch.
 #pragma once
@@ -137,19 +141,17 @@ __device__ __forceinline__ void sort_tile_and_emit(unsigned long long* __restric
     }
 }
 
-// Register budget: 64 VGPRs, so that 8 workgroups fit a CU and all 1620 tiles of a 480p frame are
-// resident at once.  With a 16-keys-per-lane variant in the same kernel the compiler needed 95
-// VGPRs (5 workgroups per CU); up to 8 keys per lane (2048 keys: real fits reach ~1200 where
-// densification piles new splats into one tile) it needs 50.  Longer lists are sorted in global
-// memory.
-__global__ void __launch_bounds__(256, 8) bin_tile_sort_kernel(const int32_t* __restrict__ offsets, int K_cap,
-                                                               unsigned long long* __restrict__ keys,
-                                                               int32_t* __restrict__ ids,
-                                                               int32_t* __restrict__ tile_range,
-                                                               const float* __restrict__ slot_rec,
-                                                               int32_t* __restrict__ slot_inv,
-                                                               int32_t* __restrict__ slot_pool, int gx, int gy) {
-    __shared__ unsigned long long sk[256];               // cross-wave exchange buffer
+// Register budget: 64 VGPRs (eight waves per SIMD).  With a 16-keys-per-lane variant in the same kernel the compiler
+// needed 95 VGPRs; up to 8 keys per lane it needs 50.  Lists beyond 4096 keys are sorted in global memory.
+constexpr int SORT_THREADS = 512;
+__global__ void __launch_bounds__(SORT_THREADS, 8) bin_tile_sort_kernel(const int32_t* __restrict__ offsets, int K_cap,
+                                                                        unsigned long long* __restrict__ keys,
+                                                                        int32_t* __restrict__ ids,
+                                                                        int32_t* __restrict__ tile_range,
+                                                                        const float* __restrict__ slot_rec,
+                                                                        int32_t* __restrict__ slot_inv,
+                                                                        int32_t* __restrict__ slot_pool, int gx, int gy) {
+    __shared__ unsigned long long sk[SORT_THREADS];      // cross-wave exchange buffer
     const int tile = blockIdx.x;
     SORT_TRACE(0);
     const int start = min(offsets[tile], K_cap);
@@ -163,16 +165,20 @@ __global__ void __launch_bounds__(256, 8) bin_tile_sort_kernel(const int32_t* __
     unsigned long long* seg = keys + start;
     int npow = 2;
     while (npow < n) npow <<= 1;
-    if (n <= 256) {
+    // keys per lane: the smallest E with npow <= SORT_THREADS * E; the lanes beyond npow / E are not needed (whole
+    // waves of them leave here, before any barrier)
+    const int E = npow <= SORT_THREADS ? 1 : (npow <= 2 * SORT_THREADS ? 2 : (npow <= 4 * SORT_THREADS ? 4 : 8));
+    if (npow <= 8 * SORT_THREADS && (int)threadIdx.x >= max(npow / E, 64)) return;
+    if (npow <= SORT_THREADS) {
         sort_tile_and_emit<1>(seg, n, npow, sk, start, tile, ids, slot_rec, slot_inv, slot_pool, gx, gy);
         SORT_TRACE(3);
-    } else if (n <= 512) {
+    } else if (npow <= 2 * SORT_THREADS) {
         sort_tile_and_emit<2>(seg, n, npow, sk, start, tile, ids, slot_rec, slot_inv, slot_pool, gx, gy);
         SORT_TRACE(3);
-    } else if (n <= 1024) {
+    } else if (npow <= 4 * SORT_THREADS) {
         sort_tile_and_emit<4>(seg, n, npow, sk, start, tile, ids, slot_rec, slot_inv, slot_pool, gx, gy);
         SORT_TRACE(3);
-    } else if (n <= 2048) {
+    } else if (npow <= 8 * SORT_THREADS) {
         sort_tile_and_emit<8>(seg, n, npow, sk, start, tile, ids, slot_rec, slot_inv, slot_pool, gx, gy);
         SORT_TRACE(3);
     } else {
