@@ -257,7 +257,8 @@ class FitEngine:
         """``count`` full iterations.  ``use_graph=True`` replays a hipGraph of the launches (captured
         lazily, re-captured whenever a pointer, a size or a hyper-parameter changed); it is ignored
         while the library's stage profiler is recording events.  Several iterations in ONE graph save the
-        6-7 us that pass between two graph launches (tools/graph_gap.py: 0.2094 -> 0.2028 ms per iteration)."""
+        2-6 us that pass between two graph launches (tools/graph_gap.py: 0.2094 -> 0.2028, 0.2079 -> 0.2058 ms per
+        iteration with two per graph)."""
         if use_graph and not PROFILE["mask"] and self._launched:
             key = bytes(self.state()) + bytes(self.hp)
             if self._graph_key != key:

@@ -606,7 +606,7 @@ class SimpleGaussian:
             return True
 
         def run(n):
-            """the next n iterations; runs of plain ones go into ONE graph launch, two or four at a time (6-7 us pass
+            """the next n iterations; runs of plain ones go into ONE graph launch, two or four at a time (2-6 us pass
             between two graph launches, tools/graph_gap.py)"""
             end = st.iteration + n
             while st.iteration < end:

@@ -20,7 +20,7 @@ for _ in range(100):
     stepper()
 eng = tr.engine
 torch.cuda.synchronize()
-for per in (1, 2, 4):
+for per in (1, 2, 4, 8, 1, 2, 4, 8):
     g = torch.cuda.CUDAGraph()
     side = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream())
