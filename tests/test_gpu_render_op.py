@@ -154,6 +154,7 @@ def test_operator_costs_about_one_fused_iteration():
 
     t_op, t_fit = timed(op_step), timed(eng.iteration)
     print(f"operator fwd+bwd {t_op * 1e3:.3f} ms, fused fit iteration {t_fit * 1e3:.3f} ms")
-    # measured 1.0x - 1.3x (0.23-0.30 ms against 0.228 ms; the operator's share is half host time: autograd, one
-    # concatenation, two allocations per direction).  The bound leaves room for a slow host on the test box.
-    assert t_op < 1.5 * t_fit, (t_op, t_fit)
+    # measured 1.0x - 1.3x (0.23-0.30 ms against 0.228 ms; half of the operator's time is HOST time: autograd, one
+    # concatenation, two allocations per direction -- the fused iteration is one graph replay).  The bound is a
+    # regression guard (the operator-by-operator path costs 9x), with room for a slow host on the test box.
+    assert t_op < 2.0 * t_fit, (t_op, t_fit)
