@@ -119,6 +119,89 @@ def cpu_baseline():
             "ms_per_step": out["c2"]["ms_per_step"], "phase_ms": out["c2"]["phase_ms"], "c1_10k_splats": out["c1"]}
 
 
+def reduce_and_report(local, dist, red_dev, rank, world, args, backend, size=None):
+    """The two metric all-reduces (SUM of a small vector, MAX of the wall times) and the JSON line rank 0 prints.
+    ``local``: this rank's measurements -- elapsed (s of the timed steps), steps, psnr_step, K (splat-tile pairs of
+    ITS scene), clip (fit_clip's metrics dict or None), clip_wall, kernels_ms, stage_ms.  Returns the dict on rank 0,
+    None elsewhere.  (A function of its own so that tests/test_host_logic.py can run it under 2-rank gloo.)"""
+    Hh, Ww, Nn = size or (H, W, N_SPLATS)
+    clip = local["clip"]
+    vec = [local["elapsed"], float(local["steps"]), local["psnr_step"], float(local["K"])]
+    if clip is not None:
+        vec += [clip[k] for k in ("frames", "iterations", "rasterisations", "psnr_sum", "splats_final")]
+    stats = torch.tensor(vec, dtype=torch.float64, device=red_dev)
+    tmax = torch.tensor([local["elapsed"], local["clip_wall"]], dtype=torch.float64, device=red_dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    if rank != 0:
+        return None
+    wall = float(tmax[0].item())
+    it_per_s = float(stats[1].item()) / wall          # whole job: iterations of all ranks / slowest rank's time
+    K_mean = float(stats[3].item()) / world           # every rank has its own scene: the mean over the ranks
+    P = Hh * Ww
+    roof = {}
+    for kind, ms in local["kernels_ms"].items():
+        if ms:
+            # rank 0's kernels on rank 0's scene
+            b = algorithmic_bytes(kind, Nn, local["K"], P)
+            roof[kind] = {"ms": ms, "algorithmic_bytes": b, "GBps": b / (ms * 1e-3) / 1e9}
+    roofline = None
+    if roof:
+        dom = max(roof, key=lambda k: roof[k]["ms"])
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": roof[dom]["GBps"], "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": roof[dom]["GBps"] / HBM_PEAK_GBPS}
+        roofline.update(pmc_traffic(dom))
+    derived = it_per_s / ITERS_PER_FRAME
+    workload = ("configs[1]" if (Hh, Ww, Nn) == (480, 854, 60000) else "other") + f": {Hh}x{Ww}, {Nn} splats"
+    if clip is not None:
+        cw = float(tmax[1].item())
+        frames_all, iters_all = float(stats[4].item()), float(stats[5].item())
+        value = frames_all / cw
+        clip_out = {"frames_per_rank": args.clip_frames, "wall_s": cw, "iterations": iters_all,
+                    "iterations_per_s": iters_all / cw, "rasterisations_per_s": float(stats[6].item()) / cw,
+                    "psnr_mean_db": float(stats[7].item()) / frames_all,
+                    "splats_final_mean": float(stats[8].item()) / world,
+                    "snapshot_interval": args.snapshot_interval,
+                    "frames_per_s_extrapolated_to_a_60_frame_clip": (iters_all / cw) / ITERS_PER_FRAME}
+        workload += (f"; value = measured fit_video fit of one {args.clip_frames}-frame synthetic clip per GPU "
+                     f"(iterations 500 first / 150 camera-only + 300 joint per later frame, densification on, "
+                     f"snapshots every {args.snapshot_interval} iterations); ms_per_step = one first-frame fit "
+                     f"iteration (grown footprint, lambda rgb/depth/var = 1/0.1/10)")
+    else:
+        value, clip_out = derived, None
+        workload += "; value DERIVED from the first-frame fit iteration (no clip fit in this run)"
+    bytes_per_iteration = 724 * Nn + 124 * K_mean + 96 * P
+    return {
+        "metric": "GFlow fit_video frames/sec (fwd+bwd+step) @60k Gaussians 480p",
+        "value": value,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1000.0,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": workload, "iterations_per_frame": ITERS_PER_FRAME, "splat_tile_pairs_K": K_mean,
+                   "parallelism": f"clip-sharded x{world}", "collective_backend": backend},
+        "value_kind": "measured clip fit" if clip is not None else "derived from the step",
+        "clip_fit": clip_out,
+        "iterations_per_s": it_per_s,
+        "rasterisations_fwd_bwd_per_s": it_per_s,
+        "frames_per_s_derived_from_step": derived,
+        "psnr_step_mean_db": float(stats[2].item()) / world,
+        "roofline": roofline,
+        "kernels": roof,
+        "stage_ms": local["stage_ms"],
+        # whole job (all ranks) and per GPU
+        "end_to_end_algorithmic_GBps": bytes_per_iteration * it_per_s / 1e9,
+        "end_to_end_algorithmic_GBps_per_gpu": bytes_per_iteration * it_per_s / world / 1e9,
+    }
+
+
 def respawn(args):
     """--gpus N without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
     import socket
@@ -241,74 +324,10 @@ def main():
     psnr_step = float(tr.psnr_of(stepper.last_render))
     del stepper, tr
 
-    vec = [elapsed, float(args.steps), psnr_step, float(K)]
-    if clip is not None:
-        vec += [clip[k] for k in ("frames", "iterations", "rasterisations", "psnr_sum", "splats_final")]
-    stats = torch.tensor(vec, dtype=torch.float64, device=red_dev)
-    tmax = torch.tensor([elapsed, clip_wall], dtype=torch.float64, device=red_dev)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-    if rank == 0:
-        wall = float(tmax[0].item())
-        it_per_s = float(stats[1].item()) / wall
-        P = H * W
-        roof = {}
-        for kind, ms in kern.items():
-            if ms:
-                b = algorithmic_bytes(kind, N_SPLATS, K, P)
-                roof[kind] = {"ms": ms, "algorithmic_bytes": b, "GBps": b / (ms * 1e-3) / 1e9}
-        roofline = None
-        if roof:
-            dom = max(roof, key=lambda k: roof[k]["ms"])
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": roof[dom]["GBps"], "peak": HBM_PEAK_GBPS,
-                        "unit": "GB/s", "frac": roof[dom]["GBps"] / HBM_PEAK_GBPS}
-            roofline.update(pmc_traffic(dom))
-        derived = it_per_s / ITERS_PER_FRAME
-        workload = ("configs[1]" if (H, W, N_SPLATS) == (480, 854, 60000) else "other") + f": {H}x{W}, {N_SPLATS} splats"
-        if clip is not None:
-            cw = float(tmax[1].item())
-            frames_all, iters_all = float(stats[4].item()), float(stats[5].item())
-            value = frames_all / cw
-            clip_out = {"frames_per_rank": args.clip_frames, "wall_s": cw, "iterations": iters_all,
-                        "iterations_per_s": iters_all / cw, "rasterisations_per_s": float(stats[6].item()) / cw,
-                        "psnr_mean_db": float(stats[7].item()) / frames_all,
-                        "splats_final_mean": float(stats[8].item()) / world,
-                        "snapshot_interval": args.snapshot_interval,
-                        "frames_per_s_60_frame_clip": (iters_all / cw) / ITERS_PER_FRAME}
-            workload += (f"; value = measured fit_video fit of one {args.clip_frames}-frame synthetic clip per GPU "
-                         f"(iterations 500 first / 150 camera-only + 300 joint per later frame, densification on, "
-                         f"snapshots every {args.snapshot_interval} iterations); ms_per_step = one first-frame fit "
-                         f"iteration (grown footprint, lambda rgb/depth/var = 1/0.1/10)")
-        else:
-            value, clip_out = derived, None
-            workload += "; value DERIVED from the first-frame fit iteration (no clip fit in this run)"
-        out = {
-            "metric": "GFlow fit_video frames/sec (fwd+bwd+step) @60k Gaussians 480p",
-            "value": value,
-            "unit": "frames/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": wall / args.steps * 1000.0,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": workload, "iterations_per_frame": ITERS_PER_FRAME, "splat_tile_pairs_K": K / world,
-                       "parallelism": f"clip-sharded x{world}", "collective_backend": backend},
-            "value_kind": "measured clip fit" if clip is not None else "derived from the step",
-            "clip_fit": clip_out,
-            "iterations_per_s": it_per_s,
-            "rasterisations_fwd_bwd_per_s": it_per_s,
-            "frames_per_s_derived_from_step": derived,
-            "psnr_step_mean_db": float(stats[2].item()) / world,
-            "roofline": roofline,
-            "kernels": roof,
-            "stage_ms": kern_all,
-            "end_to_end_algorithmic_GBps": (724 * N_SPLATS + 124 * K / world + 96 * P) * it_per_s / world / 1e9,
-        }
+    local = {"elapsed": elapsed, "steps": args.steps, "psnr_step": psnr_step, "K": K, "clip": clip,
+             "clip_wall": clip_wall, "kernels_ms": kern, "stage_ms": kern_all}
+    out = reduce_and_report(local, dist, red_dev, rank, world, args, backend)
+    if out is not None:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -1382,6 +1382,8 @@ static bool ewa_on_mfma() {
     return v == 1;
 }
 
+int gfl_ewa_on_mfma(void) { return ewa_on_mfma() ? 1 : 0; }
+
 // list length from which the forward blend walks a queue's first tile as four blocks (GFL_FWD_SPLIT_MIN overrides)
 static int fwd_split_min() {
     static int v = -1;

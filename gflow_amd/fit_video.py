@@ -125,12 +125,21 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise RuntimeError("gflow_amd.fit_video needs a HIP device (there is no CPU rasteriser)")
+    # (ranks share devices only on a box with fewer GPUs than ranks -- a functional run; RCCL refuses two ranks on
+    # one device, so the two small metric all-reduces then go over gloo, as in bench.py)
+    shared = world > n_dev
+    torch.cuda.set_device(local_rank % n_dev)
+    dev = torch.device("cuda", local_rank % n_dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if shared:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
     cfg = dict(num_points=args.num_points, iterations_first=args.iterations_first,
                iterations_after=args.iterations_after, iterations_camera=args.iterations_camera)
     local = {k: 0.0 for k in METRIC_NAMES}
@@ -152,7 +161,7 @@ def main(argv=None):
         for k in METRIC_NAMES:
             local[k] += m[k]
     torch.cuda.synchronize()
-    out = reduce_metrics(local, time.perf_counter() - t0, dist, dev)
+    out = reduce_metrics(local, time.perf_counter() - t0, dist, torch.device("cpu") if (world > 1 and shared) else dev)
     if rank == 0:
         out["frames_per_s"] = out["frames"] / out["wall_s"]
         out["iterations_per_s"] = out["iterations"] / out["wall_s"]

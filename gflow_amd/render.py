@@ -21,6 +21,10 @@ _POOL = {}              # (W, H, device) -> [FitEngine]; an engine is checked ou
 
 
 def _checkout(W, H, n, dev):
+    """An engine of the pool, reserved for the caller: returns (engine, token).  The token is the reservation --
+    ``_release`` frees the engine only for the token it was checked out with, so a stale finalizer of an earlier
+    forward (its graph node is collected AFTER the next forward took the same engine) cannot free it under the
+    forward / backward pair that owns it now."""
     from .fused import FitEngine
     key = (int(W), int(H), str(dev))
     for eng in _POOL.setdefault(key, []):
@@ -29,16 +33,36 @@ def _checkout(W, H, n, dev):
     else:
         eng = FitEngine(W, H, max(2 * n, 65536), dev)
         eng.busy = False
+        eng.owner = None
+        eng.ovf_host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+        eng.ovf_event = None
         _POOL[key].append(eng)
+    # the pair-list overflow flag of this engine's PREVIOUS call, copied to pinned memory behind that call: read it
+    # here without waiting for the device (an overflow drops splat-tile pairs silently otherwise)
+    if eng.ovf_event is not None and eng.ovf_event.query():
+        eng.ovf_event = None
+        if int(eng.ovf_host[0]):
+            eng.overflow.zero_()
+            raise RuntimeError(f"gflow_amd.render: an earlier render produced more than K_cap={eng.K_cap} splat-tile "
+                               f"pairs and dropped some; raise K_cap (FitEngine(..., K_cap=...))")
     eng.ensure_capacity(n)
     if getattr(eng, "pad2", None) is None or eng.pad2.shape[0] < eng.cap:
         eng.pad2 = torch.zeros(eng.cap, 2, dtype=torch.float32, device=eng.dev)
     eng.busy = True
-    return eng
+    eng.owner = object()
+    return eng, eng.owner
 
 
-def _release(eng):
-    eng.busy = False
+def _release(eng, token):
+    if eng.owner is token:
+        eng.owner = None
+        eng.busy = False
+
+
+def _watch_overflow(eng):
+    eng.ovf_host.copy_(eng.overflow, non_blocking=True)
+    eng.ovf_event = torch.cuda.Event()
+    eng.ovf_event.record()
 
 
 class _FusedRender(torch.autograd.Function):
@@ -52,7 +76,7 @@ class _FusedRender(torch.autograd.Function):
     def forward(ctx, xyz, scale, rotate, opacity, rgb, intr, extr, bg, W, H):
         dev = xyz.device
         n = xyz.shape[0]
-        eng = _checkout(W, H, n, dev)
+        eng, token = _checkout(W, H, n, dev)
         try:
             if n:
                 f = lambda t, c: t.detach().float().reshape(n, c)
@@ -66,19 +90,27 @@ class _FusedRender(torch.autograd.Function):
             st.N, st.intr, st.extr, st.render, st.rec = n, intr_c.data_ptr(), extr_c.data_ptr(), out.data_ptr(), rec.data_ptr()
             eng.hp.bg = float(bg)
             L.check(eng.lib.gfl_render_fwd(ctypes.byref(st), ctypes.byref(eng.hp), L.stream()), "render")
+            _watch_overflow(eng)
         except Exception:
-            _release(eng)
+            _release(eng, token)
             raise
         if any(ctx.needs_input_grad):
-            ctx.eng, ctx.n, ctx.keep = eng, n, (intr_c, extr_c, out, rec)
-            weakref.finalize(ctx, _release, eng)        # a graph that is dropped without backward frees the engine too
+            ctx.eng, ctx.n, ctx.keep, ctx.token = eng, n, (intr_c, extr_c, out, rec), token
+            # a graph that is dropped without backward frees the engine too; backward() calls this same finalizer,
+            # which runs at most once
+            ctx.fin = weakref.finalize(ctx, _release, eng, token)
         else:
-            _release(eng)
+            _release(eng, token)
         return out[:3], out[3:4], rec[:n, 0:2], rec[:n, 9:10]
 
     @staticmethod
     def backward(ctx, d_rgb, d_depth_map, d_uv, d_depth):
         eng, n = ctx.eng, ctx.n
+        if eng.owner is not ctx.token:
+            # (the tile lists, records and checkpoints of the forward live in the pooled engine, which went back to the
+            # pool with the first backward)
+            raise RuntimeError("gflow_amd.render: backward through the fused render operator a second time "
+                               "(retain_graph) is not supported; call render() again")
         dev = eng.dev
         H, W = eng.H, eng.W
         z = lambda c: torch.zeros(c, H, W, dtype=torch.float32, device=dev)
@@ -89,7 +121,7 @@ class _FusedRender(torch.autograd.Function):
         d_extr = torch.empty(12, dtype=torch.float32, device=dev)
         L.check(eng.lib.gfl_render_bwd(ctypes.byref(eng.state()), ctypes.byref(eng.hp), L.ptr(d_render), L.ptr(d_uv),
                                        L.ptr(d_depth), L.ptr(d_params), L.ptr(d_extr), L.stream()), "render backward")
-        _release(eng)
+        ctx.fin()
         g = d_params[:n]
         return (g[:, 0:3], g[:, 3:6], g[:, 6:10], g[:, 10:11], g[:, 11:14], None, d_extr.reshape(3, 4), None, None, None)
 

@@ -68,8 +68,13 @@ class _PinnedPool:
     (hipHostMalloc of the 110-180 MB a stage's snapshots need: 16-43 ms, five times per later frame in a HIP API
     trace of a clip fit), so a block goes back to the pool as soon as the arrays handed out of it are gone."""
 
+    MAX_BYTES = 4 << 30         # beyond this much page-locked memory the snapshots are handed out as pageable copies
+
     def __init__(self):
         self.blocks = []                                # [uint8 pinned tensor, arrays still alive]
+
+    def total_bytes(self):
+        return sum(b[0].numel() for b in self.blocks)
 
     def take(self, nbytes):
         for b in self.blocks:
@@ -95,6 +100,10 @@ class _PinnedPool:
 
         def gone():
             block[1] -= 1
+        if self.total_bytes() > self.MAX_BYTES:
+            # a caller that keeps every frame's snapshot lists (the reference's fit_video does, to write its videos)
+            # would otherwise hold one 110-180 MB page-locked block per train() call: tens of GB over a 60-frame clip
+            return [t.numpy().copy() for t in tensors]
         out = []
         for t in tensors:
             a = t.numpy()
@@ -231,6 +240,7 @@ class SimpleGaussian:
     def init_gaussians_from_image(self, gt_image, gt_depth=None, num_points=None, mask=None, drop_to=None):
         """trainer.py:206-238."""
         num_points = self.num_points if num_points is None else num_points
+        self._engine_live = False                    # the attributes are replaced: no longer views of the engine's rows
         xys, depths, scales, rgbs, gt_depth = complex_texture_sampling(
             gt_image, gt_depth.cpu(), num_points=num_points, mask=mask, drop_to=drop_to, rng=self.rng)
         n = xys.shape[0]
@@ -250,6 +260,7 @@ class SimpleGaussian:
         """trainer.py:123-153: group "attributes" (lr), "extr" = pose (lr_camera), depth_a / depth_b
         (lr).  depth_a and depth_b live in one (2,) tensor here."""
         self.lr, self.lr_camera = lr, lr_camera
+        self._engine_live = False
         for k in self._attributes:
             self._attributes[k] = nn.Parameter(self._attributes[k].detach().contiguous()).requires_grad_(True)
         self.pose = nn.Parameter(self.pose.detach().clone()).requires_grad_(True)
@@ -541,13 +552,20 @@ class SimpleGaussian:
                 imgs = eng.snapshot()
                 # ... and on their way to the host at once, on a copy stream into pinned memory: the reference blocks
                 # on three device-to-host copies here; 150 images per first-frame fit cost ~40 ms as one pageable copy
-                if st.pin is None:
-                    n_snaps = (iterations + snapshot_interval - 1) // snapshot_interval
-                    st.pin_block = _PINNED.take(n_snaps * 3 * H * W * 3)
-                    st.pin_hold = _PINNED.hold(st.pin_block, st)     # ... while this stepper lives
-                    st.pin = st.pin_block[0][:n_snaps * 3 * H * W * 3].view(n_snaps, 3, H, W, 3)
-                    st.copy_stream = _copy_stream(dev)
                 k = len(st.frames)
+                if st.pin is None or k >= st.pin.shape[0]:
+                    # (k >= rows: a stepper that is run for more than ``iterations`` steps gets a larger block)
+                    n_snaps = max((iterations + snapshot_interval - 1) // snapshot_interval, 2 * k, 1)
+                    block = _PINNED.take(n_snaps * 3 * H * W * 3)
+                    pin = block[0][:n_snaps * 3 * H * W * 3].view(n_snaps, 3, H, W, 3)
+                    hold = _PINNED.hold(block, st)                   # ... while this stepper lives
+                    if st.pin is not None:
+                        st.copy_stream.synchronize()
+                        pin[:k].copy_(st.pin[:k])
+                        st.frames, st.frames_depth, st.frames_center = ([pin[j, c] for j in range(k)] for c in range(3))
+                        st.pin_hold()
+                    st.pin_block, st.pin, st.pin_hold = block, pin, hold
+                    st.copy_stream = _copy_stream(dev)
                 st.copy_stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(st.copy_stream):
                     st.pin[k].copy_(imgs, non_blocking=True)
@@ -571,15 +589,16 @@ class SimpleGaussian:
             # ---- densification (trainer.py:560-571)
             densified = False
             if not camera_only and iteration == 0 and later_frame and mask is not None:
-                if mask.sum() > 0:
-                    self.densify_by_pixels(torch.ones_like(eng.err_px), error_threshold=0.0,
-                                           percent=densify_occ_percent, mask=mask)
-                    densified = True
+                # (an empty mask appends nothing: densify_by_pixels's own single host read decides, there is no
+                #  separate ``mask.sum() > 0`` read as in trainer.py:563)
+                b, a = self.densify_by_pixels(torch.ones_like(eng.err_px), error_threshold=0.0,
+                                              percent=densify_occ_percent, mask=mask)
+                densified |= a > b
             if (not camera_only and densify_interval and (iteration + 1) % densify_interval == 0
                     and (iteration + 1) // densify_interval <= densify_times):
-                self.densify_by_pixels(eng.err_px, error_threshold=densify_err_thre, percent=densify_err_percent,
-                                       mask=None)
-                densified = True
+                b, a = self.densify_by_pixels(eng.err_px, error_threshold=densify_err_thre,
+                                              percent=densify_err_percent, mask=None)
+                densified |= a > b          # the reference swaps the optimiser only inside `if densify_num > 0` (:903-936)
             st.uv, st.depth, st.last_render = rec_now[:n_rendered, 0:2], rec_now[:n_rendered, 9:10], eng.render
             if densified:
                 # trainer.py:941-951: the optimiser is replaced by Adam(attributes, lr): moments and step restart,
@@ -764,7 +783,8 @@ class SimpleGaussian:
         re-packing, the parameter views are simply re-cut)."""
         new = {"xyz": new_xyz, "scale": new_scale, "rotate": new_rotate, "opacity": new_opacity, "rgb": new_rgb}
         eng = self.engine
-        if self.fused and eng is not None and getattr(self, "_engine_live", False):
+        if (self.fused and eng is not None and getattr(self, "_engine_live", False)
+                and self._attributes["xyz"].data_ptr() == eng.params.data_ptr() and eng.N == self.current_pts_num()):
             from .fused import COLS
             n0, k = eng.N, new_xyz.shape[0]
             eng.ensure_capacity(n0 + k)
@@ -803,6 +823,7 @@ class SimpleGaussian:
 
     def load_checkpoint(self, checkpoint_path):
         ckpt = torch.load(checkpoint_path, map_location=self.device, weights_only=False)
+        self._engine_live = False                    # the attributes are replaced: no longer views of the engine's rows
         self._attributes = {k: v.to(self.device) for k, v in ckpt["attributes"].items()}
         self.intr = ckpt["intr"].to(self.device)
         self.load_camera(extr=ckpt["extr"])

@@ -83,6 +83,9 @@ typedef enum gfl_status {
 int gfl_version(void);
 /* out[10] = TILE, NEAREST, EXTENT, FOV_CLAMP, LOWPASS, EIG_FLOOR, RADIUS_SIGMA, ALPHA_MIN, ALPHA_MAX, T_MIN of this build */
 int gfl_constants(float* out10);
+/* 1 when this process runs the J Sigma J^T contraction of gfl_fit_forward / gfl_render_fwd on the matrix cores
+ * (GFL_EWA_MFMA=1 in the environment when the library first looked), 0 for the VALU form */
+int gfl_ewa_on_mfma(void);
 const char* gfl_status_string(int status);
 int gfl_last_hip_error(void);
 /* bytes of scratch any *_bwd that reduces camera gradients needs for N splats */

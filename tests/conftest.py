@@ -32,3 +32,13 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _expected_library_switches():
+    """A test run started with GFL_EXPECT_EWA_MFMA=1 (tests/test_gpu_primitives.py starts one) must really be running
+    the matrix-core contraction: the library reads GFL_EWA_MFMA once per process."""
+    if os.environ.get("GFL_EXPECT_EWA_MFMA") == "1":
+        from gflow_amd import _lib
+        assert _lib.load().gfl_ewa_on_mfma() == 1, "GFL_EWA_MFMA=1 did not reach the library"
+    yield

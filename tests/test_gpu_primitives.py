@@ -47,6 +47,27 @@ def test_ewa_contraction_on_the_matrix_cores_equals_the_valu_form():
     assert ((a - b).abs().cpu().double() / scale).max() < 1e-6
 
 
+def test_oracle_parity_holds_with_the_matrix_core_contraction():
+    """GFL_EWA_MFMA=1 puts cov2d_mfma into fused_preprocess_fwd (the variant north_star names; the library reads the
+    switch once per process, hence a process of its own): the fused forward, all fused gradients and the full-size
+    (480x854, 60 000 splats) fused iteration are held against the ORACLE again with the switch on.  conftest.py checks
+    inside that process that the library really took the switch (GFL_EXPECT_EWA_MFMA)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GFL_EWA_MFMA="1", GFL_EXPECT_EWA_MFMA="1")
+    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+           "tests/test_gpu_fused.py::test_fused_forward_matches_oracle_and_operator_path",
+           "tests/test_gpu_fused.py::test_fused_gradients_match_oracle",
+           "tests/test_gpu_render_op.py::test_render_operator_values_and_gradients_match_oracle",
+           "tests/test_gpu_fullsize.py::test_fullsize_fused_iteration_matches_oracle[bench_scene]"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout + r.stderr)[-4000:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], tail
+
+
 @pytest.mark.parametrize("box", [8, 4])
 def test_block_culling_never_drops_a_visible_pixel(box):
     """The blend kernels skip a (splat, pixel box) unit when `block_mask` says the splat cannot reach the box with

@@ -110,6 +110,55 @@ def test_two_forwards_before_their_backwards_and_empty_input():
     assert out["uv"].shape == (0, 2) and out["depth"].shape == (0, 1)
 
 
+def test_a_stale_finalizer_cannot_free_an_engine_that_is_reserved_again():
+    """backward() used to free the pooled engine while the finalizer registered in forward stayed armed; it
+    fired when the OLD graph node was collected -- after the next forward had taken the same engine -- and a third
+    render then overwrote the state of a forward / backward pair that was still open.  Reservations are tokens now."""
+    import gc
+    import gflow_amd.render as R
+    sa = to_dev(random_scene(1000, 96, 80, seed=5, sigma_px=2.0))
+    sb = to_dev(random_scene(700, 96, 80, seed=6, sigma_px=3.0))
+    cam = lambda s: dict(intr=s["intr"], extr=s["extr"], W=s["W"], H=s["H"])
+
+    def fwd(s):
+        leaves = {k: s[k].clone().requires_grad_(True) for k in NAMES}
+        return leaves, R.render(leaves, cam(s), 0.0)
+
+    la, oa = fwd(sa)
+    (oa["rgb"].sum() + oa["depth_map"].sum()).backward()
+    alone = {k: la[k].grad.clone() for k in NAMES}
+    pool = R._POOL[(96, 80, str(sa["xyz"].device))]
+    n_busy = lambda: sum(1 for e in pool if e.busy)
+    assert n_busy() == 0
+    old_leaves, old_out = fwd(sb)                                   # iteration 1 of "b": forward + backward
+    (old_out["rgb"].sum()).backward()
+    assert n_busy() == 0
+    la2, oa2 = fwd(sa)                                              # takes the engine that "b" just gave back
+    assert n_busy() == 1
+    del old_leaves, old_out                                         # the old graph node goes away NOW
+    gc.collect()
+    assert n_busy() == 1, "a stale finalizer freed an engine that another forward holds"
+    lb, ob = fwd(sb)                                                # must not get (and overwrite) that engine
+    assert n_busy() == 2
+    (ob["rgb"].sum()).backward()
+    (oa2["rgb"].sum() + oa2["depth_map"].sum()).backward()
+    assert n_busy() == 0
+    for k in NAMES:
+        assert torch.allclose(alone[k], la2[k].grad, rtol=1e-4, atol=1e-7), k
+    # a second backward through the same forward has no engine any more: a clear error, not a wrong gradient
+    lc, oc = fwd(sa)
+    loss = oc["rgb"].sum()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time"):
+        loss.backward()
+    # a forward that is dropped without a backward gives its engine back
+    ld, od = fwd(sa)
+    assert n_busy() == 1
+    del ld, od
+    gc.collect()
+    assert n_busy() == 0
+
+
 def test_operator_costs_about_one_fused_iteration():
     """the one-line swap runs forward + backward of the rasteriser in two library calls.  Bound its
     cost against the fused fit iteration (which does the same rasterisation plus loss and Adam) on a 480p / 60k frame."""

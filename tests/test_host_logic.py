@@ -104,6 +104,90 @@ def test_two_rank_gloo_reduction():
         assert o["splats_final"] == 3000
 
 
+def _bench_worker(rank, world, port, q):
+    import argparse
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    args = argparse.Namespace(steps=100, warmup=10, clip_frames=8, snapshot_interval=10)
+    # per-rank numbers as two different scenes would produce them
+    local = {"elapsed": 0.020 + 0.005 * rank, "steps": 100, "psnr_step": 30.0 + rank, "K": 240000 + 20000 * rank,
+             "clip": dict(frames=8, iterations=3650, rasterisations=4700, psnr_sum=8 * (33.0 + rank), splats_final=67000 + 2000 * rank),
+             "clip_wall": 1.0 + 0.25 * rank, "kernels_ms": {"blend_bwd": 0.070, "blend_fwd": 0.035}, "stage_ms": {}}
+    out = bench.reduce_and_report(local, dist, torch.device("cpu"), rank, world, args, "gloo", size=(480, 854, 60000))
+    dist.destroy_process_group()
+    q.put((rank, out))
+
+
+def test_bench_reduction_under_two_rank_gloo():
+    """bench.py's N > 1 line: K is the MEAN of the ranks' pair counts (round 2 divided rank 0's own K by the world
+    size), value = frames of all ranks / slowest rank's clip time, the end-to-end rate counts every rank's bytes."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert outs[1] is None
+    o = outs[0]
+    assert o["n_gpus"] == 2 and o["scaling"] == "weak" and o["config"]["collective_backend"] == "gloo"
+    assert o["config"]["splat_tile_pairs_K"] == 250000.0
+    assert abs(o["value"] - 16 / 1.25) < 1e-9                                # 2 x 8 frames / slowest clip fit
+    assert abs(o["ms_per_step"] - 0.25) < 1e-9                                # slowest rank: 25 ms / 100 steps
+    assert abs(o["iterations_per_s"] - 200 / 0.025) < 1e-6
+    bytes_it = 724 * 60000 + 124 * 250000.0 + 96 * 480 * 854
+    assert abs(o["end_to_end_algorithmic_GBps"] - bytes_it * 8000.0 / 1e9) < 1e-6
+    assert abs(o["end_to_end_algorithmic_GBps_per_gpu"] - bytes_it * 4000.0 / 1e9) < 1e-6
+    assert abs(o["clip_fit"]["psnr_mean_db"] - 33.5) < 1e-9 and o["clip_fit"]["splats_final_mean"] == 68000.0
+    # the roofline block describes rank 0's kernels on rank 0's scene
+    assert o["roofline"]["kernel"] == "blend_bwd"
+    want = (44 * 240000 + 24 * 480 * 854 + 40 * 60000) / 0.070e-3 / 1e9
+    assert abs(o["roofline"]["achieved"] - want) < 1e-6 and abs(o["roofline"]["frac"] - want / 8000.0) < 1e-9
+
+
+def test_readers_match_the_reference_on_the_same_files(tmp_path, golden_dir):
+    """gflow_amd/io.py against what the REFERENCE's read_flow / read_depth / read_camera (gflow/utils/read.py:7-38,
+    60-89) returned for the very same files: tests/golden/readers.npz keeps the files' bytes and the reference's
+    outputs (tests/golden/make_golden.py: readers_fixture)."""
+    import json
+    from gflow_amd import io as gio
+    g = np.load(os.path.join(golden_dir, "readers.npz"))
+
+    def put(name, key):
+        path = str(tmp_path / name)
+        g[key].tofile(path)
+        return path
+
+    flow = gio.read_flow(put("a_pred.flo", "flo_bytes"))
+    assert flow.dtype == torch.float32 and tuple(flow.shape) == (5, 7, 2)
+    assert np.array_equal(flow.numpy(), g["flow"]) and np.signbit(flow.numpy()[0, 0, 0])      # bit-exact, -0.0 kept
+    assert gio.read_flow(put("bad.flo", "flo_bad_bytes")) is None                             # read.py:15-18
+    npy = put("00000.npy", "depth_npy_bytes")
+    d = gio.read_depth(npy)
+    assert d.dtype == torch.float32 and np.array_equal(d.numpy(), g["depth"])
+    assert np.array_equal(gio.read_depth(npy, depth_scale=0.5, depth_offset=0.25).numpy(), g["depth_scaled"])
+    paths = []
+    for i, txt in enumerate(g["camera_json"]):
+        paths.append(str(tmp_path / f"{i:05d}.json"))
+        with open(paths[-1], "w") as f:
+            f.write(str(txt))
+    focal, pp, poses = gio.read_camera(paths)
+    assert isinstance(focal, float) and focal == float(g["focal"])
+    assert pp == g["pp"].tolist() == [428, 240]                       # the LAST file's, python round (halves to even)
+    assert poses.shape == (3, 3, 4) and np.array_equal(poses, g["poses"])
+    f2, pp2, _ = gio.read_camera(paths[:2])
+    assert f2 == float(g["focal_first_two"]) and pp2 == g["pp_first_two"].tolist() == [428, 240]
+    assert json.loads(str(g["camera_json"][1]))["pp"] == [427.5, 240.49]
+
+
 def test_sequence_readers_round_trip(tmp_path):
     """gflow_amd.io: the reference's on-disk convention (fit_video.py:79-99, read.py, conversion.py)."""
     from gflow_amd import io as gio
