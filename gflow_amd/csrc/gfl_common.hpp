@@ -150,7 +150,9 @@ __device__ __forceinline__ int reduce_scatter10_component(int lane) {
 
 // Deterministic block-level reduction of NV values -> one partial row per block.
 // partial[blockIdx.x * NV + k]; a second tiny kernel folds the rows in order.
-template <int NV, int BLOCK>
+// AGENT: the row is stored with agent-scope atomic stores (write-through), for a reader in ANOTHER workgroup of the
+// same launch (camera_tail of gfl_fused.hip).
+template <int NV, int BLOCK, bool AGENT = false>
 __device__ __forceinline__ void block_reduce_store(float (&vals)[NV], float* __restrict__ partial) {
     __shared__ float red[BLOCK / WAVE][NV];
     const int lane = threadIdx.x & (WAVE - 1);
@@ -165,7 +167,8 @@ __device__ __forceinline__ void block_reduce_store(float (&vals)[NV], float* __r
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < BLOCK / WAVE; ++w) s += red[w][threadIdx.x];
-        partial[(size_t)blockIdx.x * NV + threadIdx.x] = s;
+        if (AGENT) __hip_atomic_store(&partial[(size_t)blockIdx.x * NV + threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else partial[(size_t)blockIdx.x * NV + threadIdx.x] = s;
     }
 }
 

@@ -991,20 +991,151 @@ struct RegCfg {                 // per-splat regularisers (trainer.py:490-530)
     int freeze_all;             // camera_only, trainer.py:548-551
 };
 
+// Camera + depth-affine step as the TAIL of the per-splat kernel (round 3; it used to be a launch of its own: one
+// workgroup, 7.5 us of dependent L2 round trips = 3 % of every iteration).  Every workgroup of
+// fused_preprocess_bwd_adam takes a ticket after it has stored its row of extr partials; the workgroup that draws the
+// last one folds the rows and the loss partials (fixed shape: the result does not depend on WHICH workgroup is last),
+// chains d_extr to the pose, steps Adam for pose + depth affine and advances the step counter.  Nothing else reads
+// pose / depth_ab / step after that point of the launch: every workgroup reads them before it takes its ticket.
+struct CamTail {
+    const float* p_ssim; int n_ssim;        // SSIM partials of the loss launch
+    const float* p_grad; int n_grad;        // [n_grad][4] = {sum mse_px, sum depth term, d/d depth_a, d/d depth_b}
+    float* pose; float* pose_m; float* pose_v;
+    float* depth_ab; float* ab_m; float* ab_v;
+    float* sums;                            // [8]: sums[0..4] as gfl_loss_fwd_bwd documents
+    AdamCfg ac_cam, ac_ab;
+    int step_camera;
+    int32_t* d_step;
+    float* d_extr_out;                      // [12]
+    int32_t* ticket;                        // zero between launches
+};
+
+__device__ __forceinline__ float ld_agent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // written by other workgroups of THIS launch
+}
+
+__device__ __forceinline__ void camera_tail(const CamTail& t, const float* partial, int rows, int e_step) {
+    constexpr int NV = 17;   // 12 extr + {mse, ssim, depth, d/da, d/db}
+    __shared__ int32_t s_last;
+    __shared__ float red[REDUCE_BLOCK / 64][NV];
+    __shared__ float ge[NV];
+    // The partial row was stored with agent-scope (write-through) atomic stores; wait until they have left this
+    // wave -- NOT __threadfence(): an agent-scope release on gfx950 writes back the XCD's whole L2, i.e. the 30 MB of
+    // parameter / moment rows this launch has just written (measured: the launch went from 22 to 59 us) -- and only
+    // then draw the ticket.  The last workgroup reads the rows with agent-scope loads.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(t.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    // thread 0 needs these after the reduction: request them now
+    float pz[7], pm[7], pv[7], ab[2], abm[2], abv[2];
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(t.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { pz[k] = t.pose[k]; pm[k] = t.pose_m[k]; pv[k] = t.pose_v[k]; }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { ab[k] = t.depth_ab[k]; abm[k] = t.ab_m[k]; abv[k] = t.ab_v[k]; }
+    }
+    float acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = 0.f;
+    // one workgroup, nothing to overlap a load with but other loads: issue them in batches
+    for (int r = threadIdx.x; r < rows; r += REDUCE_BLOCK) {
+        float v[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) v[k] = ld_agent(partial + (size_t)r * 12 + k);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) acc[k] += v[k];
+    }
+    for (int r0 = threadIdx.x; r0 < t.n_ssim; r0 += 8 * REDUCE_BLOCK) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (r0 + u * REDUCE_BLOCK < t.n_ssim) ? t.p_ssim[r0 + u * REDUCE_BLOCK] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[13] += v[u];
+    }
+    for (int r0 = threadIdx.x; r0 < t.n_grad; r0 += 4 * REDUCE_BLOCK) {
+        float4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            q[u] = (r0 + u * REDUCE_BLOCK < t.n_grad) ? reinterpret_cast<const float4*>(t.p_grad)[r0 + u * REDUCE_BLOCK]
+                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc[12] += q[u].x; acc[14] += q[u].y; acc[15] += q[u].z; acc[16] += q[u].w; }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const float s = wave_sum_to_lane63(acc[k]);
+        if (lane == 63) red[wid][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        float x = 0.f;
+#pragma unroll
+        for (int w = 0; w < REDUCE_BLOCK / 64; ++w) x += red[w][threadIdx.x];
+        ge[threadIdx.x] = x;
+        if (threadIdx.x < 12) t.d_extr_out[threadIdx.x] = x;
+        else t.sums[threadIdx.x - 12] = x;
+    }
+    if (threadIdx.x >= NV && threadIdx.x < NV + 3) t.sums[threadIdx.x - NV + 5] = 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int e = e_step;
+        if (t.step_camera) {
+            // d_extr (rows R|t) -> d_pose; q = raw/|raw| in XYZW order
+            const float rx = pz[0], ry = pz[1], rz = pz[2], rw = pz[3];
+            const float n = sqrtf(rx * rx + ry * ry + rz * rz + rw * rw);
+            const float x = rx / n, y = ry / n, z = rz / n, w = rw / n;
+            const float* dR = ge;   // dR[i][j] = ge[4 i + j]
+            const float d00 = dR[0], d01 = dR[1], d02 = dR[2], d10 = dR[4], d11 = dR[5], d12 = dR[6], d20 = dR[8],
+                        d21 = dR[9], d22 = dR[10];
+            float dq[4];   // x y z w
+            dq[3] = 2.f * (-z * d01 + y * d02 + z * d10 - x * d12 - y * d20 + x * d21);
+            dq[0] = 2.f * (y * d01 + z * d02 + y * d10 - 2.f * x * d11 - w * d12 + z * d20 + w * d21 - 2.f * x * d22);
+            dq[1] = 2.f * (-2.f * y * d00 + x * d01 + w * d02 + x * d10 + z * d12 - w * d20 + z * d21 - 2.f * y * d22);
+            dq[2] = 2.f * (-2.f * z * d00 - w * d01 + x * d02 + w * d10 - 2.f * z * d11 + y * d12 + x * d20 + y * d21);
+            const float qh[4] = {x, y, z, w};
+            const float dot = qh[0] * dq[0] + qh[1] * dq[1] + qh[2] * dq[2] + qh[3] * dq[3];
+            float gp[7];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gp[k] = (dq[k] - qh[k] * dot) / n;
+            gp[4] = ge[3]; gp[5] = ge[7]; gp[6] = ge[11];
+            float ss, isb;
+            adam_scalars(t.ac_cam, e, t.ac_cam.lr, ss, isb);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                t.pose[k] = adam_update(pz[k], gp[k], pm[k], pv[k], t.ac_cam, ss, isb);
+                t.pose_m[k] = pm[k]; t.pose_v[k] = pv[k];
+            }
+            adam_scalars(t.ac_ab, e, t.ac_ab.lr, ss, isb);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                t.depth_ab[k] = adam_update(ab[k], ge[15 + k], abm[k], abv[k], t.ac_ab, ss, isb);
+                t.ab_m[k] = abm[k]; t.ab_v[k] = abv[k];
+            }
+        }
+        *t.d_step = e + 1;
+    }
+}
+
 // OP = true is the differentiable operator's backward (gfl_render_bwd): the rows hold ACTIVATED attributes, the
 // camera is the extrinsic `pose` points at (12 floats), the caller's dL/d uv and dL/d depth join the gradient, and
 // the 14 gradients are WRITTEN to d_params rows instead of stepping Adam (no regularisers, no masks).
 template <bool OP>
 __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel(
     float* __restrict__ params, float* __restrict__ adam_m, float* __restrict__ adam_v, const float* __restrict__ intr,
-    const float* __restrict__ pose, const float* __restrict__ rec, float* __restrict__ d_rec,
+    const float* pose, const float* __restrict__ rec, float* __restrict__ d_rec,
     const float* __restrict__ pair_grad, const int32_t* __restrict__ slot_pool,
     const int32_t* __restrict__ tile_range, const int32_t* __restrict__ slot_inv, int gx, int gy, int N, int W, int H,
     const float* __restrict__ flow_target, const float* __restrict__ flow_w, const float* __restrict__ still_target,
     const float* __restrict__ still_w, const uint8_t* __restrict__ row_flags, RegCfg rc, AdamCfg ac,
-    const int32_t* __restrict__ d_step, float* __restrict__ partial, const float* __restrict__ d_uv_in,
-    const float* __restrict__ d_depth_in, float* __restrict__ d_params, const int32_t* __restrict__ scale_cnt) {
+    const int32_t* d_step, float* partial, const float* __restrict__ d_uv_in,
+    const float* __restrict__ d_depth_in, float* __restrict__ d_params, const int32_t* __restrict__ scale_cnt, CamTail tail) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e_step = OP ? 0 : *d_step;              // (the tail of the LAST workgroup advances it)
     float scale_w = 0.f;                              // lambda_scale / rows of the scale term
     if (!OP && rc.lambda_scale != 0.f) {
         __shared__ int32_t s_rows;
@@ -1231,7 +1362,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
         }
         // Adam over the 64-byte row
         float step_size, isb2;
-        adam_scalars(ac, *d_step, ac.lr, step_size, isb2);
+        adam_scalars(ac, e_step, ac.lr, step_size, isb2);
         float4* prow = reinterpret_cast<float4*>(params + (size_t)i * ROW);
         float4* mrow = reinterpret_cast<float4*>(adam_m + (size_t)i * ROW);
         float4* vrow = reinterpret_cast<float4*>(adam_v + (size_t)i * ROW);
@@ -1253,7 +1384,12 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
         }
         }
     }
-    block_reduce_store<12, REDUCE_BLOCK>(e, partial);
+    if (!OP && tail.ticket) {
+        block_reduce_store<12, REDUCE_BLOCK, true>(e, partial);
+        camera_tail(tail, partial, (int)gridDim.x, e_step);
+    } else {
+        block_reduce_store<12, REDUCE_BLOCK>(e, partial);
+    }
 }
 
 // camera + depth affine: fold the extr partials, chain to the pose, Adam, step += 1
@@ -1383,6 +1519,19 @@ static bool ewa_on_mfma() {
 }
 
 int gfl_ewa_on_mfma(void) { return ewa_on_mfma() ? 1 : 0; }
+
+// GFL_CAMERA_TAIL=1: the camera / depth-affine step as the ticketed tail of the per-splat launch (camera_tail) instead of
+// a launch of its own.  Measured (round 3, one box, alternating): per-splat launch 22.3 -> 29.5 us with the tail against
+// 22.3 + a 5-7 us launch without it, step 0.2100 against 0.2088 ms: the serial chain (agent-scope ticket, agent-scope
+// loads of the rows, fold, pose chain rule) costs the same wherever it runs.  Off by default.
+static bool camera_own_launch() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GFL_CAMERA_TAIL");
+        v = (e && e[0] == '1') ? 0 : 1;
+    }
+    return v == 1;
+}
 
 // list length from which the forward blend walks a queue's first tile as four blocks (GFL_FWD_SPLIT_MIN overrides)
 static int fwd_split_min() {
@@ -1688,7 +1837,7 @@ int gfl_render_bwd(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float
         fused_preprocess_bwd_adam_kernel<true><<<rows, REDUCE_BLOCK, 0, s>>>(
             st->params, nullptr, nullptr, st->intr, st->extr, st->rec, st->d_rec, w.pair_grad, w.slot_pool, st->tile_range,
             w.slot_inv, gx, gy, st->N, st->W, st->H, nullptr, nullptr, nullptr, nullptr, nullptr, rcfg, ac, nullptr,
-            w.partial, d_uv, d_depth, d_params, nullptr);
+            w.partial, d_uv, d_depth, d_params, nullptr, CamTail{});
         fold_partials_kernel<12><<<1, 256, 0, s>>>(w.partial, rows, d_extr);
     }
     return check_launch();
@@ -1734,14 +1883,24 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
     AdamCfg ac = {hp->lr, hp->beta1, hp->beta2, hp->eps, hp->lr_end_factor, hp->total_iters};
     AdamCfg ac_cam = ac;
     ac_cam.lr = hp->lr_camera;
+    // the camera / depth-affine step: a launch of its own, or (GFL_CAMERA_TAIL=1) the tail of the per-splat launch
+    const bool own_launch = camera_own_launch();
+    CamTail tail = {};
+    if (!own_launch) {
+        tail.p_ssim = p_ssim; tail.n_ssim = n_ssim; tail.p_grad = p_grad; tail.n_grad = n_grad;
+        tail.pose = st->pose; tail.pose_m = st->pose_m; tail.pose_v = st->pose_v;
+        tail.depth_ab = st->depth_ab; tail.ab_m = st->depth_ab_m; tail.ab_v = st->depth_ab_v;
+        tail.sums = st->sums; tail.ac_cam = ac_cam; tail.ac_ab = ac; tail.step_camera = hp->step_camera;
+        tail.d_step = st->step; tail.d_extr_out = st->d_extr; tail.ticket = w.pool_counter + 8;
+    }
     {
         StageScope p(ST_PRE_BWD_ADAM, s);
         fused_preprocess_bwd_adam_kernel<false><<<rows, REDUCE_BLOCK, 0, s>>>(
             st->params, st->adam_m, st->adam_v, st->intr, st->pose, st->rec, st->d_rec, w.pair_grad, w.slot_pool,
             st->tile_range, w.slot_inv, gx, gy, st->N, st->W, st->H, st->flow_target, st->flow_w, st->still_target,
-            st->still_w, st->row_flags, rcfg, ac, st->step, w.partial, nullptr, nullptr, nullptr, w.scale_cnt);
+            st->still_w, st->row_flags, rcfg, ac, st->step, w.partial, nullptr, nullptr, nullptr, w.scale_cnt, tail);
     }
-    {
+    if (own_launch) {
         StageScope p(ST_CAMERA, s);
         fused_camera_adam_kernel<<<1, 1024, 0, s>>>(w.partial, rows, p_ssim, n_ssim, p_grad, n_grad, st->pose, st->pose_m,
                                                     st->pose_v, st->depth_ab, st->depth_ab_m, st->depth_ab_v, st->sums,
