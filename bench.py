@@ -78,7 +78,9 @@ def clip_fit(dev, rank, frames_n, snapshot_interval):
     metrics dict and the wall seconds of the timed fit."""
     from gflow_amd import synthetic as S
     from gflow_amd import fit_video as FV
-    frames = S.make_clip(frames_n, H, W, seed=rank)
+    # the clip is resident in HBM before the clock starts (bench contract: inputs already in HBM; fit_clip itself
+    # uploads a host clip as its first act -- 10 MB per frame over PCIe: ~1 ms, noted in DESIGN.md section 5)
+    frames = FV.upload_clip(S.make_clip(frames_n, H, W, seed=rank), dev)
     cfg = dict(num_points=N_SPLATS)
     FV.fit_clip(frames[:2], dev, cfg, seed=rank, snapshot_interval=snapshot_interval)      # warm-up
     torch.cuda.synchronize()

@@ -479,7 +479,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     if (item.part >= 4) continue;                    // (the backward pass has more segments than the forward pass blocks)
     if (item.part > 0) {
         owner = (item.queue + item.part * (queue.nq / 4)) % queue.nq;
-        tile = queue.count[owner] > 0 ? (queue.list[(size_t)owner * queue.cap_q] & 0x0fffffff) : -1;
+        tile = queue.count[owner] > 0 ? (queue.list[(size_t)owner * queue.cap_q] & 0xffff) : -1;
         if (tile < 0) continue;
     }
     const int tx = tile % gx, ty = tile / gx;
@@ -679,7 +679,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
         final_T[pix] = T;
         n_contrib[pix] = last;
     }
-    if (mode == 0 && lane == 0) atomicAdd(&tile_work[tile], units + 1);
+    if (mode == 0 && lane == 0) atomicAdd(&tile_work[4 * tile + (blk < 0 ? wave : blk)], units + 1);     // per 8x8 block (gfl_sched.hpp: block plan)
     // the wave stopped before the split position: every pixel's state is frozen, final = checkpoint
     for (; ck_next < parts; ++ck_next) {
         float* c5 = ck + (size_t)(ck_next - 1) * 5 * 256;
@@ -752,17 +752,36 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
     __shared__ float acc[FBB][REC];
     __shared__ unsigned char s_mask[FBB];
     __shared__ int32_t s_max_last;
-    __shared__ int32_t s_units;
     __shared__ int32_t s_ticket;
+    __shared__ int32_t s_simd[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int comp = reduce_scatter10_component(lane);     // the component this lane adds into acc[][]
+    // Which SIMD is this wave on?  The scheduler plans which SIMD walks which 8x8 block of every item (gfl_sched.hpp,
+    // "block plan"); the plan is followed only if the workgroup's four waves sit on four different SIMDs (they do: the
+    // dispatcher deals a workgroup's waves round the SIMDs), otherwise wave k walks block k.
+    unsigned hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    const int simd = (hw_id >> 4) & 3;
+    if (lane == 0) s_simd[wave] = simd;
+    __syncthreads();
+    const bool simd_ok = ((1 << s_simd[0]) | (1 << s_simd[1]) | (1 << s_simd[2]) | (1 << s_simd[3])) == 15;
   for (bool first = true;; first = false) {
     const TileItem item = next_item(queue, &s_ticket, first, true);
     const int tile = item.tile;
     if (tile < 0) break;
+    const unsigned plan = item.plan;
+    const bool plan_ok = simd_ok && ((1 << (plan & 3)) | (1 << ((plan >> 2) & 3)) | (1 << ((plan >> 4) & 3)) | (1 << ((plan >> 6) & 3))) == 15;
+#ifdef GFL_ROTATE_PARTS
+    // segments of one tile run side by side and their blocks differ a lot ([78 0 77 0] next to [0 69 0 65]): turn the plan by
+    // one SIMD per segment so that they do not all load the same two SIMDs at the same time
+    const int psimd = (simd + (item.part > 0 ? item.part : 0)) & 3;
+#else
+    const int psimd = simd;
+#endif
+    const int blk = plan_ok ? (int)((plan >> (2 * psimd)) & 3u) : wave;         // the 8x8 block of the tile this wave walks
     const int tx = tile % gx, ty = tile / gx;
-    const int px = tx * GFL_TILE + (wave & 1) * 8 + (lane & 7);
-    const int py = ty * GFL_TILE + (wave >> 1) * 8 + (lane >> 3);
+    const int px = tx * GFL_TILE + (blk & 1) * 8 + (lane & 7);
+    const int py = ty * GFL_TILE + (blk >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
     const float fx = (float)px, fy = (float)py;
     const int start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
@@ -789,16 +808,16 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
         } else {
             // state in front of this segment's far boundary, from the forward checkpoint: T as it
             // was there and S = sum_c g_c * (everything blended behind it) = sum_c g_c * (out_c - C_c)
-            const float* ck = ckpt + ((size_t)item.queue * (HEAVY_PARTS - 1) + item.part) * 5 * 256 + tid;
+            const float* ck = ckpt + ((size_t)item.queue * (HEAVY_PARTS - 1) + item.part) * 5 * 256 + blk * 64 + lane;
             T = ck[0];
             S = g0 * (render[pix] - ck[256]) + g1 * (render[plane + pix] - ck[512]) +
                 g2 * (render[2 * plane + pix] - ck[768]) + g3 * (render[3 * plane + pix] - ck[1024]);
         }
     }
-    if (tid == 0) { s_max_last = 0; s_units = 0; }
+    if (tid == 0) s_max_last = 0;
     __syncthreads();
     const unsigned long long alive0 = __ballot(inside);
-    const int px0w = tx * GFL_TILE + (wave & 1) * 8, py0w = ty * GFL_TILE + (wave >> 1) * 8;
+    const int px0w = tx * GFL_TILE + (blk & 1) * 8, py0w = ty * GFL_TILE + (blk >> 1) * 8;
     int wave_last = last;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, off));
@@ -837,7 +856,7 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
         for (int c0 = 0; c0 < cnt; c0 += 64) {
             const int slot = c0 + lane;
             const int spos = hi - 1 - r0 - slot;
-            bool hit = slot < cnt && spos < wave_last && ((s_mask[slot] >> wave) & 1);
+            bool hit = slot < cnt && spos < wave_last && ((s_mask[slot] >> blk) & 1);
             {
                 // as in the forward pass: only the pixels whose last contributor lies at or behind this group of 64
                 // positions can receive anything from it; splats that do not reach their bounding box are skipped
@@ -883,10 +902,8 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
             o[0] = a4[0]; o[1] = a4[1]; o[2] = a4[2];
         }
     }
-    // work feedback for the next iteration's schedule (gfl_sched.hpp)
-    if (lane == 0) atomicAdd(&s_units, units);
-    __syncthreads();
-    if (tid == 0) atomicAdd(&tile_work[tile], s_units + 2);
+    // work feedback for the next iteration's schedule, per 8x8 block (gfl_sched.hpp)
+    if (lane == 0) atomicAdd(&tile_work[4 * tile + blk], units + 1);
 #ifdef GFL_TRACE
     if (lane == 0 && tile < 2048) {
         unsigned hw, xcc;
@@ -898,7 +915,7 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
             tr[2] = ((long long)total << 32) | (unsigned)depth_n;
             tr[3] = ((long long)(xcc & 15) << 32) | hw;
         }
-        tr[4 + wave] = ((long long)trace_lanes << 32) | (unsigned)units;
+        tr[4 + wave] = ((long long)(trace_lanes | ((hw >> 4) & 3) << 28) << 32) | (unsigned)units;   // bits 60-61: this wave's SIMD
     }
 #endif
   }
@@ -1574,11 +1591,11 @@ size_t gfl_fit_workspace_bytes(int cap, int K_cap, int W, int H) {
            + up256((size_t)K_cap * REC * sizeof(float))                             // per-pair gradient rows
            + up256((size_t)(cap > 0 ? cap : 1) * SLOT_MAX * sizeof(int32_t))        // slot -> list position
            + 256 + up256((size_t)K_cap * sizeof(int32_t))                          // counters + slot pool
-           + up256(T * sizeof(int32_t))                                             // scheduler: work feedback
+           + up256(4 * T * sizeof(int32_t))                                         // scheduler: work feedback per 8x8 block
            + up256((size_t)SCHED_MAX_QUEUES * sched_queue_capacity((int)T, 64) * sizeof(int32_t))   // queue items
            + 2 * up256(2 * SCHED_MAX_QUEUES * sizeof(int32_t))                      // queue lengths, pull counters
            + up256((size_t)SCHED_MAX_QUEUES * (HEAVY_PARTS - 1) * 5 * 256 * sizeof(float))                  // heavy-tile checkpoints
-           + 2 * up256(T * sizeof(int32_t))                                         // forward schedule: work feedback; first_slot
+           + up256(4 * T * sizeof(int32_t)) + up256(T * sizeof(int32_t))            // forward schedule: work feedback; first_slot
            + up256((size_t)SCHED_MAX_QUEUES * sched_queue_capacity((int)T, 64) * sizeof(int32_t))   // ... queue items
            + up256(2 * SCHED_MAX_QUEUES * sizeof(int32_t))                          // ... queue lengths
            + up256(gfl_loss_workspace_bytes(W, H)) + 256
@@ -1625,7 +1642,7 @@ static FitWs carve(const gfl_fit_state* st) {
     w.slot_pool = (int32_t*)p;
     p += up256((size_t)st->K_cap * sizeof(int32_t));
     w.sched.work = (int32_t*)p;
-    p += up256(T * sizeof(int32_t));
+    p += up256(4 * T * sizeof(int32_t));
     w.sched.list = (int32_t*)p;
     p += up256((size_t)SCHED_MAX_QUEUES * sched_queue_capacity((int)T, 64) * sizeof(int32_t));
     w.sched.count = (int32_t*)p;
@@ -1639,7 +1656,7 @@ static FitWs carve(const gfl_fit_state* st) {
     w.sched.split_min = 0;
     w.sched_fwd = w.sched;
     w.sched_fwd.work = (int32_t*)p;
-    p += up256(T * sizeof(int32_t));
+    p += up256(4 * T * sizeof(int32_t));
     w.sched_fwd.list = (int32_t*)p;
     p += up256((size_t)SCHED_MAX_QUEUES * sched_queue_capacity((int)T, 64) * sizeof(int32_t));
     w.sched_fwd.count = (int32_t*)p;

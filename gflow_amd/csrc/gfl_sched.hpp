@@ -41,8 +41,8 @@ constexpr int SCHED_MAX_QUEUES = 512;
 constexpr int SCHED_MAX_WEIGHT = 65535;   // weights and tile ids are kept as 16-bit values in LDS
 
 struct Sched {
-    int32_t* work;       // [T]        feedback: units the blend kernel counted per tile in the last iteration (0: none)
-    int32_t* list;       // [nq][cap_q] items of queue c: tile | priority << 28
+    int32_t* work;       // [T][4]     feedback: units the blend kernel counted per 8x8 BLOCK of each tile in the last iteration (0: none)
+    int32_t* list;       // [nq][cap_q] items of queue c: tile | block plan << 16 | priority << 28 (ITEM_* below)
     int32_t* count;      // [nq]       items in each queue
     int32_t* counters;   // [2 nq]     pull counters, forward then backward
     int32_t* first_slot; // [T] or null: queue whose FIRST item the tile is, -1 for the others (backward schedule: the
@@ -53,6 +53,44 @@ struct Sched {
 };
 
 __host__ __device__ inline int sched_queue_capacity(int T, int nq) { return 2 * ((T + nq - 1) / nq) + 8; }
+
+// ---- block plan (round 3).  A blend workgroup has one wave on each of its CU's four SIMDs, a wave walks ONE 8x8 block of the
+// tile, and the blend kernels are issue bound: a CU is done when its BUSIEST SIMD is done.  Measured on a real fit
+// (tools/bwd_trace.py): a CU's finishing time follows the units of its busiest SIMD (r = 0.86-0.90; the CU's total adds
+// nothing), the busiest SIMD carried 7.5 % more than a quarter of its CU on average and up to 46 % more (blocks of one
+// tile differ: [50 64 62 73], [49 0 52 0] at the image's edge), and which SIMD runs wave k of a workgroup is the
+// dispatcher's choice.  So the scheduler also decides, per item, WHICH SIMD walks WHICH block: it keeps the four SIMD
+// loads of every queue and hands the heaviest block of the next tile to the least loaded SIMD and so on (weights = the
+// units each block counted in the last iteration).  A wave reads its SIMD id (HW_REG_HW_ID) and takes the block the
+// plan names for that SIMD.  Encoding: 2 bits per SIMD, plan >> (2 * simd) & 3 = block; identity = 0xE4.
+constexpr int ITEM_PLAN_SHIFT = 16;
+constexpr unsigned ITEM_PLAN_IDENTITY = 0xE4u;
+constexpr int SCHED_PLAN_TILES = 4096;     // tiles with a higher index keep the identity plan (LDS: 4 bytes per tile)
+
+// blocks in descending weight meet SIMDs in ascending load.  key[] carries the four SIMD loads as load * 4 + simd id
+// (any order; updated); bw[] the four block weights.  Two 5-comparator sorting networks on packed keys.
+__device__ __forceinline__ void plan_cswap(int& a, int& b, bool descending) {
+    const int lo = min(a, b), hi = max(a, b);
+    a = descending ? hi : lo;
+    b = descending ? lo : hi;
+}
+__device__ __forceinline__ void plan_sort4(int (&k)[4], bool descending) {
+    plan_cswap(k[0], k[1], descending); plan_cswap(k[2], k[3], descending);
+    plan_cswap(k[0], k[2], descending); plan_cswap(k[1], k[3], descending);
+    plan_cswap(k[1], k[2], descending);
+}
+__device__ __forceinline__ unsigned plan_blocks(const int (&bw)[4], int (&key)[4]) {
+    int b[4] = {(bw[0] >> 2) * 4, (bw[1] >> 2) * 4 + 1, (bw[2] >> 2) * 4 + 2, (bw[3] >> 2) * 4 + 3};
+    plan_sort4(b, true);
+    plan_sort4(key, false);
+    unsigned plan = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        plan |= (unsigned)(b[i] & 3) << (2 * (key[i] & 3));
+        key[i] += b[i] & ~3;
+    }
+    return plan;
+}
 
 // exclusive scan of one int per thread over the workgroup; `total` = sum over all threads
 __device__ __forceinline__ int sched_block_scan(int v, int32_t* wsum, int& total) {
@@ -83,6 +121,7 @@ __device__ void schedule_tiles(const int32_t* __restrict__ tile_counts, int T, c
                                int32_t* wsum) {
     __shared__ int32_t bins[SCHED_BINS];
     __shared__ int32_t s_max, s_lo;
+    __shared__ uint32_t frac4[SCHED_PLAN_TILES];                       // share of each block in its tile's weight, 4 x 8 bits
     unsigned short* w16 = reinterpret_cast<unsigned short*>(lds);      // weight of tile t
     unsigned short* ord16 = w16 + T;                                     // tiles by descending weight
     const int tid = threadIdx.x;
@@ -96,11 +135,21 @@ __device__ void schedule_tiles(const int32_t* __restrict__ tile_counts, int T, c
     __syncthreads();
     int local = 0, lmax = 1;
     for (int t = tid; t < T; t += SCHED_BLOCK) {
-        int x = sc.work[t];
-        if (x <= 0) x = max(tile_counts[t], 1);
+        int4* w4 = reinterpret_cast<int4*>(sc.work) + t;
+        const int4 b = *w4;
+        int x = b.x + b.y + b.z + b.w;
+        uint32_t fr = 0x40404040u;       // no history: four equal blocks
+        if (x > 0) {
+            const float inv = 255.f / (float)x;
+            fr = (uint32_t)((float)b.x * inv) | (uint32_t)((float)b.y * inv) << 8 | (uint32_t)((float)b.z * inv) << 16 |
+                 (uint32_t)((float)b.w * inv) << 24;
+        } else {
+            x = max(tile_counts[t], 1);
+        }
         x = min(x, SCHED_MAX_WEIGHT);
-        sc.work[t] = 0;                  // the backward blend adds this iteration's units
+        *w4 = make_int4(0, 0, 0, 0);     // the blend kernel adds this iteration's units
         w16[t] = (unsigned short)x;
+        if (t < SCHED_PLAN_TILES) frac4[t] = fr;
         local += x;
         lmax = max(lmax, x);
     }
@@ -128,9 +177,16 @@ __device__ void schedule_tiles(const int32_t* __restrict__ tile_counts, int T, c
         ord16[pos] = (unsigned short)t;
     }
     __syncthreads();
+    // (Round 3 measured two ways of tightening the CU balance further, both rejected.  A shared pool of the lightest tiles --
+    // 10-40 % of the weight, pulled with one atomic per tile by whichever workgroup runs out of work -- made the backward
+    // SLOWER, 63 -> 73 / 83 / 100 us for 10 / 20 / 40 %: the pulls of two thousand workgroups queue up on one address.  A
+    // narrower eligibility window of the rounds below (0.25-1.5 x the next tile's weight instead of 2 x) left the
+    // backward at 62.5-63 us while this scheduling workgroup, and with it the scatter launch, grew from 17 to 19-45 us:
+    // what is left of the launch's tail is not the sums of the CUs but the chains of the heaviest tiles' segments.)
     // ---- 3. greedy LPT in batches; thread c < NQ owns queue c
     const int target = (W_total + NQ - 1) / NQ;
     int my_load = 0, my_cnt = 0;
+    int simd_load[4] = {0, 1, 2, 3};                  // units planned onto each SIMD of this queue's CU, as load * 4 + simd id
     int32_t* my_list = sc.list + (size_t)min(tid, NQ - 1) * sc.cap_q;
     int next = 0;
     bool force = false;
@@ -174,7 +230,14 @@ __device__ void schedule_tiles(const int32_t* __restrict__ tile_counts, int T, c
             const int tile = ord16[next + rank];
             const int wt = w16[tile];
             const int prio = next > 0 ? 0 : (wt * 5 >= target * 2 ? 3 : (wt * 4 >= target ? 2 : 1));
-            my_list[my_cnt++] = tile | (prio << 28);
+            unsigned plan = ITEM_PLAN_IDENTITY;
+            if (tile < SCHED_PLAN_TILES) {
+                const uint32_t fr = frac4[tile];
+                const int bw[4] = {(int)(fr & 255u) * wt, (int)((fr >> 8) & 255u) * wt, (int)((fr >> 16) & 255u) * wt,
+                                   (int)(fr >> 24) * wt};
+                plan = plan_blocks(bw, simd_load);
+            }
+            my_list[my_cnt++] = tile | (int)(plan << ITEM_PLAN_SHIFT) | (prio << 28);
             my_load += wt;
             if (next == 0 && sc.first_slot) sc.first_slot[tile] = tid;       // (the barrier after the clearing loop has passed)
         }
@@ -209,14 +272,21 @@ struct TileItem {
     int tile;     // -1: the queue is empty
     int part;
     int queue;
+    unsigned plan;   // block plan (ITEM_PLAN_*): plan >> (2 * simd) & 3 = the block the wave on that SIMD walks
 };
 
 // The heaviest tile of a queue is walked in up to HEAVY_PARTS segments of its list by as many
 // workgroups of the CU (backward); the forward pass leaves a checkpoint at every segment boundary.
 // heavy_parts: number of segments; heavy_seg: their length, a multiple of 64 (the last is shorter).
-constexpr int HEAVY_PARTS = 8;
+#ifndef GFL_HEAVY_PARTS
+#define GFL_HEAVY_PARTS 8
+#endif
+#ifndef GFL_HEAVY_SEG
+#define GFL_HEAVY_SEG 160
+#endif
+constexpr int HEAVY_PARTS = GFL_HEAVY_PARTS;
 __device__ __forceinline__ int heavy_parts(int total) {
-    return total <= 128 ? 1 : min(HEAVY_PARTS, max(2, (total + 159) / 160));
+    return total <= 128 ? 1 : min(HEAVY_PARTS, max(2, (total + GFL_HEAVY_SEG - 1) / GFL_HEAVY_SEG));
 }
 __device__ __forceinline__ int heavy_seg(int total, int parts) { return ((total + parts - 1) / parts + 63) & ~63; }
 
@@ -226,6 +296,7 @@ __device__ __forceinline__ TileItem next_item(const TileQueue& q, int32_t* s_tic
     it.queue = blockIdx.x % q.nq;
     it.part = -1;
     it.tile = -1;
+    it.plan = ITEM_PLAN_IDENTITY;
     int idx = blockIdx.x / q.nq;                     // first pull: the slot number, no atomic
     if (!first) {
         __syncthreads();                             // the previous tile's LDS traffic is complete
@@ -238,8 +309,9 @@ __device__ __forceinline__ TileItem next_item(const TileQueue& q, int32_t* s_tic
     if (split && idx < HEAVY_PARTS) it.part = idx;   // (also when this queue is empty: the forward pass helps other queues)
     if (k >= q.count[it.queue]) return it;
     const int item = q.list[(size_t)it.queue * q.cap_q + k];
-    it.tile = item & 0x0fffffff;
-    const int prio = item >> 28;
+    it.tile = item & 0xffff;
+    it.plan = ((unsigned)item >> ITEM_PLAN_SHIFT) & 0xffu;
+    const int prio = (item >> 28) & 3;
     if (prio == 3) __builtin_amdgcn_s_setprio(3);
     else if (prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (prio == 1) __builtin_amdgcn_s_setprio(1);

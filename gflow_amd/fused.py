@@ -320,12 +320,34 @@ class FitEngine:
         torch.cuda.synchronize(self.dev)
         lst = self.workspace[off_l:off_l + 4 * nq.value * cap.value].view(torch.int32).reshape(nq.value, cap.value).cpu()
         cnt = self.workspace[off_c:off_c + 4 * nq.value].view(torch.int32).cpu()
-        return [(lst[c, :int(cnt[c])] & 0x0fffffff).long() for c in range(nq.value)]
+        return [(lst[c, :int(cnt[c])] & 0xffff).long() for c in range(nq.value)]
 
     def check_overflow(self):
+        """Blocking read of the pair-list overflow flag (sticky on the device); raises if pairs were dropped."""
+        self._ovf_event = None
         if int(self.overflow.item()):
-            self.overflow.zero_()          # the flag is sticky on the device
+            self.overflow.zero_()
             raise RuntimeError(f"FitEngine: more than K_cap={self.K_cap} splat-tile pairs; raise K_cap")
+
+    def watch_overflow(self):
+        """The same check without stopping the host: the flag is copied to pinned memory behind the work queued so
+        far; ``poll_overflow`` (called here first, for the previous watch) raises once that copy has landed and shows
+        dropped pairs.  train() calls this once per frame -- a blocking read there drained the queue between two
+        stages -- and fit_clip ends with the blocking check."""
+        self.poll_overflow()
+        if getattr(self, "_ovf_host", None) is None:
+            self._ovf_host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+        self._ovf_host.copy_(self.overflow, non_blocking=True)
+        self._ovf_event = torch.cuda.Event()
+        self._ovf_event.record()
+
+    def poll_overflow(self):
+        ev = getattr(self, "_ovf_event", None)
+        if ev is not None and ev.query():
+            self._ovf_event = None
+            if int(self._ovf_host[0]):
+                self.overflow.zero_()
+                raise RuntimeError(f"FitEngine: more than K_cap={self.K_cap} splat-tile pairs; raise K_cap")
 
     def loss_terms(self):
         """(loss_rgb, loss_depth) of the last backward_step as device scalars (trainer.py:460-462,485)."""

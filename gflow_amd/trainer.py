@@ -241,17 +241,29 @@ class SimpleGaussian:
         """trainer.py:206-238."""
         num_points = self.num_points if num_points is None else num_points
         self._engine_live = False                    # the attributes are replaced: no longer views of the engine's rows
-        xys, depths, scales, rgbs, gt_depth = complex_texture_sampling(
-            gt_image, gt_depth.cpu(), num_points=num_points, mask=mask, drop_to=drop_to, rng=self.rng)
-        n = xys.shape[0]
-        xys = torch.from_numpy(xys).float().to(self.device)
-        depths = depths.float().to(self.device)
-        self.gt_depth = gt_depth.float().to(self.device)
+        if mask is None and drop_to is None:
+            # everything on the device (sampling.complex_texture_sampling_device): no image / depth / sample round trip
+            from .sampling import complex_texture_sampling_device
+            img = gt_image.to(self.device)
+            self.gt_depth = gt_depth.float().to(self.device)
+            xys, depths, scales, rgbs = complex_texture_sampling_device(img, self.gt_depth, num_points, generator=self.gen)
+            n = xys.shape[0]
+            xys, depths = xys.float(), depths.float()
+            scales = (scales * (depths / depths.min()).squeeze(1).double()).float()
+            rgbs = rgbs.float()
+        else:
+            xys, depths, scales, rgbs, gt_depth = complex_texture_sampling(
+                gt_image, gt_depth.cpu(), num_points=num_points, mask=mask, drop_to=drop_to, rng=self.rng)
+            n = xys.shape[0]
+            xys = torch.from_numpy(xys).float().to(self.device)
+            depths = depths.float().to(self.device)
+            self.gt_depth = gt_depth.float().to(self.device)
+            scales = torch.from_numpy(scales * (depths / depths.min()).squeeze().cpu().numpy()).float().to(self.device)
+            rgbs = torch.from_numpy(rgbs).float().contiguous().to(self.device)
         self._attributes["xyz"] = geometry.pix2world(xys, depths, self.intr, self.get_extr().detach())
-        scales = scales * (depths / depths.min()).squeeze().cpu().numpy()
-        scales = torch.from_numpy(scales).float().unsqueeze(1).repeat(1, 3).to(self.device)
+        scales = scales.unsqueeze(1).repeat(1, 3)
         self._attributes["scale"] = self._activations_inv["scale"](torch.clamp(scales, max=1e-3))
-        rgbs = torch.clamp(torch.from_numpy(rgbs).float().contiguous().to(self.device), 1e-15, 1 - 1e-15)
+        rgbs = torch.clamp(rgbs.contiguous(), 1e-15, 1 - 1e-15)
         self._attributes["rgb"] = self._activations_inv["rgb"](rgbs)
         self._attributes["opacity"] = self._activations_inv["opacity"](0.99 * torch.ones(n, 1, device=self.device))
         self._attributes["rotate"] = F.normalize(torch.rand(n, 4, device=self.device, generator=self.gen))
@@ -312,7 +324,8 @@ class SimpleGaussian:
     def make_stepper(self, iterations=500, lr=1e-2, lr_camera=0.0, lambda_rgb=1.0, lambda_depth=0.0,
                      lambda_flow=0.0, lambda_var=0.0, lambda_still=0.0, lambda_scale=0.0, move_mask=None,
                      densify_interval=500, densify_times=1, mask=None, camera_only=False, densify_occ_percent=0.1,
-                     densify_err_thre=1e-2, densify_err_percent=0.2, snapshot_interval=10, log_interval=0):
+                     densify_err_thre=1e-2, densify_err_percent=0.2, snapshot_interval=10, log_interval=0,
+                     mask_count=None):
         """Set up one ``train`` call (pre-update, fresh Adam + LinearLR, trainer.py:347-384) and
         return a callable that runs ONE iteration of trainer.py:387-582 per call."""
         W, H, dev = self.W, self.H, self.device
@@ -344,7 +357,7 @@ class SimpleGaussian:
                 densify_interval=densify_interval, densify_times=densify_times, mask=mask, camera_only=camera_only,
                 densify_occ_percent=densify_occ_percent, densify_err_thre=densify_err_thre,
                 densify_err_percent=densify_err_percent, snapshot_interval=snapshot_interval,
-                log_interval=log_interval)
+                log_interval=log_interval, mask_count=mask_count)
 
         self.add_optimizer(lr, lr_camera, depth_invariant=True)
         self.scheduler = LinearLR(self.optimizer, start_factor=1.0, end_factor=0.1, total_iters=iterations)
@@ -472,7 +485,7 @@ class SimpleGaussian:
     def _make_fused_stepper(self, iterations, lr, lr_camera, lambda_rgb, lambda_depth, lambda_flow, lambda_var,
                             lambda_still, lambda_scale, move_mask, densify_interval, densify_times, mask, camera_only,
                             densify_occ_percent, densify_err_thre, densify_err_percent, snapshot_interval,
-                            log_interval):
+                            log_interval, mask_count=None):
         """Same iteration as ``make_stepper`` but every step is ONE call into
         libgflow_hip (gfl_fit_iteration): no autograd graph, no torch kernels, no host sync."""
         W, H, dev = self.W, self.H, self.device
@@ -592,7 +605,7 @@ class SimpleGaussian:
                 # (an empty mask appends nothing: densify_by_pixels's own single host read decides, there is no
                 #  separate ``mask.sum() > 0`` read as in trainer.py:563)
                 b, a = self.densify_by_pixels(torch.ones_like(eng.err_px), error_threshold=0.0,
-                                              percent=densify_occ_percent, mask=mask)
+                                              percent=densify_occ_percent, mask=mask, n_masked=mask_count)
                 densified |= a > b
             if (not camera_only and densify_interval and (iteration + 1) % densify_interval == 0
                     and (iteration + 1) // densify_interval <= densify_times):
@@ -647,17 +660,22 @@ class SimpleGaussian:
         st.fn_batch = run
         return st
 
-    def train(self, iterations=500, save_ckpt=False, ckpt_name="ckpt", snapshot_interval=10, **kw):
+    def train(self, iterations=500, save_ckpt=False, ckpt_name="ckpt", snapshot_interval=10, render_parts=True,
+              lazy_images=False, **kw):
         """One call = the optimisation of one frame (trainer.py:332-711); keyword arguments
         as ``make_stepper``.  Returns (frames, frames_center, frames_depth, still_rgb,
         still_center, move_rgb, move_center, move_seg) like the reference; the frame lists
-        hold (H,W,3) uint8 snapshots taken every ``snapshot_interval`` iterations (0 = none)."""
+        hold (H,W,3) uint8 snapshots taken every ``snapshot_interval`` iterations (0 = none).
+        ``render_parts``: the four images of the still / moving splats the reference renders at the end of EVERY train()
+        (trainer.py:632-677); False skips them (None in the tuple).  ``lazy_images``: return without waiting for the
+        images -- they are views of page-locked memory that the device fills behind the queued work; read them after
+        ``torch.cuda.synchronize()``.  (A caller that drops them, like fit_clip, saves one full stop of the host per call.)"""
         W, H, dev = self.W, self.H, self.device
         st = self.make_stepper(iterations=iterations, snapshot_interval=snapshot_interval, **kw)
         st.run(iterations)
         self.train_log = st.log
         if self.fused and self.engine is not None:
-            self.engine.check_overflow()          # one host read per frame: dropped pairs must not go unnoticed
+            self.engine.watch_overflow()          # dropped pairs must not go unnoticed -- without stopping the host here
         camera_only, move_mask = st.camera_only, kw.get("move_mask")
         if move_mask is not None:
             move_mask = move_mask.to(dev).bool()
@@ -692,29 +710,74 @@ class SimpleGaussian:
             self.last_num = self.last_xyz.shape[0]
 
         still_rgb = still_center = move_rgb = move_center = None
-        if hasattr(self, "still_mask") and snapshot_interval:
-            with torch.no_grad():
-                o = render_mod.render_multiple(self._input_group(sel=self.still_mask, detach=True), ["rgb", "center"])
-                still_rgb, still_center = render_mod.render2img(o["rgb"]), render_mod.render2img(o["center"])
-                o = render_mod.render_multiple(self._input_group(sel=~self.still_mask, detach=True), ["rgb", "center"])
-                move_rgb, move_center = render_mod.render2img(o["rgb"]), render_mod.render2img(o["center"])
-                self.rasterisations_done += 2
+        parts_pin = parts_block = None
+        if hasattr(self, "still_mask") and render_parts:
+            if self.fused and self.engine is not None and self.engine.N == self.still_mask.shape[0]:
+                # both renders through the fused kernels on a second engine, the images converted on the device and on
+                # their way to page-locked memory without stopping the host (four operator-path renders and four
+                # blocking copies took ~3 ms per train() call: 4 % of a clip fit)
+                parts_dev = self._render_parts_fused()
+                parts_block = _PINNED.take(parts_dev.numel())
+                parts_pin = parts_block[0][:parts_dev.numel()].view(parts_dev.shape)
+                cs = _copy_stream(dev)
+                cs.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(cs):
+                    parts_pin.copy_(parts_dev, non_blocking=True)
+                parts_dev.record_stream(cs)
+                if getattr(st, "copy_stream", None) is None:
+                    st.copy_stream = cs
+            else:
+                with torch.no_grad():
+                    o = render_mod.render_multiple(self._input_group(sel=self.still_mask, detach=True), ["rgb", "center"])
+                    still_rgb, still_center = render_mod.render2img(o["rgb"]), render_mod.render2img(o["center"])
+                    o = render_mod.render_multiple(self._input_group(sel=~self.still_mask, detach=True), ["rgb", "center"])
+                    move_rgb, move_center = render_mod.render2img(o["rgb"]), render_mod.render2img(o["center"])
+            self.rasterisations_done += 2
         self.last_render = st.last_render.clone()
         if save_ckpt:
             self.save_checkpoint(ckpt_name=ckpt_name)
         # the snapshots stayed on the device as uint8 images: ONE copy to the host per list here, not three
         # blocking copies every 10th iteration (trainer.py:573-582)
         if getattr(st, "copy_stream", None) is not None:
-            st.copy_stream.synchronize()             # fused path: the images are already in pinned host memory
-            to_host = lambda lst: _PINNED.hand_out(st.pin_block, lst)
+            if not lazy_images:
+                st.copy_stream.synchronize()         # fused path: the images are already in pinned host memory
+            to_host = lambda lst: _PINNED.hand_out(st.pin_block, lst) if lst else []
         else:
             to_host = lambda lst: [f for f in torch.stack(lst).cpu().numpy()] if lst else []
+        if parts_pin is not None:
+            still_rgb, still_center, move_rgb, move_center = _PINNED.hand_out(
+                parts_block, [parts_pin[0, 0], parts_pin[0, 2], parts_pin[1, 0], parts_pin[1, 2]])
         out = (to_host(st.frames), to_host(st.frames_center), to_host(st.frames_depth), still_rgb, still_center,
                move_rgb, move_center, self.move_seg)
         if getattr(st, "pin_hold", None) is not None:
             st.frames, st.frames_depth, st.frames_center, st.pin = [], [], [], None
             st.pin_hold()                            # (the stepper and its closure are a cycle: do not wait for the GC)
         return out
+
+    def _render_parts_fused(self):
+        """(2, 3, H, W, 3) uint8 on the device: [still splats, moving splats] x [rgb, depth colour, centre blobs] of the
+        current state (trainer.py:632-677 renders rgb and centre of both sets).  A splat that is not in the set gets a raw
+        opacity of -1000 -- sigmoid(-10^4) = 0 < 1/255, so the preprocess kernel never bins it -- instead of being
+        gathered out: no boolean gather (that is a host read of the count), the depth order of the others is unchanged."""
+        from .fused import FitEngine
+        eng = self.engine
+        n = eng.N
+        aux = getattr(self, "_aux", None)
+        if aux is None or aux.cap < n:
+            aux = self._aux = FitEngine(self.W, self.H, max(eng.cap, n), self.device, bg=self.bg)
+        aux.set_count(n)
+        aux.pose.copy_(eng.pose)
+        aux.intr.copy_(eng.intr)
+        aux.hp.bg = self.bg
+        out = []
+        hidden = torch.full((), -1000.0, device=self.device)
+        for sel in (self.still_mask, ~self.still_mask):
+            aux.params[:n].copy_(eng.params[:n])
+            aux.params[:n, 10] = torch.where(sel, eng.params[:n, 10], hidden)
+            aux.forward()
+            out.append(aux.snapshot())
+        aux.watch_overflow()
+        return torch.stack(out)
 
     # ------------------------------------------------------------ densification
     def densify_weights(self, error_map, error_threshold=1e-3, mask=None):
@@ -753,13 +816,17 @@ class SimpleGaussian:
         new_op = torch.logit(0.99 * torch.ones(k, 1, device=dev)) / 10.0
         return new_xyz, new_scale, new_rot, new_op, new_rgb
 
-    def densify_by_pixels(self, error_map, error_threshold=1e-3, percent=0.1, mask=None):
+    def densify_by_pixels(self, error_map, error_threshold=1e-3, percent=0.1, mask=None, n_masked=None):
         """trainer.py:878-939 on the device.  ONE host read per call -- the number of masked pixels, which fixes how
         many rows are appended (launch sizes and tensor shapes live on the host); the reference moves the whole error
-        map to the host and samples with numpy."""
+        map to the host and samples with numpy.  ``n_masked``: that number, when the caller knows it already (the
+        occlusion mask is an INPUT of the frame: fit_video counts it once when the clip is uploaded) -- no read at all."""
         W = self.W
+        if n_masked == 0:
+            return self.current_pts_num(), self.current_pts_num()
         err, m = self.densify_weights(error_map, error_threshold, mask)
-        n_masked = int(m.sum())                                            # the host read
+        if n_masked is None:
+            n_masked = int(m.sum())                                        # the host read
         densify_num = int(self.num_points * (n_masked / m.numel()) * percent)     # float64 like numpy (:896-901)
         num_before = self.current_pts_num()
         if densify_num > 0:

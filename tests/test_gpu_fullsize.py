@@ -116,6 +116,32 @@ def test_config3_shape_eight_frame_clip_at_480p_60k():
     assert min(psnrs) > 25.0, logs                                 # no frame falls apart along the clip
 
 
+def test_config3_thirty_two_frame_clip_at_480p_60k():
+    """configs[2] at length: a 32-frame 480p / 60k clip with the README iteration counts (500 + 31 x (150 + 300) =
+    14 450 iterations, 62 densification events, 63 train() calls on ONE engine): the pair lists never overflow, the splat
+    count only grows (there is no pruning, trainer.py:841-876 is dead code) and by what the events' formula says, no
+    frame falls apart late in the clip, every parameter stays free of NaN."""
+    from gflow_amd import synthetic as S
+    from gflow_amd.fit_video import fit_clip
+    n_frames = 32
+    frames = S.make_clip(n_frames, H, W, seed=0)
+    logs = []
+    m = fit_clip(frames, DEV, dict(num_points=N), seed=0, log=logs.append)       # (check_overflow() after every train())
+    assert m["frames"] == n_frames and m["iterations"] == 500 + (n_frames - 1) * (150 + 300)
+    psnrs = [float(l.split("psnr ")[1].split(" dB")[0]) for l in logs]
+    counts = [int(l.split("splats ")[1]) for l in logs]
+    assert len(psnrs) == n_frames
+    assert all(b > a for a, b in zip(counts, counts[1:])), counts              # every later frame appends (occlusion mask)
+    assert counts[0] > N and counts[-1] == m["splats_final"]
+    # per later frame: int(N * occ_ratio * 1.0) at iteration 0 plus int(N * err_ratio * 1.0) at iteration 99
+    occ = [int(N * float(fr["occ_mask"].float().mean()) * 1.0) for fr in frames[1:]]
+    assert all(c1 - c0 >= o for c0, c1, o in zip(counts, counts[1:], occ)), (counts, occ)
+    assert min(psnrs) > 25.0 and sum(psnrs) / n_frames > 28.0, psnrs
+    assert min(psnrs[-8:]) > min(psnrs[:8]) - 3.0, psnrs                        # no drift towards the end of the clip
+    print(f"[config 3, {n_frames} frames] psnr min {min(psnrs):.2f} mean {sum(psnrs) / n_frames:.2f} dB, "
+          f"splats {counts[0]} -> {counts[-1]}")
+
+
 def test_config5_720p_200k_with_densification():
     """configs[4]: 720x1280, 200 000 splats, densify_interval = 150, 320 iterations (two densification events):
     no list overflow, finite state, the loss goes down, N grows by int(num_points * mask_ratio * percent) per event."""

@@ -29,6 +29,33 @@ def test_sobel_and_sampler_follow_gradient_magnitude():
     assert abs(sc.sum() - 100.0) < 1e-6
 
 
+def test_device_sampler_draws_from_the_same_distribution():
+    """sampling.complex_texture_sampling_device (what the trainer uses: no host round trip) against the host version:
+    the same probability map to rounding, samples that follow it, the same derived quantities."""
+    from gflow_amd import synthetic as S
+    from gflow_amd.sampling import _probability, complex_texture_sampling_device, texture_probability_device
+    fr = S.make_frame(40, 56, seed=5)
+    image = fr["image"].numpy() * 255
+    gray = (0.299 * image[..., 0] + 0.587 * image[..., 1] + 0.114 * image[..., 2]).astype(np.float32)
+    want = _probability(gray)
+    got = texture_probability_device(fr["image"]).numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-15)
+    n = 200000
+    xys, depths, scales, rgbs = complex_texture_sampling_device(fr["image"], fr["depth"], n,
+                                                                generator=torch.Generator().manual_seed(0))
+    assert xys.shape == (n, 2) and depths.shape == (n, 1) and rgbs.shape == (n, 3) and scales.shape == (n,)
+    flat = (xys[:, 1] * 56 + xys[:, 0]).numpy()
+    counts = np.bincount(flat, minlength=40 * 56).astype(np.float64)
+    expected = want.flatten() * n
+    chi2 = ((counts - expected) ** 2 / expected).sum()
+    dof = 40 * 56 - 1
+    assert abs(chi2 - dof) < 6 * math.sqrt(2 * dof), (chi2, dof)              # a chi-square statistic: mean dof, sd sqrt(2 dof)
+    assert torch.equal(depths, fr["depth"][xys[:, 1], xys[:, 0]])
+    np.testing.assert_allclose(rgbs.numpy(), fr["image"][xys[:, 1], xys[:, 0]].numpy(), atol=1e-6)
+    assert abs(float(scales.sum()) - 100.0) < 1e-6
+    np.testing.assert_allclose(scales.numpy() * (1.0 / want.flatten()[flat]).sum() / 100.0, 1.0 / want.flatten()[flat], rtol=1e-6)
+
+
 def test_pix2world_matches_golden(golden_dir):
     from gflow_amd.geometry import pix2world
     g = np.load(os.path.join(golden_dir, "pix2world.npz"))

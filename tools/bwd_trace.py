@@ -47,6 +47,7 @@ fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert fn(buf, NT) == 0
 a = np.frombuffer(buf, dtype=np.int64).reshape(NT, 8)
+ROWID = np.nonzero(a[:, 0] > a[:, 1].max() - 30000)[0]     # tile + 2048 * (1 + part) for the near segments of heavy tiles
 a = a[a[:, 0] > a[:, 1].max() - 30000]     # last launch only; rows 8192+ are the near halves of split tiles
 np.save(os.path.join(ROOT, "gpurun_out", "bwd_trace.npy"), a)
 t0, t1 = a[:, 0], a[:, 1]
@@ -81,11 +82,53 @@ for r in rows[:6]:
     print("CU end %.1f  units %d  items %d  top items %s  max wave %d" % r)
 for r in rows[-2:]:
     print("CU end %.1f  units %d  items %d  top items %s  max wave %d" % r)
+if "--items" in sys.argv:
+    # item timelines of the three slowest CUs and of a median one
+    idx_rows = np.nonzero(a[:, 0] > a[:, 1].max() - 30000)[0] if False else None
+    order_cu = sorted(groups.items(), key=lambda kv: -max((t1[kv[1]] - base) / 100.0))
+    for c_, ts in order_cu[:3] + [order_cu[len(order_cu) // 2]]:
+        print("CU %x: end %.1f" % (c_, max((t1[ts] - base) / 100.0)))
+        for i in sorted(ts, key=lambda i: t0[i]):
+            print("   row %5d  start %5.1f end %5.1f  entries %4d depth_n %4d  units %s" %
+                  (ROWID[i], (t0[i] - base) / 100.0, (t1[i] - base) / 100.0, total[i], depth_n[i], units[i].tolist()))
 U = np.array([r[1] for r in rows]); E = np.array([r[0] for r in rows])
+# what predicts a CU's finishing time?  least squares  end ~ a units + b list entries + c items + d
+L = np.array([int(total[ts].sum()) for ts in groups.values()], dtype=np.float64)
+I = np.array([len(ts) for ts in groups.values()], dtype=np.float64)
+Uu = np.array([int(units[ts].sum()) for ts in groups.values()], dtype=np.float64)
+Ee = np.array([max((t1[ts] - base) / 100.0) for ts in groups.values()])
+for names, cols in ((("units",), [Uu]), (("units", "items"), [Uu, I]), (("units", "entries"), [Uu, L]),
+                    (("units", "entries", "items"), [Uu, L, I])):
+    A = np.stack(cols + [np.ones_like(Uu)], axis=1)
+    coef, res, *_ = np.linalg.lstsq(A, Ee, rcond=None)
+    pred = A @ coef
+    print("fit end ~", " + ".join(f"{c:.4f} {n}" for c, n in zip(coef, names)), f"+ {coef[-1]:.1f}",
+          f"| residual rms {np.sqrt(np.mean((pred - Ee) ** 2)):.2f} us, corr {np.corrcoef(pred, Ee)[0, 1]:.2f}")
 print("CU units mean %.0f max %d min %d ; end mean %.1f min %.1f max %.1f ; corr(end, units) %.2f" %
       (U.mean(), U.max(), U.min(), E.mean(), E.min(), E.max(), np.corrcoef(E, U)[0, 1]))
 if not FWD:
-    lanes = (a[:, 4:8] >> 32).sum()
+    # per-SIMD view: which SIMD ran wave k of each item, and does the busiest SIMD predict the CU's finishing time?
+    simd = (a[:, 4:8] >> 60) & 3
+    print("wave k -> SIMD histogram (rows: wave 0..3):")
+    for k in range(4):
+        print("  wave", k, np.bincount(simd[:, k], minlength=4))
+    smax, ssum = [], []
+    for ts in groups.values():
+        load = np.zeros(4)
+        for i in ts:
+            for k in range(4):
+                load[simd[i, k]] += units[i, k]
+        smax.append(load.max()); ssum.append(load.sum())
+    smax, ssum = np.array(smax), np.array(ssum)
+    print("busiest SIMD units: mean %.0f max %.0f ; (CU units / 4: mean %.0f)" % (smax.mean(), smax.max(), ssum.mean() / 4))
+    for names, cols in ((("max SIMD units",), [smax]), (("max SIMD units", "CU units"), [smax, ssum]),
+                        (("max SIMD units", "CU units", "entries"), [smax, ssum, L])):
+        A = np.stack(cols + [np.ones_like(smax)], axis=1)
+        coef, *_ = np.linalg.lstsq(A, Ee, rcond=None)
+        pred = A @ coef
+        print("fit end ~", " + ".join(f"{c:.4f} {n}" for c, n in zip(coef, names)), f"+ {coef[-1]:.1f}",
+              f"| residual rms {np.sqrt(np.mean((pred - Ee) ** 2)):.2f} us, corr {np.corrcoef(pred, Ee)[0, 1]:.2f}")
+    lanes = ((a[:, 4:8] >> 32) & 0x0fffffff).sum()
     print("valid lanes per unit: %.1f of 64" % (lanes / max(units.sum(), 1)))
 if FWD:
     done_px = (a[:, 4:8] >> 32).sum(1)

@@ -8,7 +8,7 @@ from gflow_amd import synthetic as S, fit_video as FV
 n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 snap = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dev = torch.device("cuda", 0)
-frames = S.make_clip(n_frames, 480, 854, seed=0)
+frames = FV.upload_clip(S.make_clip(n_frames, 480, 854, seed=0), dev)
 FV.fit_clip(frames[:2], dev, dict(num_points=60000), seed=0, snapshot_interval=snap)
 torch.cuda.synchronize()
 pr = cProfile.Profile()
