@@ -132,6 +132,39 @@ def fit_clip(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, 
                 rasterisations=tr.rasterisations_done, clips=1, splats_final=tr.current_pts_num())
 
 
+def fit_clips_concurrent(clips, device, cfg=None, seeds=None, snapshot_interval=0):
+    """Fit several clips AT THE SAME TIME on ONE device: one host thread and one stream per clip, every clip with its own
+    trainer and engine (nothing is shared but the device).  One fit leaves the chip partly idle -- its kernels are a chain
+    of dependent launches, several of them latency bound with about one wave per SIMD, and the blend launches end with a
+    tail of a few busy CUs -- so the launches of a second and third fit fill the gaps.  Clips are independent (SURVEY.md
+    8e): this is the same sharding as one clip per GPU, applied inside a GPU.  Returns the list of the clips' metrics
+    dicts (fit_clip) in order; the caller times the call."""
+    import threading
+    n = len(clips)
+    seeds = list(range(n)) if seeds is None else seeds
+    results, errors = [None] * n, []
+    dev = torch.device(device)
+
+    def work(i):
+        try:
+            torch.cuda.set_device(dev)
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                results[i] = fit_clip(clips[i], dev, cfg, seed=seeds[i], snapshot_interval=snapshot_interval)
+            stream.synchronize()
+        except BaseException as e:                      # noqa: BLE001 -- re-raised in the caller's thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,), name=f"clip-{i}") for i in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return results
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description="fit synthetic clips, one process per GPU")
     ap.add_argument("--clips", type=int, default=1)

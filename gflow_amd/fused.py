@@ -265,15 +265,28 @@ class FitEngine:
                 self._graphs, self._graph_key = {}, key
             g = self._graphs.get(count)
             if g is None:
+                # capture_begin / capture_end directly: the torch.cuda.graph() context manager synchronises the device,
+                # runs the Python garbage collector and empties the allocator's cache on entry -- a full stop of the fit,
+                # ~60 times per 8-frame clip (the graphs are re-captured whenever N or a hyper-parameter changes) -- to
+                # protect allocations inside the capture; the library allocates nothing.  "thread_local": a capture
+                # in one host thread must not fail because another thread (another clip on the same device,
+                # fit_video.fit_clips_concurrent) reads a value back at that moment.
                 g = torch.cuda.CUDAGraph()
-                side = torch.cuda.Stream(device=self.dev)
-                side.wait_stream(torch.cuda.current_stream())
+                if getattr(self, "_capture_stream", None) is None:
+                    self._capture_stream = torch.cuda.Stream(device=self.dev)
+                side = self._capture_stream
+                cur = torch.cuda.current_stream()
+                st, hp = self.state(), self.hp
+                side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    with torch.cuda.graph(g, stream=side):
+                    g.capture_begin(capture_error_mode="thread_local")
+                    try:
                         for _ in range(count):
-                            L.check(self.lib.gfl_fit_iteration(ctypes.byref(self.state()), ctypes.byref(self.hp),
-                                                               L.stream()), "fit iteration (capture)")
-                torch.cuda.current_stream().wait_stream(side)
+                            L.check(self.lib.gfl_fit_iteration(ctypes.byref(st), ctypes.byref(hp), L.stream()),
+                                    "fit iteration (capture)")
+                    finally:
+                        g.capture_end()
+                cur.wait_stream(side)
                 self._graphs[count] = g
             g.replay()
             return

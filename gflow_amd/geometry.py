@@ -3,7 +3,9 @@ import torch
 
 
 def inv(mat):
-    return torch.linalg.inv(mat)
+    """torch.linalg.inv without its error check (the check reads a status word back from the device: a full stop of
+    the host in the middle of a fit; a singular extrinsic does not occur -- it is a rotation and a translation)."""
+    return torch.linalg.inv_ex(mat, check_errors=False).inverse
 
 
 def depth2pts3d(depth, xys, focal, pp):
@@ -21,6 +23,7 @@ def pix2world(uv, depth, intr, extr):
     Like the reference (geometry.py:105-106) the single focal intr[0] is used for both
     axes."""
     rel = depth2pts3d(depth, uv, intr[0], intr[2:])
-    bottom = torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=extr.device, dtype=extr.dtype)
+    bottom = extr.new_zeros(1, 4)                   # (built on the device: torch.tensor([...], device=) is a blocking copy)
+    bottom[0, 3] = 1.0
     cam2world = inv(torch.cat((extr, bottom), dim=0))
     return geotrf(cam2world, rel)

@@ -71,27 +71,39 @@ class _PinnedPool:
     MAX_BYTES = 4 << 30         # beyond this much page-locked memory the snapshots are handed out as pageable copies
 
     def __init__(self):
+        import threading
         self.blocks = []                                # [uint8 pinned tensor, arrays still alive]
+        self.lock = threading.Lock()                    # several fits may run in one process (fit_clips_concurrent)
 
     def total_bytes(self):
         return sum(b[0].numel() for b in self.blocks)
 
     def take(self, nbytes):
-        for b in self.blocks:
-            if b[1] == 0 and b[0].numel() >= nbytes:
-                return b
-        step = 32 << 20
-        b = [torch.empty((nbytes + step - 1) // step * step, dtype=torch.uint8, pin_memory=True), 0]
-        self.blocks.append(b)
-        return b
+        """a free block of at least ``nbytes``; it counts as taken (one reference) until ``release``"""
+        with self.lock:
+            for b in self.blocks:
+                if b[1] == 0 and b[0].numel() >= nbytes:
+                    b[1] = 1
+                    return b
+            step = 32 << 20
+            b = [torch.empty((nbytes + step - 1) // step * step, dtype=torch.uint8, pin_memory=True), 1]
+            self.blocks.append(b)
+            return b
+
+    def release(self, block):
+        """drop the reference ``take`` left (after ``hold`` / ``hand_out`` have added theirs)"""
+        with self.lock:
+            block[1] -= 1
 
     def hold(self, block, owner):
         """the block stays taken while ``owner`` is alive"""
         import weakref
 
         def gone():
-            block[1] -= 1
-        block[1] += 1
+            with self.lock:
+                block[1] -= 1
+        with self.lock:
+            block[1] += 1
         return weakref.finalize(owner, gone)             # call it to let go early
 
     def hand_out(self, block, tensors):
@@ -99,7 +111,8 @@ class _PinnedPool:
         import weakref
 
         def gone():
-            block[1] -= 1
+            with self.lock:
+                block[1] -= 1
         if self.total_bytes() > self.MAX_BYTES:
             # a caller that keeps every frame's snapshot lists (the reference's fit_video does, to write its videos)
             # would otherwise hold one 110-180 MB page-locked block per train() call: tens of GB over a 60-frame clip
@@ -107,7 +120,8 @@ class _PinnedPool:
         out = []
         for t in tensors:
             a = t.numpy()
-            block[1] += 1
+            with self.lock:
+                block[1] += 1
             weakref.finalize(a, gone)
             out.append(a)
         return out
@@ -118,8 +132,10 @@ _COPY_STREAMS = {}
 
 
 def _copy_stream(dev):
-    """one side stream per device for the snapshot copies (creating a stream per train() call cost 1.4 ms each)"""
-    key = (dev.type, dev.index)
+    """one side stream per device and host thread for the snapshot copies (creating a stream per train() call cost
+    1.4 ms each)"""
+    import threading
+    key = (dev.type, dev.index, threading.get_ident())
     if key not in _COPY_STREAMS:
         _COPY_STREAMS[key] = torch.cuda.Stream(device=dev)
     return _COPY_STREAMS[key]
@@ -214,9 +230,10 @@ class SimpleGaussian:
 
     def load_camera(self, focal=None, pp=None, extr=None, scale=None, show=False):
         if focal is not None:
-            self.intr[:2] = torch.tensor([focal, focal], dtype=torch.float32, device=self.device)
+            self.intr[:2].fill_(float(focal))
         if pp is not None:
-            self.intr[2:] = torch.tensor(pp, dtype=torch.float32, device=self.device)
+            self.intr[2:3].fill_(float(pp[0]))
+            self.intr[3:4].fill_(float(pp[1]))
         if extr is not None:
             extr = torch.as_tensor(extr, dtype=torch.float32, device=self.device)
             T = extr[:3, 3] * (scale if scale is not None else 1.0)
@@ -493,7 +510,8 @@ class SimpleGaussian:
         eng = self._pack_to_engine()
         eng.pose.copy_(self.pose.detach())
         self.pose = eng.pose                       # live: get_extr() follows the optimised pose
-        eng.depth_ab.copy_(torch.tensor([1.0, 0.0], device=dev))     # trainer.py:145-146: reset every train()
+        eng.depth_ab.zero_()                                         # trainer.py:145-146: (a, b) = (1, 0) on every train()
+        eng.depth_ab[0:1].fill_(1.0)                                 # (fills, not torch.tensor(..., device=): that copy blocks)
         self.depth_ab = eng.depth_ab
         eng.intr.copy_(self.intr)
         eng.reset_optimizer()
@@ -572,6 +590,7 @@ class SimpleGaussian:
                     block = _PINNED.take(n_snaps * 3 * H * W * 3)
                     pin = block[0][:n_snaps * 3 * H * W * 3].view(n_snaps, 3, H, W, 3)
                     hold = _PINNED.hold(block, st)                   # ... while this stepper lives
+                    _PINNED.release(block)
                     if st.pin is not None:
                         st.copy_stream.synchronize()
                         pin[:k].copy_(st.pin[:k])
@@ -747,6 +766,7 @@ class SimpleGaussian:
         if parts_pin is not None:
             still_rgb, still_center, move_rgb, move_center = _PINNED.hand_out(
                 parts_block, [parts_pin[0, 0], parts_pin[0, 2], parts_pin[1, 0], parts_pin[1, 2]])
+            _PINNED.release(parts_block)
         out = (to_host(st.frames), to_host(st.frames_center), to_host(st.frames_depth), still_rgb, still_center,
                move_rgb, move_center, self.move_seg)
         if getattr(st, "pin_hold", None) is not None:
@@ -812,7 +832,8 @@ class SimpleGaussian:
         new_xyz = geometry.pix2world(xys, depths, self.intr, self.get_extr().detach())
         new_scale = torch.abs(scales.unsqueeze(1).repeat(1, 3))
         new_rgb = torch.logit(torch.clamp(self.gt_image[ys, xs].contiguous(), 1e-15, 1 - 1e-15))
-        new_rot = torch.tensor([1.0, 0.0, 0.0, 0.0], device=dev).repeat(k, 1)
+        new_rot = torch.zeros(k, 4, device=dev)
+        new_rot[:, 0] = 1.0
         new_op = torch.logit(0.99 * torch.ones(k, 1, device=dev)) / 10.0
         return new_xyz, new_scale, new_rot, new_op, new_rgb
 
