@@ -62,6 +62,15 @@ def _declare(lib):
 
 PROFILE = {"mask": 0}
 
+# Graph captures and graph destruction are serialised process-wide: with several fits in one process
+# (fit_video.fit_clips_concurrent) HIP refuses to destroy a graph while ANY stream is capturing ("operation not permitted
+# when stream is capturing", raised from a destructor: the process dies).  Launches and replays of other threads are not
+# affected (the captures run in "thread_local" mode).
+import gc as _gc
+import threading as _threading
+
+_GRAPH_LOCK = _threading.RLock()
+
 
 def set_profile(mask):
     """Enable the library's per-stage HIP-event timing (bit i = stage i, include/gflow_hip.h)."""
@@ -113,6 +122,13 @@ class FitEngine:
         self._launched = False
         self.busy = False              # checked out by the differentiable operator (gflow_amd.render)
         self._alloc(int(capacity))
+
+    def __del__(self):
+        try:
+            with _GRAPH_LOCK:
+                self._graphs.clear()
+        except Exception:                            # interpreter shutdown
+            pass
 
     # ------------------------------------------------------------------ storage
     def _alloc(self, cap):
@@ -262,7 +278,9 @@ class FitEngine:
         if use_graph and not PROFILE["mask"] and self._launched:
             key = bytes(self.state()) + bytes(self.hp)
             if self._graph_key != key:
-                self._graphs, self._graph_key = {}, key
+                with _GRAPH_LOCK:
+                    self._graphs.clear()             # (the old graphs are destroyed here, under the lock)
+                self._graph_key = key
             g = self._graphs.get(count)
             if g is None:
                 # capture_begin / capture_end directly: the torch.cuda.graph() context manager synchronises the device,
@@ -271,22 +289,29 @@ class FitEngine:
                 # protect allocations inside the capture; the library allocates nothing.  "thread_local": a capture
                 # in one host thread must not fail because another thread (another clip on the same device,
                 # fit_video.fit_clips_concurrent) reads a value back at that moment.
-                g = torch.cuda.CUDAGraph()
                 if getattr(self, "_capture_stream", None) is None:
                     self._capture_stream = torch.cuda.Stream(device=self.dev)
                 side = self._capture_stream
                 cur = torch.cuda.current_stream()
                 st, hp = self.state(), self.hp
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    g.capture_begin(capture_error_mode="thread_local")
+                with _GRAPH_LOCK:
+                    gc_on = _gc.isenabled()
+                    _gc.disable()                    # (a cycle collection inside the capture could destroy an old engine's graphs)
                     try:
-                        for _ in range(count):
-                            L.check(self.lib.gfl_fit_iteration(ctypes.byref(st), ctypes.byref(hp), L.stream()),
-                                    "fit iteration (capture)")
+                        g = torch.cuda.CUDAGraph()
+                        side.wait_stream(cur)
+                        with torch.cuda.stream(side):
+                            g.capture_begin(capture_error_mode="thread_local")
+                            try:
+                                for _ in range(count):
+                                    L.check(self.lib.gfl_fit_iteration(ctypes.byref(st), ctypes.byref(hp), L.stream()),
+                                            "fit iteration (capture)")
+                            finally:
+                                g.capture_end()
+                        cur.wait_stream(side)
                     finally:
-                        g.capture_end()
-                cur.wait_stream(side)
+                        if gc_on:
+                            _gc.enable()
                 self._graphs[count] = g
             g.replay()
             return
