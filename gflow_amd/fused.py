@@ -269,19 +269,31 @@ class FitEngine:
         L.check(self.lib.gfl_fit_backward_step(ctypes.byref(self.state()), ctypes.byref(self.hp), L.stream()),
                 "fit backward/step")
 
-    def iteration(self, use_graph=False, count=1):
-        """``count`` full iterations.  ``use_graph=True`` replays a hipGraph of the launches (captured
+    def iteration(self, use_graph=False, count=1, snapshot=False):
+        """``count`` full iterations; ``snapshot=True`` (count 1): followed by gfl_fit_snapshot into the engine's own
+        image buffer -- returns that (3, H, W, 3) uint8 tensor, which the NEXT snapshot overwrites -- so that the
+        iteration and the eight launches of the snapshot replay as ONE graph (launched one by one they left ~6 us
+        between each other: 40-50 us per snapshot, every tenth iteration of a clip fit).  ``use_graph=True`` replays a hipGraph of the launches (captured
         lazily, re-captured whenever a pointer, a size or a hyper-parameter changed); it is ignored
         while the library's stage profiler is recording events.  Several iterations in ONE graph save the
         2-6 us that pass between two graph launches (tools/graph_gap.py: 0.2094 -> 0.2028, 0.2079 -> 0.2058 ms per
         iteration with two per graph)."""
+        if snapshot:
+            from .color import lut
+            assert count == 1
+            if getattr(self, "_snap_out", None) is None:
+                need = self.lib.gfl_fit_snapshot_workspace_bytes(self.cap, self.W, self.H)
+                self._snap_ws = torch.empty(int(need), dtype=torch.uint8, device=self.dev)
+                self._snap_out = torch.empty(3, self.H, self.W, 3, dtype=torch.uint8, device=self.dev)
+            snap_args = (L.ptr(lut("turbo", self.dev)), L.ptr(self._snap_out), L.ptr(self._snap_ws), self._snap_ws.numel())
+        gkey = ("snap", count) if snapshot else count
         if use_graph and not PROFILE["mask"] and self._launched:
             key = bytes(self.state()) + bytes(self.hp)
             if self._graph_key != key:
                 with _GRAPH_LOCK:
                     self._graphs.clear()             # (the old graphs are destroyed here, under the lock)
                 self._graph_key = key
-            g = self._graphs.get(count)
+            g = self._graphs.get(gkey)
             if g is None:
                 # capture_begin / capture_end directly: the torch.cuda.graph() context manager synchronises the device,
                 # runs the Python garbage collector and empties the allocator's cache on entry -- a full stop of the fit,
@@ -306,19 +318,27 @@ class FitEngine:
                                 for _ in range(count):
                                     L.check(self.lib.gfl_fit_iteration(ctypes.byref(st), ctypes.byref(hp), L.stream()),
                                             "fit iteration (capture)")
+                                if snapshot:
+                                    L.check(self.lib.gfl_fit_snapshot(ctypes.byref(st), ctypes.byref(hp), *snap_args,
+                                                                      L.stream()), "snapshot (capture)")
                             finally:
                                 g.capture_end()
                         cur.wait_stream(side)
                     finally:
                         if gc_on:
                             _gc.enable()
-                self._graphs[count] = g
+                self._graphs[gkey] = g
             g.replay()
-            return
+            return self._snap_out if snapshot else None
         for _ in range(count):
             L.check(self.lib.gfl_fit_iteration(ctypes.byref(self.state()), ctypes.byref(self.hp), L.stream()),
                     "fit iteration")
         self._launched = True          # every kernel is loaded now: capture is safe from here on
+        if snapshot:
+            L.check(self.lib.gfl_fit_snapshot(ctypes.byref(self.state()), ctypes.byref(self.hp), *snap_args, L.stream()),
+                    "snapshot")
+            return self._snap_out
+        return None
 
     def snapshot(self):
         """(3, H, W, 3) uint8 on the device: rgb, depth_map_color, center of the last forward (gfl_fit_snapshot).

@@ -576,11 +576,13 @@ class SimpleGaussian:
             snap = bool(snapshot_interval) and iteration % snapshot_interval == 0
             if tentative:
                 self.rasterisations_done += 1                # the reference's extra render of the moving set
-            eng.iteration(use_graph=self.use_graph)          # one call (or one hipGraph replay)
             if snap:
                 # the three images of THIS iteration's forward (render, records and lists are untouched by the
-                # backward) in one library call; after the backward because it reuses the forward's workspace
-                imgs = eng.snapshot()
+                # backward) behind the iteration, in the same graph launch; the engine's image buffer is free again
+                # once the previous snapshot's copy has left it
+                if getattr(eng, "snap_copy_done", None) is not None:
+                    torch.cuda.current_stream().wait_event(eng.snap_copy_done)
+                imgs = eng.iteration(use_graph=self.use_graph, snapshot=True)
                 # ... and on their way to the host at once, on a copy stream into pinned memory: the reference blocks
                 # on three device-to-host copies here; 150 images per first-frame fit cost ~40 ms as one pageable copy
                 k = len(st.frames)
@@ -601,10 +603,13 @@ class SimpleGaussian:
                 st.copy_stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(st.copy_stream):
                     st.pin[k].copy_(imgs, non_blocking=True)
-                imgs.record_stream(st.copy_stream)
+                    eng.snap_copy_done = torch.cuda.Event()
+                    eng.snap_copy_done.record()
                 st.frames.append(st.pin[k, 0])
                 st.frames_depth.append(st.pin[k, 1])
                 st.frames_center.append(st.pin[k, 2])
+            else:
+                eng.iteration(use_graph=self.use_graph)      # one call (or one hipGraph replay)
             self.rasterisations_done += 1
             self.iterations_done += 1
             rec_now = eng.rec                        # (densification may re-allocate the engine's buffers below)
