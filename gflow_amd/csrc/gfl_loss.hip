@@ -69,6 +69,7 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
 
 __global__ void step_inc_kernel(int32_t* d_step) { *d_step += 1; }
 
+
 }  // namespace gfl
 
 using namespace gfl;

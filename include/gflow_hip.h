@@ -276,7 +276,9 @@ typedef struct gfl_fit_hyper {
     float lr, lr_camera, beta1, beta2, eps, lr_end_factor;
     int32_t total_iters;       /* LinearLR total_iters, 0 = constant lr */
     int32_t freeze_rgb;        /* trainer.py:537-540 */
-    int32_t freeze_all_splats; /* camera_only, trainer.py:548-551 */
+    int32_t freeze_all_splats; /* camera_only, trainer.py:548-551: every splat gradient is zeroed.  The rows and their Adam moments
+                                * are then left untouched (not read, not written): what Adam does with zero gradients and
+                                * the zero moments a fresh optimiser starts from (trainer.py:383) */
     int32_t step_camera;       /* 0 after densification replaced the optimiser (trainer.py:951) */
 } gfl_fit_hyper;
 

@@ -117,3 +117,4 @@ def test_block_culling_never_drops_a_visible_pixel(box):
     assert needed > 50_000                                                   # the sample does exercise visible boxes
     print(f"box {box}: {let_through} boxes let through for {needed} with a visible pixel ({let_through / needed:.3f}x)")
     assert let_through <= 1.06 * needed, (let_through, needed)               # measured 1.02x (continuous box, margins)
+
