@@ -304,7 +304,12 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* _
     const int T = gx * gy;
     if (blockIdx.x >= gridDim.x - 2) {
         // two extra workgroups (the launch leaves CUs idle) build the blend kernels' tile queues
-        schedule_tiles(tile_counts, T, blockIdx.x == gridDim.x - 1 ? sched_bwd : sched_fwd, cursor, wsum);
+        __shared__ SchedLds sched_lds;
+        const Sched sc = blockIdx.x == gridDim.x - 1 ? sched_bwd : sched_fwd;
+        if (sc.xcd && T <= SCHED_PLAN_TILES && sc.nq % 8 == 0 && sc.nq / 8 <= 64)
+            schedule_tiles_xcd(tile_counts, T, sc, cursor, wsum, sched_lds);
+        else
+            schedule_tiles(tile_counts, T, sc, cursor, wsum, sched_lds);
         return;
     }
     const int32_t* base_row = hist_g + (size_t)blockIdx.x * T;
@@ -1555,6 +1560,17 @@ static bool camera_own_launch() {
     return v == 1;
 }
 
+// XCD-local bands + LPT in rounds (gfl_sched.hpp: schedule_tiles_xcd) -- the default; GFL_SCHED_XCD=0: the batched LPT over
+// all queues of rounds 1-2 (schedule_tiles)
+static int sched_xcd() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GFL_SCHED_XCD");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v;
+}
+
 // list length from which the forward blend walks a queue's first tile as four blocks (GFL_FWD_SPLIT_MIN overrides)
 static int fwd_split_min() {
     static int v = -1;
@@ -1657,8 +1673,11 @@ static FitWs carve(const gfl_fit_state* st) {
     w.ckpt = (float*)p;
     p += up256((size_t)SCHED_MAX_QUEUES * (HEAVY_PARTS - 1) * 5 * 256 * sizeof(float));
     w.sched.nq = blend_queues();
-    w.sched.cap_q = sched_queue_capacity((int)T, w.sched.nq);
+    // (the list is sized for 512 queues: with fewer queues each may hold more -- a band of the XCD-local schedule
+    //  can have many more tiles than T / 8)
+    w.sched.cap_q = (int)(((size_t)SCHED_MAX_QUEUES * sched_queue_capacity((int)T, 64)) / w.sched.nq);
     w.sched.split_min = 0;
+    w.sched.xcd = sched_xcd();
     w.sched_fwd = w.sched;
     w.sched_fwd.work = (int32_t*)p;
     p += up256(4 * T * sizeof(int32_t));
@@ -1698,7 +1717,7 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
     const FitWs w = carve(st);
     const int nblk = fit_nblk(st->N > 0 ? st->N : 1);
     const size_t lds = (size_t)T * sizeof(int32_t);
-    if (lds > 64 * 1024) return GFL_ERR_INVALID;   // tile grid too large for the LDS histogram
+    if (lds > 42 * 1024) return GFL_ERR_INVALID;   // tile grid too large for the LDS histogram (+ 21 KB of scheduler state: 64 KB)
     {
         StageScope p(ST_PREPROCESS, s);
         auto kern = ewa_on_mfma() ? fused_preprocess_fwd_kernel<true> : fused_preprocess_fwd_kernel<false>;

@@ -50,6 +50,7 @@ struct Sched {
     int nq;              // queues (= CUs)
     int cap_q;           // capacity of one queue
     int split_min;       // forward schedule: a first tile with a longer list is walked on four CUs; 0: never
+    int xcd;             // 1: XCD-local bands + snake deal (schedule_tiles_xcd) instead of the batched LPT
 };
 
 __host__ __device__ inline int sched_queue_capacity(int T, int nq) { return 2 * ((T + nq - 1) / nq) + 8; }
@@ -115,13 +116,23 @@ __device__ __forceinline__ int sched_block_scan(int v, int32_t* wsum, int& total
     return wprefix + sc - v;
 }
 
+// static LDS of the scheduling workgroup, declared ONCE in the kernel that calls either scheduler
+struct SchedLds {
+    int32_t bins[SCHED_BINS];
+    uint32_t frac4[SCHED_PLAN_TILES];     // share of each block in its tile's weight, 4 x 8 bits
+    int32_t s_max, s_lo;
+    int32_t g_base[9];
+    int32_t rank[SCHED_BLOCK];
+};
+
 // lds: scratch of T ints (used as two 16-bit arrays); wsum: LDS scratch of SCHED_BLOCK / 64 ints.
 // Whole workgroup.
 __device__ void schedule_tiles(const int32_t* __restrict__ tile_counts, int T, const Sched sc, int32_t* lds,
-                               int32_t* wsum) {
-    __shared__ int32_t bins[SCHED_BINS];
-    __shared__ int32_t s_max, s_lo;
-    __shared__ uint32_t frac4[SCHED_PLAN_TILES];                       // share of each block in its tile's weight, 4 x 8 bits
+                               int32_t* wsum, SchedLds& sl) {
+    int32_t (&bins)[SCHED_BINS] = sl.bins;
+    int32_t& s_max = sl.s_max;
+    int32_t& s_lo = sl.s_lo;
+    uint32_t (&frac4)[SCHED_PLAN_TILES] = sl.frac4;
     unsigned short* w16 = reinterpret_cast<unsigned short*>(lds);      // weight of tile t
     unsigned short* ord16 = w16 + T;                                     // tiles by descending weight
     const int tid = threadIdx.x;
@@ -255,6 +266,194 @@ __device__ void schedule_tiles(const int32_t* __restrict__ tile_counts, int T, c
         next += min(m, avail);
     }
     if (tid < NQ) sc.count[tid] = my_cnt;
+}
+
+// value of lane (lane ^ D), D in {1, 2, 4, 8, 16}, on the VALU only (DPP / v_permlane16_swap; see gfl_tile_sort.hpp)
+template <int D>
+__device__ __forceinline__ unsigned sched_xor_lane(unsigned v, int lane) {
+    const int x = (int)v;
+    if constexpr (D == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);
+    else if constexpr (D == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);
+    else if constexpr (D == 4) {
+        int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);
+        t = __builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);
+        return (unsigned)t;
+    } else if constexpr (D == 8) return (unsigned)__builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, true);
+    else {
+        float a = __builtin_bit_cast(float, v), b = a;
+        permlane16_swap(a, b);
+        return __builtin_bit_cast(unsigned, (lane & 16) ? a : b);
+    }
+}
+template <int D>
+__device__ __forceinline__ void sched_cx(unsigned& key, int k, int lane) {
+    const unsigned other = sched_xor_lane<D>(key, lane);
+    const bool take_min = ((lane & D) == 0) == ((lane & 31 & k) == 0);
+    key = ((key < other) == take_min) ? key : other;
+}
+// ascending bitonic sort of one unique 32-bit key per lane inside each 32-lane half of the wave (15 exchange steps)
+__device__ __forceinline__ unsigned sched_sort32(unsigned key, int lane) {
+    sched_cx<1>(key, 2, lane);
+    sched_cx<2>(key, 4, lane); sched_cx<1>(key, 4, lane);
+    sched_cx<4>(key, 8, lane); sched_cx<2>(key, 8, lane); sched_cx<1>(key, 8, lane);
+    sched_cx<8>(key, 16, lane); sched_cx<4>(key, 16, lane); sched_cx<2>(key, 16, lane); sched_cx<1>(key, 16, lane);
+    sched_cx<16>(key, 32, lane); sched_cx<8>(key, 32, lane); sched_cx<4>(key, 32, lane); sched_cx<2>(key, 32, lane);
+    sched_cx<1>(key, 32, lane);
+    return key;
+}
+
+// ---- XCD-local schedule (round 3; GFL_SCHED_XCD=1).
+// The dispatcher places workgroup b on XCD b % 8 and every XCD has its own L2.  With the queues above a tile lands on
+// whichever CU balances the loads, so every XCD ends up walking tiles from all over the image and pulls (nearly) ALL
+// splat records through its own L2: the blend kernels fetched the 2.9 MB of records eight times (19.7 MB read by the
+// forward against 10.7 algorithmic, rocprofv3 FETCH_SIZE).  Here the image is first cut into eight horizontal BANDS of
+// equal weight (a prefix sum of the tile weights in row-major order), band x belongs to the queues q with q % 8 == x, and
+// inside a band the tiles are dealt in order of descending weight in a snake over the band's queues (stripe k forwards,
+// stripe k + 1 backwards): no iterative rounds at all -- the scheduling workgroup is no longer the long pole of the
+// scatter launch.  The first tile of every queue is still one of the band's heaviest (segments / four-CU walk), the
+// block plans are made per queue in order.  Needs nq % 8 == 0 and nq / 8 <= 64; otherwise the caller uses schedule_tiles.
+__device__ void schedule_tiles_xcd(const int32_t* __restrict__ tile_counts, int T, const Sched sc, int32_t* lds, int32_t* wsum,
+                                   SchedLds& sl) {
+    int32_t (&bins)[SCHED_BINS] = sl.bins;
+    int32_t& s_max = sl.s_max;
+    uint32_t (&frac4)[SCHED_PLAN_TILES] = sl.frac4;
+    int32_t (&g_base)[9] = sl.g_base;
+    unsigned short* w16 = reinterpret_cast<unsigned short*>(lds);      // weight of tile t
+    unsigned short* ord16 = w16 + T;                                     // tiles by (band, descending weight)
+    const int tid = threadIdx.x;
+    const int NQ = sc.nq, NQG = NQ / 8;
+    if (tid == 0) s_max = 1;
+    for (int b = tid; b < SCHED_BINS; b += SCHED_BLOCK) bins[b] = 0;
+    for (int c = tid; c < 2 * NQ; c += SCHED_BLOCK) sc.counters[c] = 0;
+    if (sc.first_slot)
+        for (int t = tid; t < T; t += SCHED_BLOCK) sc.first_slot[t] = -1;
+    __syncthreads();
+    // ---- weights; thread tid owns the CONTIGUOUS tiles [tid * per, (tid + 1) * per) (row-major order = bands)
+    const int per = (T + SCHED_BLOCK - 1) / SCHED_BLOCK;
+    const int t_lo = tid * per, t_hi = min(T, t_lo + per);
+    int local = 0, lmax = 1;
+    for (int t = t_lo; t < t_hi; ++t) {
+        int4* w4 = reinterpret_cast<int4*>(sc.work) + t;
+        const int4 b = *w4;
+        int x = b.x + b.y + b.z + b.w;
+        uint32_t fr = 0x40404040u;
+        if (x > 0) {
+            const float inv = 255.f / (float)x;
+            fr = (uint32_t)((float)b.x * inv) | (uint32_t)((float)b.y * inv) << 8 | (uint32_t)((float)b.z * inv) << 16 |
+                 (uint32_t)((float)b.w * inv) << 24;
+        } else {
+            x = max(tile_counts[t], 1);
+        }
+        x = min(x, SCHED_MAX_WEIGHT);
+        *w4 = make_int4(0, 0, 0, 0);
+        w16[t] = (unsigned short)x;
+        if (t < SCHED_PLAN_TILES) frac4[t] = fr;
+        local += x;
+        lmax = max(lmax, x);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) lmax = max(lmax, __shfl_xor(lmax, off));
+    if ((tid & 63) == 0) atomicMax(&s_max, lmax);
+    int W_total;
+    int run = sched_block_scan(local, wsum, W_total);      // weight in front of this thread's tiles (+ the barriers)
+    int shift = 0;
+    while ((s_max >> shift) >= 128) ++shift;
+    // ---- counting sort by (band, descending weight); the band of a tile = where its prefix weight falls
+    const long long Wt = max(W_total, 1);
+    for (int t = t_lo; t < t_hi; ++t) {
+        const int band = min(7, (int)(((long long)run * 8) / Wt));
+        run += w16[t];
+        ord16[t] = (unsigned short)band;                   // (parked here until the scatter below)
+        atomicAdd(&bins[band * 128 + 127 - (w16[t] >> shift)], 1);
+    }
+    __syncthreads();
+    {
+        const int a = bins[2 * tid], b = bins[2 * tid + 1];
+        int tot;
+        const int excl = sched_block_scan(a + b, wsum, tot);
+        bins[2 * tid] = excl;
+        bins[2 * tid + 1] = excl + a;
+    }
+    __syncthreads();
+    if (tid < 8) g_base[tid] = bins[tid * 128];
+    if (tid == 8) g_base[8] = T;
+    // (T <= 4096 = SCHED_PLAN_TILES here, i.e. at most 8 tiles per thread: every parked band is read before any sorted
+    //  position is written)
+    int my_pos[8];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int t = t_lo + k;
+        if (k < per && t < t_hi) my_pos[k] = atomicAdd(&bins[(int)ord16[t] * 128 + 127 - (w16[t] >> shift)], 1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int t = t_lo + k;
+        if (k < per && t < t_hi) ord16[my_pos[k]] = (unsigned short)t;
+    }
+    __syncthreads();
+    // ---- deal, band by band: LPT in rounds.  Thread x * NQG + j owns queue q = j * 8 + x, so the NQG queues of a band sit
+    // in NQG consecutive lanes (NQG <= 64 and a power of two dividing 64, or the band's ranks are taken with the snake
+    // below).  Round k hands the band's tiles k * NQG ... (k + 1) * NQG - 1 (descending weight) to the queues in order of
+    // ASCENDING load: the least loaded queue takes the heaviest tile of the round (ranks by wave shuffles, no LDS, no
+    // barrier -- the batched LPT above needs six barriers per round).
+    const int target = (W_total + NQ - 1) / NQ;
+    const bool ranked = NQG == 32;                       // (ranks by a 32-lane register sort; other queue counts: the snake)
+    if (tid < NQ) {
+        const int x = tid / NQG, j = tid % NQG;
+        const int q = j * 8 + x;
+        const int b0 = g_base[x], cnt = g_base[x + 1] - b0;
+        int32_t* my_list = sc.list + (size_t)q * sc.cap_q;
+        int key[4] = {0, 1, 2, 3};
+        int load = 0, n_items = 0;
+        const int lane = tid & 63;
+        const int rounds = (cnt + NQG - 1) / NQG;                      // (uniform over the band's lanes)
+        for (int k = 0; k < rounds && k < sc.cap_q; ++k) {
+            int rank = (k & 1) ? NQG - 1 - j : j;                      // snake (also the first round: all loads are zero)
+            if (ranked && k > 0) {
+                // rank of this queue's load among its band's 32: a register bitonic sort of (load, lane) over the
+                // half-wave -- 15 DPP / permlane steps -- and the inverse permutation through LDS.  (32 ds_bpermute
+                // shuffles per round made this workgroup 13 us slower, 64 v_readlane broadcasts 20 us: its four waves
+                // are alone on their SIMDs and issue every ~8 cycles.)
+                const unsigned sorted = sched_sort32(((unsigned)max(load, 0) << 6) | (unsigned)j, lane);
+                sl.rank[(tid - j) + (int)(sorted & 63u)] = j;          // lane j of the half now holds the rank-j queue's key
+                rank = sl.rank[tid];
+            }
+            const int p = k * NQG + rank;
+            if (p < cnt) {
+                const int tile = ord16[b0 + p];
+                const int wt = w16[tile];
+                const int prio = k > 0 ? 0 : (wt * 5 >= target * 2 ? 3 : (wt * 4 >= target ? 2 : 1));
+                unsigned plan = ITEM_PLAN_IDENTITY;
+                if (tile < SCHED_PLAN_TILES) {
+                    const uint32_t fr = frac4[tile];
+                    const int bw[4] = {(int)(fr & 255u) * wt, (int)((fr >> 8) & 255u) * wt, (int)((fr >> 16) & 255u) * wt,
+                                       (int)(fr >> 24) * wt};
+                    plan = plan_blocks(bw, key);
+                }
+                my_list[n_items] = tile | (int)(plan << ITEM_PLAN_SHIFT) | (prio << 28);
+                if (n_items == 0 && sc.first_slot) sc.first_slot[tile] = q;
+                ++n_items;
+                load += wt;
+            }
+            if (k == 0 && sc.split_min > 0) {
+                // forward schedule: a long first tile costs its own CU a quarter, the other three quarters go to the queues
+                // that help it (next_item: items 1..3 of queue q walk blocks of the first tile of queue q + p nq/4)
+                if (cnt > j && tile_counts[ord16[b0 + j]] > sc.split_min) load -= w16[ord16[b0 + j]] - (w16[ord16[b0 + j]] >> 2);
+#pragma unroll
+                for (int b = 1; b < 4; ++b) {
+                    const int owner = (q + b * (NQ / 4)) % NQ;
+                    const int ox = owner & 7, oj = owner >> 3;
+                    if (g_base[ox + 1] - g_base[ox] > oj) {
+                        const int ot = ord16[g_base[ox] + oj];
+                        if (tile_counts[ot] > sc.split_min) load += w16[ot] >> 2;
+                    }
+                }
+            }
+        }
+        sc.count[q] = n_items;
+    }
 }
 
 // ---- consumer side

@@ -23,7 +23,8 @@ def pix2world(uv, depth, intr, extr):
     Like the reference (geometry.py:105-106) the single focal intr[0] is used for both
     axes."""
     rel = depth2pts3d(depth, uv, intr[0], intr[2:])
-    bottom = extr.new_zeros(1, 4)                   # (built on the device: torch.tensor([...], device=) is a blocking copy)
-    bottom[0, 3] = 1.0
-    cam2world = inv(torch.cat((extr, bottom), dim=0))
-    return geotrf(cam2world, rel)
+    # camera -> world of the rigid world -> camera transform [R | t]: [R^T | -R^T t].  The reference inverts the 4x4
+    # numerically (geometry.py:107); for a rotation + translation that is the same matrix up to rounding, and the
+    # closed form is three small kernels instead of an LU factorisation in the middle of a fit
+    Rt = extr[:3, :3].T
+    return rel @ Rt.T + (-(Rt @ extr[:3, 3]))
