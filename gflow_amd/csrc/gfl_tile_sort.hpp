@@ -152,7 +152,10 @@ __global__ void __launch_bounds__(SORT_THREADS, 8) bin_tile_sort_kernel(const in
                                                                         int32_t* __restrict__ slot_inv,
                                                                         int32_t* __restrict__ slot_pool, int gx, int gy) {
     __shared__ unsigned long long sk[SORT_THREADS];      // cross-wave exchange buffer
-    const int tile = blockIdx.x;
+    // XCD x sorts one contiguous range of tiles (the dispatcher places workgroup b on XCD b % 8): the records the slot
+    // table needs (uv, radius of every key's splat) are those of neighbouring tiles; with block = tile every XCD pulled
+    // all of them through its own L2 (22 MB read for 3.9 MB of keys, rocprofv3 FETCH_SIZE)
+    const int tile = xcd_logical_block((int)blockIdx.x, (int)gridDim.x);
     SORT_TRACE(0);
     const int start = min(offsets[tile], K_cap);
     const int end = min(offsets[tile + 1], K_cap);

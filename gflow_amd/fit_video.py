@@ -86,21 +86,35 @@ def fit_clip(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, 
     (``extr``, read from the sequence's camera files) load it before they are fitted
     (fit_video.py:115-116, :252-253)."""
     dev_ = torch.device(device)
+    g = fit_clip_steps(frames, device, cfg=cfg, seed=seed, snapshot_interval=snapshot_interval, fused=fused, log=log,
+                       load_extr=load_extr, chunk=None)
+
+    def drive():
+        try:
+            while True:
+                next(g)
+        except StopIteration as e:
+            return e.value
+
     if dev_.type == "cuda" and torch.cuda.current_stream(dev_) == torch.cuda.default_stream(dev_):
         # Never fit on the default stream: it is HIP's legacy NULL stream, which every other (blocking) stream
         # synchronises with -- the snapshot copies on the copy stream then run BETWEEN the fit's launches instead of
         # beside them (measured: the same 8-frame clip fit 0.95 s on a stream of its own, 1.09 s on the default stream).
-        import threading
-        key = (dev_.index, threading.get_ident())
+        key = dev_.index
         if key not in _FIT_STREAMS:
             _FIT_STREAMS[key] = torch.cuda.Stream(device=dev_)
         fs = _FIT_STREAMS[key]
         fs.wait_stream(torch.cuda.current_stream(dev_))
         with torch.cuda.stream(fs):
-            out = fit_clip(frames, device, cfg=cfg, seed=seed, snapshot_interval=snapshot_interval, fused=fused, log=log,
-                           load_extr=load_extr)
+            out = drive()
         torch.cuda.current_stream(dev_).wait_stream(fs)
         return out
+    return drive()
+
+
+def fit_clip_steps(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, log=None, load_extr=True, chunk=None):
+    """fit_clip as a generator: yields after every ``chunk`` iterations of a stage (None: never) and returns the metrics
+    dict.  The caller owns the stream the work is enqueued on (fit_clips_concurrent gives every clip its own)."""
     from .trainer import SimpleGaussian
     c = dict(DEFAULTS)
     c.update(cfg or {})
@@ -116,11 +130,12 @@ def fit_clip(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, 
     common = dict(lambda_rgb=c["lambda_rgb"], lambda_depth=c["lambda_depth"], lambda_scale=c["lambda_scale"],
                   densify_occ_percent=c["densify_occ_percent"], densify_err_thre=c["densify_err_thre"],
                   densify_err_percent=c["densify_err_percent"], snapshot_interval=snapshot_interval,
-                  lazy_images=True)        # (the image lists train() returns are not read here: do not wait for them)
+                  lazy_images=True,        # (the image lists train() returns are not read here: do not wait for them)
+                  chunk=chunk)
     # first frame (fit_video.py:119-142)
-    tr.train(iterations=c["iterations_first"], lr=c["lr"], lr_camera=c["lr_camera"], lambda_var=c["lambda_var"],
-             densify_interval=c["densify_interval"], densify_times=c["densify_times"], move_mask=f0["move_mask"],
-             **common)
+    yield from tr.train_steps(iterations=c["iterations_first"], lr=c["lr"], lr_camera=c["lr_camera"],
+                              lambda_var=c["lambda_var"], densify_interval=c["densify_interval"],
+                              densify_times=c["densify_times"], move_mask=f0["move_mask"], **common)
     # (PSNR stays on the device and is read ONCE at the end of the clip: a float() per frame drained the queue between
     #  two frames; with a log callback the caller asked for the numbers as they come)
     psnr_sum = tr.psnr().double()
@@ -133,14 +148,16 @@ def fit_clip(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, 
         if load_extr and fr.get("extr") is not None:
             tr.load_camera(extr=fr["extr"])              # fit_video.py:252-253
         if c["camera_first"]:                            # fit_video.py:256-278
-            tr.train(iterations=c["iterations_camera"], lr_camera=c["lr_camera_after"], lambda_var=0.0,
-                     lambda_still=0.0, lambda_flow=c["lambda_flow"], densify_interval=c["densify_interval"],
-                     densify_times=c["densify_times"], camera_only=True, move_mask=fr["move_mask"], **common)
+            yield from tr.train_steps(iterations=c["iterations_camera"], lr_camera=c["lr_camera_after"], lambda_var=0.0,
+                                      lambda_still=0.0, lambda_flow=c["lambda_flow"],
+                                      densify_interval=c["densify_interval"], densify_times=c["densify_times"],
+                                      camera_only=True, move_mask=fr["move_mask"], **common)
         if c["iterations_after"] > 0:                    # fit_video.py:288-315
-            tr.train(iterations=c["iterations_after"], lr=c["lr_after"], lr_camera=0.0, lambda_var=c["lambda_var"],
-                     lambda_still=c["lambda_still"], lambda_flow=c["lambda_flow"],
-                     densify_interval=c["densify_interval_after"], densify_times=c["densify_times_after"],
-                     mask=fr.get("occ_mask"), mask_count=fr.get("occ_count"), move_mask=fr["move_mask"], **common)
+            yield from tr.train_steps(iterations=c["iterations_after"], lr=c["lr_after"], lr_camera=0.0,
+                                      lambda_var=c["lambda_var"], lambda_still=c["lambda_still"],
+                                      lambda_flow=c["lambda_flow"], densify_interval=c["densify_interval_after"],
+                                      densify_times=c["densify_times_after"], mask=fr.get("occ_mask"),
+                                      mask_count=fr.get("occ_count"), move_mask=fr["move_mask"], **common)
         p = tr.psnr()
         psnr_sum = psnr_sum + p.double()
         if log:
@@ -151,38 +168,40 @@ def fit_clip(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, 
                 rasterisations=tr.rasterisations_done, clips=1, splats_final=tr.current_pts_num())
 
 
-def fit_clips_concurrent(clips, device, cfg=None, seeds=None, snapshot_interval=0):
-    """Fit several clips AT THE SAME TIME on ONE device: one host thread and one stream per clip, every clip with its own
-    trainer and engine (nothing is shared but the device).  One fit leaves the chip partly idle -- its kernels are a chain
-    of dependent launches, several of them latency bound with about one wave per SIMD, and the blend launches end with a
-    tail of a few busy CUs -- so the launches of a second and third fit fill the gaps.  Clips are independent (SURVEY.md
-    8e): this is the same sharding as one clip per GPU, applied inside a GPU.  Returns the list of the clips' metrics
-    dicts (fit_clip) in order; the caller times the call."""
-    import threading
+def fit_clips_concurrent(clips, device, cfg=None, seeds=None, snapshot_interval=0, chunk=32):
+    """Fit several clips AT THE SAME TIME on ONE device, in one host thread: every clip has its own trainer, engine and
+    STREAM, and the clips take turns enqueueing ``chunk`` iterations each (fit_clip_steps), so their graph launches
+    interleave on the device.  One fit leaves the chip partly idle -- its kernels are a chain of dependent launches,
+    several of them latency bound with about one wave per SIMD, and the blend launches end with a tail of a few busy CUs
+    -- so the launches of a second and third fit fill the gaps.  Clips are independent: this is the same
+    sharding as one clip per GPU, applied inside a GPU.  A value read back by one fit (a densification event) stops
+    the host only until THAT fit's stream has caught up; the others have their chunks queued meanwhile.
+    (One host thread on purpose: with a thread per clip, graph captures of one thread and launches / allocations of
+    another crashed inside the HIP runtime of ROCm 7.2 about once in four runs -- aborts in hipGraphDestroy, segmentation
+    faults beside hipStreamEndCapture, silent exits.)  Returns the clips' metrics dicts in order; the caller times the call."""
     n = len(clips)
     seeds = list(range(n)) if seeds is None else seeds
-    results, errors = [None] * n, []
     dev = torch.device(device)
     if dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
-
-    def work(i):
-        try:
-            torch.cuda.set_device(dev)
-            stream = torch.cuda.Stream(device=dev)
-            with torch.cuda.stream(stream):
-                results[i] = fit_clip(clips[i], dev, cfg, seed=seeds[i], snapshot_interval=snapshot_interval)
-            stream.synchronize()
-        except BaseException as e:                      # noqa: BLE001 -- re-raised in the caller's thread
-            errors.append(e)
-
-    threads = [threading.Thread(target=work, args=(i,), name=f"clip-{i}") for i in range(n)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    if errors:
-        raise errors[0]
+    cur = torch.cuda.current_stream(dev)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n)]
+    for s in streams:
+        s.wait_stream(cur)
+    gens = [fit_clip_steps(clips[i], dev, cfg, seed=seeds[i], snapshot_interval=snapshot_interval, chunk=chunk)
+            for i in range(n)]
+    results = [None] * n
+    live = list(range(n))
+    while live:
+        for i in list(live):
+            with torch.cuda.stream(streams[i]):
+                try:
+                    next(gens[i])
+                except StopIteration as e:
+                    results[i] = e.value
+                    live.remove(i)
+    for s in streams:
+        cur.wait_stream(s)
     return results
 
 

@@ -79,3 +79,4 @@ def complex_texture_sampling_device(gt_image, gt_depth, num_points, generator=No
     scales_norm = scales * 100.0 / scales.sum()
     rgbs = (gt_image.detach().float() * 255)[ys, xs] / 255.0
     return torch.stack([xs, ys], dim=1), gt_depth[ys, xs], scales_norm, rgbs
+

@@ -151,10 +151,9 @@ _COPY_STREAMS = {}
 
 
 def _copy_stream(dev):
-    """one side stream per device and host thread for the snapshot copies (creating a stream per train() call cost
-    1.4 ms each)"""
-    import threading
-    key = (dev.type, dev.index, threading.get_ident())
+    """one side stream per device and FIT stream for the snapshot copies (creating a stream per train() call cost
+    1.4 ms each; several fits on one device -- fit_clips_concurrent -- must not queue behind each other's copies)"""
+    key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
     if key not in _COPY_STREAMS:
         _COPY_STREAMS[key] = torch.cuda.Stream(device=dev)
     return _COPY_STREAMS[key]
@@ -704,9 +703,20 @@ class SimpleGaussian:
         st.fn_batch = run
         return st
 
-    def train(self, iterations=500, save_ckpt=False, ckpt_name="ckpt", snapshot_interval=10, render_parts=True,
-              lazy_images=False, **kw):
-        """One call = the optimisation of one frame (trainer.py:332-711); keyword arguments
+    def train(self, *a, **kw):
+        """``train_steps`` run to the end (the generator exists so that several fits can take turns on one device,
+        fit_video.fit_clips_concurrent); same arguments, returns what it returns."""
+        g = self.train_steps(*a, **kw)
+        try:
+            while True:
+                next(g)
+        except StopIteration as e:
+            return e.value
+
+    def train_steps(self, iterations=500, save_ckpt=False, ckpt_name="ckpt", snapshot_interval=10, render_parts=True,
+                    lazy_images=False, chunk=None, **kw):
+        """A generator: yields after every ``chunk`` iterations (None: never), returns train()'s tuple.
+        One call = the optimisation of one frame (trainer.py:332-711); keyword arguments
         as ``make_stepper``.  Returns (frames, frames_center, frames_depth, still_rgb,
         still_center, move_rgb, move_center, move_seg) like the reference; the frame lists
         hold (H,W,3) uint8 snapshots taken every ``snapshot_interval`` iterations (0 = none).
@@ -716,7 +726,15 @@ class SimpleGaussian:
         ``torch.cuda.synchronize()``.  (A caller that drops them, like fit_clip, saves one full stop of the host per call.)"""
         W, H, dev = self.W, self.H, self.device
         st = self.make_stepper(iterations=iterations, snapshot_interval=snapshot_interval, **kw)
-        st.run(iterations)
+        if chunk:
+            done = 0
+            while done < iterations:
+                n = min(int(chunk), iterations - done)
+                st.run(n)
+                done += n
+                yield
+        else:
+            st.run(iterations)
         self.train_log = st.log
         if self.fused and self.engine is not None:
             self.engine.watch_overflow()          # dropped pairs must not go unnoticed -- without stopping the host here

@@ -225,9 +225,9 @@ def test_batched_graph_launches_equal_one_iteration_at_a_time():
 
 
 def test_concurrent_fits_on_one_device_equal_the_fits_one_after_another():
-    """fit_video.fit_clips_concurrent: three clips at the same time on ONE device (a host thread, a stream, a trainer
-    and an engine per clip; graph captures in "thread_local" mode) reach what the same three fits reach one after
-    another -- the clips share nothing but the device."""
+    """fit_video.fit_clips_concurrent: three clips at the same time on ONE device (a stream, a trainer and an engine per
+    clip; the clips take turns to enqueue their iterations from one host thread) reach what the same three fits reach
+    one after another -- the clips share nothing but the device."""
     from gflow_amd.fit_video import fit_clip, fit_clips_concurrent
     clips = [_clip(seed=s) for s in (11, 12, 13)]
     alone = [fit_clip(c, DEV, SMALL, seed=i, snapshot_interval=10) for i, c in enumerate(clips)]
@@ -238,6 +238,6 @@ def test_concurrent_fits_on_one_device_equal_the_fits_one_after_another():
         assert b["frames"] == 3 and b["iterations"] == a["iterations"] and b["clips"] == 1
         assert abs(a["psnr_sum"] - b["psnr_sum"]) / 3 < 0.7, (a, b)       # (the backward's LDS atomics are unordered)
         assert abs(a["splats_final"] - b["splats_final"]) <= 0.02 * a["splats_final"], (a, b)
-    # an exception in one clip's thread reaches the caller
+    # an exception inside one clip's fit reaches the caller
     with pytest.raises(Exception):
         fit_clips_concurrent([clips[0], [dict(clips[1][0], image=None)]], DEV, SMALL)
