@@ -249,8 +249,13 @@ constexpr int CS_TILES = 32;
 constexpr int CS_GROUPS = 8;
 __global__ void __launch_bounds__(256) bin_colscan_kernel(int32_t* __restrict__ hist_g, int nblk, int T,
                                                          int32_t* __restrict__ tile_counts,
-                                                         int32_t* __restrict__ pool_counter) {
+                                                         int32_t* __restrict__ pool_counter,
+                                                         int32_t* __restrict__ pull_counters, int n_pull) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *pool_counter = 0;   // preprocess is done with it
+    // the pull counters of this iteration's two blend launches (the tile queues themselves may be older: they are
+    // rebuilt at the END of an iteration, beside the per-splat launch)
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < n_pull; c += 256) pull_counters[c] = 0;
     __shared__ int32_t gsum[CS_GROUPS][CS_TILES];
     const int tl = threadIdx.x % CS_TILES, rg = threadIdx.x / CS_TILES;
     const int t = blockIdx.x * CS_TILES + tl;
@@ -292,24 +297,31 @@ __global__ void __launch_bounds__(256) bin_colscan_kernel(int32_t* __restrict__ 
 
 static_assert(SCHED_BLOCK == BIN_BLOCK, "the tile scheduler runs as one extra block of the scatter launch");
 
+__device__ __forceinline__ bool sched_xcd_usable(const Sched& sc, int T, int block) {
+    return sc.xcd && T <= SCHED_PLAN_TILES && sc.nq % 8 == 0 && sc.nq / 8 <= 64 && sc.nq <= block;
+}
+
 __global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* __restrict__ rec, int N, int gx, int gy,
                                                                   const int32_t* __restrict__ hist_g,
                                                                   const int32_t* __restrict__ tile_counts,
                                                                   int32_t* __restrict__ tile_offsets, int K_cap,
                                                                   unsigned long long* __restrict__ keys,
                                                                   int32_t* __restrict__ overflow,
-                                                                  Sched sched_bwd, Sched sched_fwd) {
+                                                                  Sched sched_bwd, Sched sched_fwd,
+                                                                  const int32_t* __restrict__ sched_valid) {
     extern __shared__ int32_t cursor[];
     __shared__ int32_t wsum[BIN_BLOCK / 64];
     const int T = gx * gy;
     if (blockIdx.x >= gridDim.x - 2) {
-        // two extra workgroups (the launch leaves CUs idle) build the blend kernels' tile queues
+        // Two extra workgroups build the blend kernels' tile queues -- but only while there is no schedule yet: from
+        // the first backward on, the queues of iteration i + 1 are built at the END of iteration i, by two extra
+        // workgroups of the per-splat launch (they need nothing but the work the blend kernels of iteration i counted).
+        // In here they set the duration of the whole launch: 16-18 us against the scatter's own 12.
+        if (*sched_valid) return;
         __shared__ SchedLds sched_lds;
         const Sched sc = blockIdx.x == gridDim.x - 1 ? sched_bwd : sched_fwd;
-        if (sc.xcd && T <= SCHED_PLAN_TILES && sc.nq % 8 == 0 && sc.nq / 8 <= 64)
-            schedule_tiles_xcd(tile_counts, T, sc, cursor, wsum, sched_lds);
-        else
-            schedule_tiles(tile_counts, T, sc, cursor, wsum, sched_lds);
+        if (sched_xcd_usable(sc, T, SCHED_BLOCK)) schedule_tiles_xcd<SCHED_BLOCK>(tile_counts, T, sc, cursor, wsum, sched_lds);
+        else schedule_tiles(tile_counts, T, sc, cursor, wsum, sched_lds);
         return;
     }
     const int32_t* base_row = hist_g + (size_t)blockIdx.x * T;
@@ -1048,7 +1060,7 @@ __device__ __forceinline__ void camera_tail(const CamTail& t, const float* parti
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0)
-        s_last = __hip_atomic_fetch_add(t.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+        s_last = __hip_atomic_fetch_add(t.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == rows - 1;
     __syncthreads();
     if (!s_last) return;
     // thread 0 needs these after the reduction: request them now
@@ -1143,6 +1155,15 @@ __device__ __forceinline__ void camera_tail(const CamTail& t, const float* parti
     }
 }
 
+// the next iteration's schedule, built by two extra workgroups of the per-splat launch (rows = the per-splat workgroups)
+struct NextSched {
+    int rows;
+    int T;
+    const int32_t* tile_counts;
+    Sched bwd, fwd;
+    int32_t* valid;
+};
+
 // OP = true is the differentiable operator's backward (gfl_render_bwd): the rows hold ACTIVATED attributes, the
 // camera is the extrinsic `pose` points at (12 floats), the caller's dL/d uv and dL/d depth join the gradient, and
 // the 14 gradients are WRITTEN to d_params rows instead of stepping Adam (no regularisers, no masks).
@@ -1155,7 +1176,18 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
     const float* __restrict__ flow_target, const float* __restrict__ flow_w, const float* __restrict__ still_target,
     const float* __restrict__ still_w, const uint8_t* __restrict__ row_flags, RegCfg rc, AdamCfg ac,
     const int32_t* d_step, float* partial, const float* __restrict__ d_uv_in,
-    const float* __restrict__ d_depth_in, float* __restrict__ d_params, const int32_t* __restrict__ scale_cnt, CamTail tail) {
+    const float* __restrict__ d_depth_in, float* __restrict__ d_params, const int32_t* __restrict__ scale_cnt, CamTail tail,
+    NextSched ns) {
+    if ((int)blockIdx.x >= ns.rows) {
+        // the two workgroups behind the per-splat ones build the NEXT iteration's tile queues (see fused_scatter_kernel)
+        extern __shared__ int32_t sched_scratch[];
+        __shared__ SchedLds sched_lds;
+        __shared__ int32_t sched_wsum[REDUCE_BLOCK / 64];
+        const Sched sc = (int)blockIdx.x == ns.rows ? ns.bwd : ns.fwd;
+        schedule_tiles_xcd<REDUCE_BLOCK>(ns.tile_counts, ns.T, sc, sched_scratch, sched_wsum, sched_lds);
+        if (threadIdx.x == 0) *ns.valid = 1;
+        return;
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int e_step = OP ? 0 : *d_step;              // (the tail of the LAST workgroup advances it)
     float scale_w = 0.f;                              // lambda_scale / rows of the scale term
@@ -1413,7 +1445,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
     }
     if (!OP && tail.ticket) {
         block_reduce_store<12, REDUCE_BLOCK, true>(e, partial);
-        camera_tail(tail, partial, (int)gridDim.x, e_step);
+        camera_tail(tail, partial, ns.rows, e_step);
     } else {
         block_reduce_store<12, REDUCE_BLOCK>(e, partial);
     }
@@ -1571,6 +1603,17 @@ static int sched_xcd() {
     return v;
 }
 
+// GFL_SCHED_NEXT=0: the tile queues are built in line by the scatter launch in every iteration (rounds 1-2), not at the end
+// of the previous iteration
+static bool next_sched_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GFL_SCHED_NEXT");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 // list length from which the forward blend walks a queue's first tile as four blocks (GFL_FWD_SPLIT_MIN overrides)
 static int fwd_split_min() {
     static int v = -1;
@@ -1633,6 +1676,7 @@ struct FitWs {
     int32_t* slot_inv;
     int32_t* slot_pool;
     int32_t* pool_counter;
+    int32_t* sched_valid;    // != 0: the tile queues in the workspace were built at the end of the last iteration
     Sched sched;             // tile queues of the backward blend; sched.work persists between calls
     Sched sched_fwd;         // ... and of the forward blend (its own work feedback)
     float* ckpt;             // [queue][boundary][T a0 a1 a2 a3][256 pixels] forward state at the heavy tile's segment boundaries
@@ -1659,6 +1703,7 @@ static FitWs carve(const gfl_fit_state* st) {
     w.slot_inv = (int32_t*)p;
     p += up256((size_t)(st->cap > 0 ? st->cap : 1) * SLOT_MAX * sizeof(int32_t));
     w.pool_counter = (int32_t*)p;
+    w.sched_valid = w.pool_counter + 16;
     p += 256;
     w.slot_pool = (int32_t*)p;
     p += up256((size_t)st->K_cap * sizeof(int32_t));
@@ -1696,6 +1741,25 @@ static FitWs carve(const gfl_fit_state* st) {
     return w;
 }
 
+// the next iteration's tile queues are built by two extra workgroups of the per-splat launch when the XCD-local scheduler
+// can run on REDUCE_BLOCK threads (otherwise the scatter launch keeps building them in line, every iteration)
+static bool next_sched_ok(const FitWs& w, int T) {
+    return w.sched.xcd && T <= SCHED_PLAN_TILES && w.sched.nq % 8 == 0 && w.sched.nq / 8 <= 64 && w.sched.nq <= REDUCE_BLOCK &&
+           next_sched_enabled();
+}
+static int next_sched_blocks(const FitWs& w, int T) { return next_sched_ok(w, T) ? 2 : 0; }
+static size_t next_sched_lds(const FitWs& w, int T) { return next_sched_ok(w, T) ? (size_t)T * sizeof(int32_t) : 0; }
+static NextSched next_sched(const FitWs& w, int rows, int T) {
+    NextSched ns;
+    ns.rows = rows;
+    ns.T = T;
+    ns.tile_counts = w.tile_counts;
+    ns.bwd = w.sched;
+    ns.fwd = w.sched_fwd;
+    ns.valid = w.sched_valid;
+    return ns;
+}
+
 static int fit_check(const gfl_fit_state* st, const gfl_fit_hyper* hp) {
     if (!st || !hp) return GFL_ERR_INVALID;
     if (st->N < 0 || st->N > st->cap || st->W <= 0 || st->H <= 0 || st->K_cap < 0) return GFL_ERR_INVALID;
@@ -1731,12 +1795,14 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
     }
     {
         StageScope p(ST_COLSCAN, s);
-        bin_colscan_kernel<<<(T + CS_TILES - 1) / CS_TILES, 256, 0, s>>>(w.hist, nblk, T, w.tile_counts, w.pool_counter);
+        bin_colscan_kernel<<<(T + CS_TILES - 1) / CS_TILES, 256, 0, s>>>(w.hist, nblk, T, w.tile_counts, w.pool_counter,
+                                                                         w.sched.counters, 2 * w.sched.nq);
     }
     {
         StageScope p(ST_SCATTER, s);
         fused_scatter_kernel<<<nblk + 2, BIN_BLOCK, lds, s>>>(st->rec, st->N, gx, gy, w.hist, w.tile_counts,
-                                                              st->tile_offsets, st->K_cap, w.keys, st->overflow, w.sched, w.sched_fwd);
+                                                              st->tile_offsets, st->K_cap, w.keys, st->overflow, w.sched, w.sched_fwd,
+                                                              w.sched_valid);
     }
     {
         StageScope p(ST_TILE_SORT, s);
@@ -1875,10 +1941,11 @@ int gfl_render_bwd(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float
     AdamCfg ac = {};
     {
         StageScope p(ST_PRE_BWD_ADAM, s);
-        fused_preprocess_bwd_adam_kernel<true><<<rows, REDUCE_BLOCK, 0, s>>>(
+        const NextSched ns = next_sched(w, rows, T);
+        fused_preprocess_bwd_adam_kernel<true><<<rows + next_sched_blocks(w, T), REDUCE_BLOCK, next_sched_lds(w, T), s>>>(
             st->params, nullptr, nullptr, st->intr, st->extr, st->rec, st->d_rec, w.pair_grad, w.slot_pool, st->tile_range,
             w.slot_inv, gx, gy, st->N, st->W, st->H, nullptr, nullptr, nullptr, nullptr, nullptr, rcfg, ac, nullptr,
-            w.partial, d_uv, d_depth, d_params, nullptr, CamTail{});
+            w.partial, d_uv, d_depth, d_params, nullptr, CamTail{}, ns);
         fold_partials_kernel<12><<<1, 256, 0, s>>>(w.partial, rows, d_extr);
     }
     return check_launch();
@@ -1936,10 +2003,11 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
     }
     {
         StageScope p(ST_PRE_BWD_ADAM, s);
-        fused_preprocess_bwd_adam_kernel<false><<<rows, REDUCE_BLOCK, 0, s>>>(
+        const NextSched ns = next_sched(w, rows, T);
+        fused_preprocess_bwd_adam_kernel<false><<<rows + next_sched_blocks(w, T), REDUCE_BLOCK, next_sched_lds(w, T), s>>>(
             st->params, st->adam_m, st->adam_v, st->intr, st->pose, st->rec, st->d_rec, w.pair_grad, w.slot_pool,
             st->tile_range, w.slot_inv, gx, gy, st->N, st->W, st->H, st->flow_target, st->flow_w, st->still_target,
-            st->still_w, st->row_flags, rcfg, ac, st->step, w.partial, nullptr, nullptr, nullptr, w.scale_cnt, tail);
+            st->still_w, st->row_flags, rcfg, ac, st->step, w.partial, nullptr, nullptr, nullptr, w.scale_cnt, tail, ns);
     }
     if (own_launch) {
         StageScope p(ST_CAMERA, s);

@@ -82,6 +82,29 @@ for r in rows[:6]:
     print("CU end %.1f  units %d  items %d  top items %s  max wave %d" % r)
 for r in rows[-2:]:
     print("CU end %.1f  units %d  items %d  top items %s  max wave %d" % r)
+if "--queues" in sys.argv and not FWD:
+    # planned (scheduler's queues) against observed (hardware CU ids): units per queue and which CUs ran a queue's tiles
+    qs = tr.engine.schedule()
+    tile_units = np.zeros(T, dtype=np.int64)
+    tile_cu = [set() for _ in range(T)]
+    for i in range(len(ROWID)):
+        t = int(ROWID[i]) % 2048
+        tile_units[t] += int(units[i].sum())
+        tile_cu[t].add(int(cu[i]))
+    np.save(os.path.join(ROOT, "gpurun_out", "tile_units.npy"), tile_units)
+    np.save(os.path.join(ROOT, "gpurun_out", "queue_tiles.npy"), np.array([np.pad(q.numpy(), (0, 64 - len(q)), constant_values=-1) for q in qs]))
+    qsum = np.array([int(tile_units[q.numpy()].sum()) for q in qs])
+    print("queues %d: units per queue mean %.0f max %d min %d" % (len(qs), qsum.mean(), qsum.max(), qsum.min()))
+    ncu = [len(set().union(*[tile_cu[int(t)] for t in q.numpy()])) if len(q) else 0 for q in qs]
+    print("distinct CUs that ran a queue's tiles: mean %.2f max %d" % (np.mean(ncu), max(ncu)))
+    # how many queues did a CU serve?
+    cu_q = collections.defaultdict(set)
+    for qi, q in enumerate(qs):
+        for t in q.numpy():
+            for c_ in tile_cu[int(t)]:
+                cu_q[c_].add(qi)
+    nq_per_cu = [len(v) for v in cu_q.values()]
+    print("queues per CU: mean %.2f max %d ; CUs seen %d" % (np.mean(nq_per_cu), max(nq_per_cu), len(cu_q)))
 if "--items" in sys.argv:
     # item timelines of the three slowest CUs and of a median one
     idx_rows = np.nonzero(a[:, 0] > a[:, 1].max() - 30000)[0] if False else None
