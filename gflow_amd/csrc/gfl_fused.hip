@@ -473,11 +473,19 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     __shared__ RecLDS recs[FB + 1];          // recs[FB]: an all-zero record (opacity 0: never blends)
     __shared__ unsigned char s_mask[FB];
     __shared__ int32_t s_ticket;
+    __shared__ int32_t s_simd[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid == 0) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         recs[FB].p0 = z; recs[FB].p1 = z; recs[FB].p2 = z;
     }
+    // block plan (gfl_sched.hpp): which 8x8 block of a whole tile this wave walks follows from the SIMD it sits on
+    unsigned hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    const int simd = (hw_id >> 4) & 3;
+    if (lane == 0) s_simd[wave] = simd;
+    __syncthreads();
+    const bool simd_ok = ((1 << s_simd[0]) | (1 << s_simd[1]) | (1 << s_simd[2]) | (1 << s_simd[3])) == 15;
   for (bool first = true;; first = false) {
     const TileItem item = next_item(queue, &s_ticket, first, true);
     if (item.tile < 0) {
@@ -505,8 +513,14 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     const int blk = (first_tile && end - start > split_min) ? item.part : -1;
     if (first_tile && blk < 0 && item.part > 0) continue;                     // not long enough: its own CU walks it whole
     const int bs = blk < 0 ? 8 : 4;                                           // edge of a wave's pixel box
+    // wb: the wave's box inside the workgroup's area -- a quarter of the block (blk >= 0: wave k takes quarter k) or an
+    // 8x8 block of the whole tile, the one the item's plan names for this wave's SIMD
+    const unsigned plan = item.plan;
+    const bool plan_ok = blk < 0 && item.part <= 0 && simd_ok &&
+                         ((1 << (plan & 3)) | (1 << ((plan >> 2) & 3)) | (1 << ((plan >> 4) & 3)) | (1 << ((plan >> 6) & 3))) == 15;
+    const int wb = plan_ok ? (int)((plan >> (2 * simd)) & 3u) : wave;
     const int org_x = tx * GFL_TILE + (blk < 0 ? 0 : (blk & 1) * 8), org_y = ty * GFL_TILE + (blk < 0 ? 0 : (blk >> 1) * 8);
-    const int px0w = org_x + (wave & 1) * bs, py0w = org_y + (wave >> 1) * bs;
+    const int px0w = org_x + (wb & 1) * bs, py0w = org_y + (wb >> 1) * bs;
     const int px = px0w + (blk < 0 ? (lane & 7) : (lane & 3)), py = py0w + (blk < 0 ? (lane >> 3) : ((lane >> 2) & 3));
     // (a block's wave: all four 16-lane rows carry the quarter's sixteen pixels -- four splats per step below --
     //  and row 0 writes)
@@ -521,7 +535,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     const int parts = heavy ? heavy_parts(end - start) : 1;
     const int seg = heavy_seg(end - start, parts);
     const bool ck_lane = blk < 0 || lane < 16;
-    const int ftid = blk < 0 ? tid : blk * 64 + ((py - org_y) << 3) + (px - org_x);
+    const int ftid = blk < 0 ? wb * 64 + lane : blk * 64 + ((py - org_y) << 3) + (px - org_x);
     float* ck = ckpt + (size_t)max(slot, 0) * (HEAVY_PARTS - 1) * 5 * 256 + ftid;
     int units = 0;                                   // work feedback for the forward schedule (wave-uniform)
     int ck_next = 1;                                 // next boundary to checkpoint: position ck_next * seg
@@ -567,7 +581,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                 ++ck_next;
             }
             const int slot = c0 + lane;
-            bool hit = slot < cnt && ((s_mask[slot] >> wave) & 1);
+            bool hit = slot < cnt && ((s_mask[slot] >> wb) & 1);
             {
                 // Once pixels have stopped, only splats that reach a pixel that is still ALIVE matter.  In a tile
                 // where densification piled up a thousand small splats the pile's own pixels stop early and the rest
@@ -696,7 +710,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
         final_T[pix] = T;
         n_contrib[pix] = last;
     }
-    if (mode == 0 && lane == 0) atomicAdd(&tile_work[4 * tile + (blk < 0 ? wave : blk)], units + 1);     // per 8x8 block (gfl_sched.hpp: block plan)
+    if (mode == 0 && lane == 0) atomicAdd(&tile_work[4 * tile + (blk < 0 ? wb : blk)], units + 1);     // per 8x8 block (gfl_sched.hpp: block plan)
     // the wave stopped before the split position: every pixel's state is frozen, final = checkpoint
     for (; ck_next < parts; ++ck_next) {
         float* c5 = ck + (size_t)(ck_next - 1) * 5 * 256;
