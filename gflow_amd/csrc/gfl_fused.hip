@@ -33,6 +33,10 @@ constexpr int BIN_BLOCK = 512;
 constexpr int WIDE_TILES = 16;   // splats covering more tiles are binned by a whole wave
 constexpr int ROW = 16;   // floats per params row
 constexpr int REC = 12;   // floats per rec row
+#ifndef GFL_PG_STRIDE
+#define GFL_PG_STRIDE 12
+#endif
+constexpr int PG = GFL_PG_STRIDE;   // floats per pair_grad row (12 live; 16 = one 64-byte sector per row)
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
@@ -864,7 +868,7 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
     // pairs behind the deepest contributor of the tile get a zero row
     if (last_part)
         for (int p = depth_n + tid; p < total; p += 256) {
-            float4* o = reinterpret_cast<float4*>(pair_grad + (size_t)(start + p) * REC);
+            float4* o = reinterpret_cast<float4*>(pair_grad + (size_t)(start + p) * PG);
             o[0] = zero4; o[1] = zero4; o[2] = zero4;
         }
 
@@ -929,7 +933,7 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
         __syncthreads();
         if (pos_t >= lo) {
             const float4* a4 = reinterpret_cast<const float4*>(&acc[tid][0]);
-            float4* o = reinterpret_cast<float4*>(pair_grad + (size_t)(start + pos_t) * REC);
+            float4* o = reinterpret_cast<float4*>(pair_grad + (size_t)(start + pos_t) * PG);
             o[0] = a4[0]; o[1] = a4[1]; o[2] = a4[2];
         }
     }
@@ -1266,7 +1270,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const bool ok = 4 * k + j < nt && pos[j] >= 0;
-                            const float4* g4 = reinterpret_cast<const float4*>(pair_grad + (size_t)(ok ? pos[j] : 0) * REC);
+                            const float4* g4 = reinterpret_cast<const float4*>(pair_grad + (size_t)(ok ? pos[j] : 0) * PG);
                             r0[j] = g4[0]; r1[j] = g4[1]; r2[j] = g4[2];
                         }
 #pragma unroll
@@ -1302,7 +1306,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
             for (int q = lane; q < nt && code <= -2; q += 64) {
                 const int lo = slot_pool[-2 - code + q];
                 if (lo >= 0) {
-                    const float4* g4 = reinterpret_cast<const float4*>(pair_grad + (size_t)lo * REC);
+                    const float4* g4 = reinterpret_cast<const float4*>(pair_grad + (size_t)lo * PG);
                     const float4 q0 = g4[0], q1 = g4[1], q2 = g4[2];
                     a[0] += q0.x; a[1] += q0.y; a[2] += q0.z; a[3] += q0.w; a[4] += q1.x; a[5] += q1.y; a[6] += q1.z;
                     a[7] += q1.w; a[8] += q2.x; a[9] += q2.y;
@@ -1666,7 +1670,7 @@ size_t gfl_fit_workspace_bytes(int cap, int K_cap, int W, int H) {
            + up256((size_t)K_cap * sizeof(unsigned long long))                      // keys
            + up256((size_t)reduce_rows(cap > 0 ? cap : 1) * 12 * sizeof(float))    // extr partials
            + up256(T * sizeof(int32_t))                                             // tile totals
-           + up256((size_t)K_cap * REC * sizeof(float))                             // per-pair gradient rows
+           + up256((size_t)K_cap * PG * sizeof(float))                             // per-pair gradient rows
            + up256((size_t)(cap > 0 ? cap : 1) * SLOT_MAX * sizeof(int32_t))        // slot -> list position
            + 256 + up256((size_t)K_cap * sizeof(int32_t))                          // counters + slot pool
            + up256(4 * T * sizeof(int32_t))                                         // scheduler: work feedback per 8x8 block
@@ -1713,7 +1717,7 @@ static FitWs carve(const gfl_fit_state* st) {
     w.tile_counts = (int32_t*)p;
     p += up256(T * sizeof(int32_t));
     w.pair_grad = (float*)p;
-    p += up256((size_t)st->K_cap * REC * sizeof(float));
+    p += up256((size_t)st->K_cap * PG * sizeof(float));
     w.slot_inv = (int32_t*)p;
     p += up256((size_t)(st->cap > 0 ? st->cap : 1) * SLOT_MAX * sizeof(int32_t));
     w.pool_counter = (int32_t*)p;

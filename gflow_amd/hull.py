@@ -1,0 +1,203 @@
+"""Moving-region mask from the projected moving splats -- the counterpart of gflow/utils/concave_hull.py
+(``FastConcaveHull2D``), which the reference calls at the end of every joint ``train()`` (trainer.py:604-609).
+
+The reference builds the hull with the ``concave_hull`` package (a binding of mapbox's *concaveman*), smooths the ring
+(``gaussian_smooth_geom``) and rasterises it with PIL.  Neither ``concave_hull`` nor ``shapely`` exists in this
+environment, so
+
+  * ``concave_hull`` below is OUR restatement of the published concaveman algorithm (convex hull, then every edge, longest
+    candidates first in queue order, is "dug in" towards the nearest interior point that is closer to it than to its two
+    neighbour edges, within edge length / concavity, and whose two new edges cross no hull edge), with the package's
+    defaults concavity = 2, length_threshold = 0.  It cannot be pinned to the package's output here: treat the exact ring
+    as unpinned (like the rasteriser's constants); what is tested is what a hull must satisfy
+    (tests/test_host_logic.py: every point inside, never outside the convex hull, follows a concavity).
+  * ``gaussian_smooth`` and ``polygon_to_mask`` follow concave_hull.py:10-31 line by line (numpy, scipy and PIL are here),
+    including the reference's quirk that ``FastConcaveHull2D``'s ``sigma`` / ``num_points_factor`` arguments never reach
+    ``gaussian_smooth`` (it is called with its own defaults 2 and 2, concave_hull.py:40).
+
+This is host work on a few thousand points once per frame (the reference moves ``uv`` to the host for it); it is NOT on
+the iteration path and ``SimpleGaussian.train`` runs it only when asked (``move_seg=True``)."""
+import numpy as np
+
+
+def _convex_hull(P):
+    """Andrew's monotone chain; indices of the hull vertices in counter-clockwise order."""
+    order = np.lexsort((P[:, 1], P[:, 0]))
+    pts = P[order]
+
+    def cross(o, a, b):
+        return (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0])
+
+    lower, upper = [], []
+    for i in range(len(pts)):
+        while len(lower) >= 2 and cross(pts[lower[-2]], pts[lower[-1]], pts[i]) <= 0:
+            lower.pop()
+        lower.append(i)
+    for i in range(len(pts) - 1, -1, -1):
+        while len(upper) >= 2 and cross(pts[upper[-2]], pts[upper[-1]], pts[i]) <= 0:
+            upper.pop()
+        upper.append(i)
+    return order[np.array(lower[:-1] + upper[:-1], dtype=np.int64)]
+
+
+def _sq_seg_dist(P, a, b):
+    """squared distance of the points P (n,2) to the segment a-b"""
+    ab = b - a
+    den = float(ab @ ab)
+    if den == 0.0:
+        return ((P - a) ** 2).sum(1)
+    t = np.clip(((P - a) @ ab) / den, 0.0, 1.0)
+    proj = a + t[:, None] * ab
+    return ((P - proj) ** 2).sum(1)
+
+
+def _orient(p, q, r):
+    return (q[..., 1] - p[..., 1]) * (r[..., 0] - q[..., 0]) - (q[..., 0] - p[..., 0]) * (r[..., 1] - q[..., 1])
+
+
+def _no_intersections(P, a_idx, b_idx, ea, eb):
+    """the segment a-b crosses none of the hull edges (ea[i], eb[i]); edges that share an end point with it do not count
+    (concaveman's ``intersects``: p1 !== q2 && q1 !== p2 && the two orientation tests)"""
+    p1, q1 = P[ea], P[eb]
+    p2, q2 = P[a_idx], P[b_idx]
+    shares = (ea == b_idx) | (eb == a_idx)
+    o1 = _orient(p1, q1, p2) > 0
+    o2 = _orient(p1, q1, q2) > 0
+    o3 = _orient(p2[None], q2[None], p1) > 0
+    o4 = _orient(p2[None], q2[None], q1) > 0
+    return not bool(((~shares) & (o1 != o2) & (o3 != o4)).any())
+
+
+def concave_hull(points, concavity=2.0, length_threshold=0.0):
+    """(n,2) points -> (m,2) ring vertices (not closed), concaveman's algorithm (see the module docstring)."""
+    P = np.unique(np.asarray(points, dtype=np.float64).reshape(-1, 2), axis=0)
+    if len(P) <= 3:
+        return P
+    hull = _convex_hull(P)
+    m0 = len(hull)
+    cap = 2 * len(P) + 8
+    node_p = np.zeros(cap, dtype=np.int64)            # node -> point index; node i is also the edge (node i, next[i])
+    nxt = np.zeros(cap, dtype=np.int64)
+    prv = np.zeros(cap, dtype=np.int64)
+    alive = np.zeros(cap, dtype=bool)
+    node_p[:m0] = hull
+    nxt[:m0] = (np.arange(m0) + 1) % m0
+    prv[:m0] = (np.arange(m0) - 1) % m0
+    alive[:m0] = True
+    n_nodes = m0
+    free = np.ones(len(P), dtype=bool)                # points not on the hull yet
+    free[hull] = False
+    queue = list(range(m0))
+    sq_conc = concavity * concavity
+    sq_len_thr = length_threshold * length_threshold
+    head = 0
+    while head < len(queue):
+        node = queue[head]
+        head += 1
+        if not alive[node]:
+            continue
+        a_i, b_i = node_p[node], node_p[nxt[node]]
+        a, b = P[a_i], P[b_i]
+        sq_len = float(((a - b) ** 2).sum())
+        if sq_len < sq_len_thr or not free.any():
+            continue
+        max_sq = sq_len / sq_conc
+        cand = np.nonzero(free)[0]
+        d = _sq_seg_dist(P[cand], a, b)
+        near = d <= max_sq
+        if not near.any():
+            continue
+        cand, d = cand[near], d[near]
+        prev_p, next_p = P[node_p[prv[node]]], P[node_p[nxt[nxt[node]]]]
+        ok = (d < _sq_seg_dist(P[cand], prev_p, a)) & (d < _sq_seg_dist(P[cand], b, next_p))
+        cand, d = cand[ok], d[ok]
+        if len(cand) == 0:
+            continue
+        live = np.nonzero(alive[:n_nodes])[0]
+        ea, eb = node_p[live], node_p[nxt[live]]
+        chosen = -1
+        for j in np.argsort(d, kind="stable"):
+            c = cand[j]
+            if _no_intersections(P, b_i, c, ea, eb) and _no_intersections(P, a_i, c, ea, eb):
+                chosen = c
+                break
+        if chosen < 0:
+            continue
+        pc = P[chosen]
+        if min(float(((pc - a) ** 2).sum()), float(((pc - b) ** 2).sum())) > max_sq:
+            continue
+        # a -> chosen -> b : the new node sits behind `node`
+        new = n_nodes
+        n_nodes += 1
+        node_p[new] = chosen
+        nxt[new], prv[new] = nxt[node], node
+        prv[nxt[node]] = new
+        nxt[node] = new
+        alive[new] = True
+        free[chosen] = False
+        queue.append(node)
+        queue.append(new)
+    ring = []
+    start = int(np.nonzero(alive[:n_nodes])[0][0])
+    i = start
+    while True:
+        ring.append(node_p[i])
+        i = int(nxt[i])
+        if i == start:
+            break
+    return P[np.array(ring, dtype=np.int64)]
+
+
+def gaussian_smooth(coords, sigma=2, num_points_factor=2):
+    """concave_hull.py:19-29: resample the ring to ``num_points_factor`` x as many vertices (linear), then a wrapped 1-D
+    Gaussian filter over x and over y."""
+    from scipy.ndimage import gaussian_filter1d
+    coords = np.array(coords)
+    x, y = coords.T
+    xp = np.linspace(0, 1, coords.shape[0])
+    interp = np.linspace(0, 1, coords.shape[0] * num_points_factor)
+    x = np.interp(interp, xp, x)
+    y = np.interp(interp, xp, y)
+    x = gaussian_filter1d(x, sigma, mode="wrap")
+    y = gaussian_filter1d(y, sigma, mode="wrap")
+    return x, y
+
+
+def polygon_to_mask(ring, width, height):
+    """concave_hull.py:10-17: PIL polygon fill (outline = 1, fill = 1) -> (H,W) uint8 of 0 / 1."""
+    from PIL import Image, ImageDraw
+    mask = Image.new("L", (width, height), 0)
+    draw = ImageDraw.Draw(mask)
+    draw.polygon([(float(px), float(py)) for px, py in ring], outline=1, fill=1)
+    del draw
+    return np.array(mask)
+
+
+class FastConcaveHull2D:
+    """Same surface as the reference's class (concave_hull.py:73-92): ``FastConcaveHull2D(points).mask(W, H)``."""
+
+    def __init__(self, points, sigma=2, num_points_factor=5):
+        try:
+            import torch
+            if isinstance(points, torch.Tensor):
+                points = points.detach().cpu().numpy()
+        except ImportError:                              # pragma: no cover
+            pass
+        self.points = np.asarray(points, dtype=np.float64)
+        ring = concave_hull(self.points)
+        # shapely's Polygon(points).exterior.coords is the CLOSED ring: the first vertex once more at the end
+        closed = np.concatenate([ring, ring[:1]], axis=0)
+        if sigma > 0:
+            # (the reference calls gaussian_smooth(geom.exterior.coords) WITHOUT passing sigma / num_points_factor on,
+            #  concave_hull.py:40, then closes the smoothed ring again, :43-44)
+            x, y = gaussian_smooth(closed)
+            x, y = np.append(x, x[0]), np.append(y, y[0])
+            closed = np.stack([x, y], axis=1)
+        self.hull = closed
+
+    def area(self):
+        x, y = self.hull[:, 0], self.hull[:, 1]
+        return 0.5 * abs(float(np.dot(x[:-1], y[1:]) - np.dot(x[1:], y[:-1])))
+
+    def mask(self, width, height):
+        return polygon_to_mask(self.hull, width, height)

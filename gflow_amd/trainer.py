@@ -714,12 +714,13 @@ class SimpleGaussian:
             return e.value
 
     def train_steps(self, iterations=500, save_ckpt=False, ckpt_name="ckpt", snapshot_interval=10, render_parts=True,
-                    lazy_images=False, chunk=None, **kw):
+                    lazy_images=False, chunk=None, move_seg=False, **kw):
         """A generator: yields after every ``chunk`` iterations (None: never), returns train()'s tuple.
         One call = the optimisation of one frame (trainer.py:332-711); keyword arguments
         as ``make_stepper``.  Returns (frames, frames_center, frames_depth, still_rgb,
         still_center, move_rgb, move_center, move_seg) like the reference; the frame lists
         hold (H,W,3) uint8 snapshots taken every ``snapshot_interval`` iterations (0 = none).
+        ``move_seg``: also build ``self.move_seg`` / ``self.move_seg_erode`` (trainer.py:604-609; off by default, see below).
         ``render_parts``: the four images of the still / moving splats the reference renders at the end of EVERY train()
         (trainer.py:632-677); False skips them (None in the tuple).  ``lazy_images``: return without waiting for the
         images -- they are views of page-locked memory that the device fills behind the queued work; read them after
@@ -765,6 +766,19 @@ class SimpleGaussian:
             self.still_mask_tentative = still.clone()
             if hasattr(self, "last_still_mask"):
                 self.still_mask[:self.last_still_mask.shape[0]] = self.last_still_mask
+            if move_seg:
+                # trainer.py:604-609: the moving region as the smoothed concave hull of the moving splats' projections
+                # (gflow_amd/hull.py).  Host work on a few thousand points -- the reference does it after every joint
+                # train(); here only on request, because it reads uv back and stops the host (visualisation and
+                # trajectory seeds use it, the optimisation does not).
+                from .hull import FastConcaveHull2D
+                from scipy.ndimage import minimum_filter
+                sel = within & ~self.still_mask[:uv_d.shape[0]]
+                pts = uv_d[sel].cpu().numpy()
+                if pts.shape[0] > 5:
+                    self.move_seg = (FastConcaveHull2D(pts).mask(W, H) * 255).astype(np.uint8)
+                    # cv2.erode(move_seg, ones((20, 20))): minimum over x-10 .. x+9, nothing eroded from the border
+                    self.move_seg_erode = minimum_filter(self.move_seg, size=20, mode="constant", cval=255)
             self.last_still_mask = self.still_mask.detach()
             self.last_uv = uv_d
             self.last_depth = depth_d

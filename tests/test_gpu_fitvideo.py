@@ -241,3 +241,35 @@ def test_concurrent_fits_on_one_device_equal_the_fits_one_after_another():
     # an exception inside one clip's fit reaches the caller
     with pytest.raises(Exception):
         fit_clips_concurrent([clips[0], [dict(clips[1][0], image=None)]], DEV, SMALL)
+
+
+def test_move_seg_covers_the_moving_splats():
+    """train(move_seg=True): the mask of trainer.py:604-609 (smoothed concave hull of the moving splats' projections,
+    gflow_amd/hull.py) and its eroded version; off by default."""
+    import numpy as np
+    from gflow_amd.trainer import SimpleGaussian
+    f0 = _clip(1, H=192, W=256, seed=5)[0]
+    tr = SimpleGaussian(f0["image"], f0["depth"], num_points=6000, device=DEV, seed=0)
+    tr.load_camera(focal=f0["focal"], pp=f0["pp"])
+    tr.init_gaussians_from_image(f0["image"], f0["depth"], num_points=6000)
+    kw = dict(iterations=25, lr=4e-3, lambda_rgb=1.0, lambda_depth=1e-2, lambda_var=10.0, densify_interval=0,
+              move_mask=f0["move_mask"], snapshot_interval=0)
+    out = tr.train(**kw)
+    assert out[7] is None and tr.move_seg is None
+    tr.set_gt_flow(torch.zeros_like(f0["flow"]))                           # (a second fit of the same frame: nothing moves)
+    out = tr.train(move_seg=True, **kw)
+    seg = out[7]
+    assert seg is tr.move_seg and seg.dtype == np.uint8 and seg.shape == (192, 256) and set(np.unique(seg)) <= {0, 255}
+    uv = tr.last_uv.cpu()
+    inside = (uv[:, 0] > 0) & (uv[:, 0] < 255) & (uv[:, 1] > 0) & (uv[:, 1] < 191)
+    mv = uv[inside & ~tr.still_mask.cpu()].long()
+    assert mv.shape[0] > 100
+    from gflow_amd.hull import FastConcaveHull2D
+    raw = FastConcaveHull2D(uv[inside & ~tr.still_mask.cpu()], sigma=0).mask(256, 192)
+    assert raw[mv[:, 1], mv[:, 0]].mean() > 0.97                            # the moving splats lie inside their hull ...
+    cover = seg[mv[:, 1], mv[:, 0]].mean() / 255.0
+    assert cover > 0.85, cover                                              # (the smoothed ring cuts the hull's own vertices off)
+    gt = f0["move_mask"].numpy()
+    assert (seg[gt] > 0).mean() > 0.8 and (seg[~gt] > 0).mean() < 0.1, ((seg[gt] > 0).mean(), (seg[~gt] > 0).mean())
+    er = tr.move_seg_erode
+    assert er.shape == seg.shape and not bool(((er > 0) & (seg == 0)).any()) and 0 < (er > 0).sum() < (seg > 0).sum()

@@ -56,6 +56,44 @@ def test_device_sampler_draws_from_the_same_distribution():
     np.testing.assert_allclose(scales.numpy() * (1.0 / want.flatten()[flat]).sum() / 100.0, 1.0 / want.flatten()[flat], rtol=1e-6)
 
 
+def test_concave_hull_properties():
+    """gflow_amd/hull.py -- the moving-region mask of trainer.py:604-609.  The ring cannot be pinned to the reference's
+    ``concave_hull`` package (absent), so it is held to what a concave hull must satisfy: it keeps (nearly) every point
+    inside, never leaves the convex hull, and follows a concavity the convex hull bridges."""
+    from gflow_amd.hull import FastConcaveHull2D, _convex_hull, concave_hull, gaussian_smooth, polygon_to_mask
+    g = np.random.default_rng(0)
+
+    def area(r):
+        x, y = r[:, 0], r[:, 1]
+        return 0.5 * abs(np.dot(x, np.roll(y, -1)) - np.dot(np.roll(x, -1), y))
+
+    pts = g.uniform(0, 100, (5000, 2))
+    pts = pts[~((pts[:, 0] > 40) & (pts[:, 1] > 40))]                    # an L: true area 6 400, convex hull ~8 100
+    ring = concave_hull(pts)
+    conv = pts[_convex_hull(pts)]
+    assert 5600 < area(ring) < 6500 and area(conv) > 7800
+    ring_set = {tuple(p) for p in ring}
+    assert all(tuple(p) in {tuple(q) for q in pts} for p in ring)        # vertices are input points, each once
+    assert len(ring_set) == len(ring)
+    raw_mask = polygon_to_mask(ring, 128, 128)
+    assert raw_mask[pts[:, 1].astype(int), pts[:, 0].astype(int)].mean() > 0.99
+    assert raw_mask[70:95, 70:95].sum() == 0                             # the notch of the L stays outside
+    conv_mask = polygon_to_mask(conv, 128, 128)
+    assert not bool(((raw_mask == 1) & (conv_mask == 0)).any())         # never outside the convex hull
+    h = FastConcaveHull2D(torch.from_numpy(pts))
+    m = h.mask(128, 128)
+    assert m.dtype == np.uint8 and set(np.unique(m)) <= {0, 1} and m.shape == (128, 128)
+    assert m[pts[:, 1].astype(int), pts[:, 0].astype(int)].mean() > 0.98 and abs(h.area() - area(ring)) < 0.03 * area(ring)
+    # the smoothing step by itself (concave_hull.py:19-29): twice the vertices, a wrapped filter keeps the centroid
+    sq = np.array([[0, 0], [10, 0], [10, 10], [0, 10], [0, 0]], dtype=float)
+    x, y = gaussian_smooth(sq)
+    assert len(x) == 10 and abs(x.mean() - np.interp(np.linspace(0, 1, 10), np.linspace(0, 1, 5), sq[:, 0]).mean()) < 1e-9
+    # a convex cloud: the concave hull stays close to the convex one
+    disc = g.normal(size=(3000, 2))
+    disc = disc[(disc ** 2).sum(1) < 4] * 20 + 50
+    assert area(concave_hull(disc)) > 0.9 * area(disc[_convex_hull(disc)])
+
+
 def test_pix2world_matches_golden(golden_dir):
     from gflow_amd.geometry import pix2world
     g = np.load(os.path.join(golden_dir, "pix2world.npz"))
