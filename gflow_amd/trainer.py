@@ -1040,8 +1040,8 @@ class SimpleGaussian:
         return self.psnr_of(self.last_render)
 
     def psnr_of(self, render4):
-        """PSNR of a rendered frame against the ground truth (clamped like the saved PNGs the
-        reference evaluates, benchmark.py:191-230)."""
-        img = torch.clamp(render4[:3].permute(1, 2, 0), 0.0, 1.0)
+        """PSNR of a rendered frame against the ground truth, on what the reference evaluates (benchmark.py:191-230): the
+        SAVED image -- render2img's clamp, x 255, truncation to uint8 (render.py:158-166) -- read back as uint8 / 255."""
+        img = torch.floor(torch.clamp(render4[:3].permute(1, 2, 0), 0.0, 1.0) * 255.0) / 255.0
         mse = ((img - self.gt_image) ** 2).mean()
         return -10.0 * torch.log10(mse)
