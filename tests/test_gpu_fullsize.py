@@ -79,7 +79,9 @@ def test_fullsize_fused_iteration_matches_oracle(which):
     loss, info = FO.fit_loss(rc, pose, ab, raw["intr"], dict(image=frame["image"], depth=frame["depth"]), 0.0,
                              lam["lambda_rgb"], lam["lambda_depth"], lam["lambda_var"])
     loss.backward()
-    close_frac(eng.render, info["render4"], 1e-4, 1e-5, bad_frac=3e-4, hard=5e-2, what=f"{which}: render vs oracle")
+    # observed (round 3, gpurun_out/observed_parity.log): 1-2e-5 of the pixels off the 1e-4 tolerance, largest error 1.5e-3 /
+    # 2.3e-3 (threshold flips of single splats at single pixels), 99.99th percentile 9e-6
+    close_frac(eng.render, info["render4"], 1e-4, 1e-5, bad_frac=1e-4, hard=1e-2, what=f"{which}: render vs oracle")
     assert eng.K <= info["K"]                                   # exact-disc culling only ever drops pairs
     l_rgb, l_depth = eng.loss_terms()
     assert abs(l_rgb.item() - info["l_rgb"].item()) <= 1e-4 * abs(info["l_rgb"].item())
