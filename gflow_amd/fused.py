@@ -143,7 +143,7 @@ class FitEngine:
         self.d_rec = torch.zeros(cap, REC, **f32)
         if old is not None and n:
             self.params[:n] = old[:n]
-        self.K_cap = int(self.K_cap_req) if self.K_cap_req else max(2_000_000, 4 * cap)
+        self.K_cap = int(self.K_cap_req) if self.K_cap_req else max(4_000_000, 8 * cap)     # (64 B per pair: 0.25-0.5 GB of 288)
         self.ids = torch.zeros(self.K_cap, dtype=torch.int32, device=self.dev)
         nbytes = self.lib.gfl_fit_workspace_bytes(cap, self.K_cap, self.W, self.H)
         self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.dev)   # the pool counter must start at 0
