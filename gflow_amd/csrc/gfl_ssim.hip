@@ -48,23 +48,6 @@ __device__ __forceinline__ void load12(const float* __restrict__ row, float (&v)
     v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
 }
 
-// First-version statistics kernel (one output per lane); the sliding-window variants measured
-// slower here (36 us vs 26 us): the kernel is bound by halo re-fetch through L2, not by LDS.
-__device__ __forceinline__ float ld_render(const float* __restrict__ render, const uint8_t* __restrict__ keep, int c,
-                                           int x, int y, int W, int H) {
-    if (x < 0 || y < 0 || x >= W || y >= H) return 0.f;
-    const size_t pix = (size_t)y * W + x;
-    const float v = render[(size_t)c * H * W + pix];
-    return (keep && !keep[pix]) ? 0.f : v;
-}
-__device__ __forceinline__ float ld_gt(const float* __restrict__ gt_rgb, const uint8_t* __restrict__ keep, int c, int x,
-                                       int y, int W, int H) {
-    if (x < 0 || y < 0 || x >= W || y >= H) return 0.f;
-    const size_t pix = (size_t)y * W + x;
-    const float v = gt_rgb[pix * 3 + c];
-    return (keep && !keep[pix]) ? 0.f : v;
-}
-
 // grid gx*gy*3 blocks in XCD order, the three channel blocks of a tile adjacent (they share the
 // HWC ground-truth lines); dmaps[3 channels][3 maps][H][W]; partial[block] = sum of S
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -75,7 +58,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 //         during the hundreds of iterations of a fit): three maps instead of five through LDS and
 //         the filter passes.
 // MODE 2: write gt_stats, nothing else.
-template <int MODE>
+// KEEP: an occlusion mask is given (a second template parameter instead of a pointer test per load: the staging loads
+// below have to be straight-line code to be issued together).
+template <int MODE, bool KEEP>
 __global__ void __launch_bounds__(256) ssim_stats_kernel(const float* __restrict__ render,
                                                          const float* __restrict__ gt_rgb,
                                                          const uint8_t* __restrict__ keep, int W, int H, int gx,
@@ -108,10 +93,34 @@ __global__ void __launch_bounds__(256) ssim_stats_kernel(const float* __restrict
             e22_own = gt_stats[(size_t)(2 * c + 1) * H * W + opix];
         }
     }
-    for (int i = tid; i < SI * SI; i += 256) {
+    // Staging: ALL of a lane's loads (three staged pixels x render, target, mask) are issued before the first is used.
+    // Written as a loop with a load, a test and a store per pass, the compiler waited for memory in every pass: six
+    // dependent round trips in the life of a workgroup, which is what these kernels' duration was made of.  Addresses
+    // outside the image are clamped to pixel 0 and the value replaced afterwards.
+    constexpr int NS = (SI * SI + 255) / 256;
+    const size_t plane_s = (size_t)H * W;
+    float xs[NS], ys[NS];
+    int kb[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int i = min(tid + 256 * j, SI * SI - 1);
         const int r = i / SI, q = i - r * SI;
-        const float xv = MODE == 2 ? 0.f : ld_render(render, keep, c, x0 + q, y0 + r, W, H);
-        const float yv = ld_gt(gt_rgb, keep, c, x0 + q, y0 + r, W, H);
+        const int x = x0 + q, y = y0 + r;
+        const bool in = x >= 0 && y >= 0 && x < W && y < H;
+        const size_t pix = in ? (size_t)y * W + x : 0;
+        xs[j] = MODE == 2 ? 0.f : render[(size_t)c * plane_s + pix];
+        ys[j] = gt_rgb[pix * 3 + c];
+        kb[j] = KEEP ? (int)keep[pix] : 1;
+    }
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        // (no branch here either, or the last pass's loads sink into it: lanes past the end write the pad column)
+        const int i = tid + 256 * j;
+        int r = i / SI, q = i - r * SI;
+        const int x = x0 + q, y = y0 + r;
+        const bool k = x >= 0 && y >= 0 && x < W && y < H && kb[j] != 0;
+        const float xv = k ? xs[j] : 0.f, yv = k ? ys[j] : 0.f;
+        if (i >= SI * SI) { r = tid & 15; q = SI; }
         if (MODE == 0) {
             s_a[r][q] = (v2f){xv, yv};
             s_b[r][q] = (v2f){xv * xv, yv * yv};
@@ -196,6 +205,7 @@ __global__ void __launch_bounds__(256) ssim_stats_kernel(const float* __restrict
 // grid gx*gy*4 blocks in XCD order, the four blocks of a tile adjacent: 0..2 -> gradient of one
 // rgb plane; 3 -> depth plane + per-pixel mse.
 // partial rows: [block][4] = {sum mse_px, sum depth term, d/d depth_a, d/d depth_b}
+template <bool KEEP>
 __global__ void __launch_bounds__(256) loss_grad_kernel(
     const float* __restrict__ render, const float* __restrict__ gt_rgb, const float* __restrict__ gt_depth,
     const uint8_t* __restrict__ keep, const float* __restrict__ depth_ab, const float* __restrict__ dmaps, int W, int H,
@@ -213,22 +223,32 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(
         const int px = bx * ST + lx, py = by * ST + ly;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (px < W && py < H) {
+            // every load first (see the staging below)
             const size_t pix = (size_t)py * W + px;
-            const bool k = !(keep && !keep[pix]);
+            const int kb = KEEP ? (int)keep[pix] : 1;
+            float rr[3], gg[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                rr[c] = render[c * plane + pix];
+                gg[c] = gt_rgb[pix * 3 + c];
+            }
+            const bool with_depth = depth_scale != 0.f;
+            const float D = with_depth ? render[3 * plane + pix] : 0.f;
+            const float gt = with_depth ? gt_depth[pix] : 0.f;
+            const bool k = kb != 0;
             float e = 0.f;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float d = k ? (render[c * plane + pix] - gt_rgb[pix * 3 + c]) : 0.f;
+                const float d = k ? (rr[c] - gg[c]) : 0.f;
                 e = fmaf(d, d, e);
             }
             e *= (1.f / 3.f);
             err_px[pix] = e;
             v[0] = e;
             float gD = 0.f;
-            if (depth_scale != 0.f) {
+            if (with_depth) {
                 const float a = depth_ab[0], b = depth_ab[1];
-                const float D = render[3 * plane + pix];
-                const float d = fmaf(a, D, b), gt = gt_depth[pix];
+                const float d = fmaf(a, D, b);
                 const float diff = d - gt, sum = d + gt;
                 if (k) {
                     v[1] = diff * diff / sum;
@@ -255,7 +275,7 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(
     // the column-pass lanes fetch their own pixels' x, y now: issued last, the two loads would sit
     // at the end of the workgroup's life with nothing left to overlap them
     float own_x[2] = {0.f, 0.f}, own_y[2] = {0.f, 0.f};
-    bool own_keep[2] = {false, false};
+    int own_kb[2] = {0, 0};
     if (tid < 128) {
         const int r0 = (tid >> 4) * 2, col = tid & 15;
         const int px = bx * ST + col;
@@ -264,21 +284,37 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(
             const int py = by * ST + r0 + o;
             if (px < W && py < H) {
                 const size_t pix = (size_t)py * W + px;
-                own_keep[o] = !(keep && !keep[pix]);
+                own_kb[o] = KEEP ? (int)keep[pix] : 1;
                 own_x[o] = render[ch * plane + pix];
                 own_y[o] = gt_rgb[pix * 3 + ch];
             }
         }
     }
-    for (int i = tid; i < SI * 32; i += 256) {       // 28 of every 32 slots: columns 26, 27 are zero padding
-        const int r = i >> 5, q = i & 31;
-        if (q >= 28) continue;
+    // staging: 26 rows x 28 columns (columns 26, 27 are zero padding for the 16-byte row reads) of the three maps, all
+    // nine loads of a lane in flight together (ssim_stats_kernel explains why)
+    constexpr int SQ = 28, NG = (SI * SQ + 255) / 256;
+    float dm[NG][3];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int i = min(tid + 256 * j, SI * SQ - 1);
+        const int r = i / SQ, q = i - r * SQ;
         const int x = x0 + q, y = y0 + r;
         const bool in = q < SI && x >= 0 && y >= 0 && x < W && y < H;
-        const size_t p = (size_t)y * W + x;
-        sm[0][r][q] = in ? base[p] : 0.f;
-        sm[1][r][q] = in ? base[plane + p] : 0.f;
-        sm[2][r][q] = in ? base[2 * plane + p] : 0.f;
+        const size_t p = in ? (size_t)y * W + x : 0;
+        dm[j][0] = base[p];
+        dm[j][1] = base[plane + p];
+        dm[j][2] = base[2 * plane + p];
+    }
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int i = tid + 256 * j;
+        int r = i / SQ, q = i - r * SQ;
+        const int x = x0 + q, y = y0 + r;
+        const bool in = q < SI && x >= 0 && y >= 0 && x < W && y < H;
+        if (i >= SI * SQ) { r = tid & 15; q = SQ + 4; }      // lanes past the end: a pad column nobody reads
+        sm[0][r][q] = in ? dm[j][0] : 0.f;
+        sm[1][r][q] = in ? dm[j][1] : 0.f;
+        sm[2][r][q] = in ? dm[j][2] : 0.f;
     }
     __syncthreads();
     // row pass: item = (map, row, group of 4 columns): 312 items
@@ -321,7 +357,7 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(
             if (px < W && py < H) {
                 const size_t pix = (size_t)py * W + px;
                 float out = 0.f;
-                if (own_keep[o]) {
+                if (own_kb[o] != 0) {
                     const float x = own_x[o], y = own_y[o];
                     out = g[0][o] + 2.f * x * g[1][o] + y * g[2][o] + mse_scale * (x - y);
                 }
@@ -402,15 +438,14 @@ static int loss_launch(const float* render, const float* gt_rgb, const float* gt
     static const Win win = make_window();
     const float hw = (float)W * (float)H;
     // L = lambda_rgb * (mean mse + 1 - mean S)  ->  dL/dS = -lambda_rgb / (3HW)
-    if (gt_stats)
-        ssim_stats_kernel<1><<<gx * gy * 3, 256, 0, s>>>(render, gt_rgb, keep, W, H, gx, gy, win, -lambda_rgb / (3.f * hw),
-                                                      dmaps, p_ssim, const_cast<float*>(gt_stats));
-    else
-        ssim_stats_kernel<0><<<gx * gy * 3, 256, 0, s>>>(render, gt_rgb, keep, W, H, gx, gy, win, -lambda_rgb / (3.f * hw),
-                                                      dmaps, p_ssim, nullptr);
-    loss_grad_kernel<<<gx * gy * 4, 256, 0, s>>>(render, gt_rgb, gt_depth, keep, depth_ab, dmaps, W, H, gx, gy, win,
-                                              lambda_rgb * 2.f / (3.f * hw), lambda_depth / hw, d_render, err_px,
-                                              p_grad);
+    const float s_scale = -lambda_rgb / (3.f * hw);
+    float* st = const_cast<float*>(gt_stats);
+    auto stats = gt_stats ? (keep ? ssim_stats_kernel<1, true> : ssim_stats_kernel<1, false>)
+                          : (keep ? ssim_stats_kernel<0, true> : ssim_stats_kernel<0, false>);
+    stats<<<gx * gy * 3, 256, 0, s>>>(render, gt_rgb, keep, W, H, gx, gy, win, s_scale, dmaps, p_ssim, st);
+    auto grad = keep ? loss_grad_kernel<true> : loss_grad_kernel<false>;
+    grad<<<gx * gy * 4, 256, 0, s>>>(render, gt_rgb, gt_depth, keep, depth_ab, dmaps, W, H, gx, gy, win,
+                                     lambda_rgb * 2.f / (3.f * hw), lambda_depth / hw, d_render, err_px, p_grad);
     if (sums) loss_fold_kernel<<<1, 1024, 0, s>>>(p_ssim, gx * gy * 3, p_grad, gx * gy, sums);
     if (p_ssim_out) { *p_ssim_out = p_ssim; *n_ssim = gx * gy * 3; *p_grad_out = p_grad; *n_grad = gx * gy; }
     return check_launch();
@@ -438,8 +473,9 @@ int gfl_loss_prepare_gt(const float* gt_rgb, const uint8_t* keep, int W, int H, 
     if (W <= 0 || H <= 0 || !gt_rgb || !gt_stats) return GFL_ERR_INVALID;
     const int gx = (W + ST - 1) / ST, gy = (H + ST - 1) / ST;
     static const Win win = make_window();
-    ssim_stats_kernel<2><<<gx * gy * 3, 256, 0, (hipStream_t)stream>>>(nullptr, gt_rgb, keep, W, H, gx, gy, win, 0.f, nullptr,
-                                                                     nullptr, gt_stats);
+    auto stats = keep ? ssim_stats_kernel<2, true> : ssim_stats_kernel<2, false>;
+    stats<<<gx * gy * 3, 256, 0, (hipStream_t)stream>>>(nullptr, gt_rgb, keep, W, H, gx, gy, win, 0.f, nullptr, nullptr,
+                                                        gt_stats);
     return check_launch();
 }
 
