@@ -40,6 +40,19 @@ __device__ __forceinline__ void load16(const float* __restrict__ row, float (&v)
     v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w; v[12] = d.x; v[13] = d.y; v[14] = d.z; v[15] = d.w;
 }
 
+// a float at a 32-bit BYTE offset from a wave-uniform base: the address costs no 64-bit vector arithmetic
+__device__ __forceinline__ float ld_f32(const float* __restrict__ base, unsigned byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+// y * W + x as ONE full-rate 24-bit multiply-add (the launcher checks W, H < 2^24): a plain 32-bit multiply is a
+// quarter-rate instruction, and the 64-bit multiply-add the compiler picked instead dragged a register pair with a
+// don't-care high half along -- which happened to be the destination of a load in flight, a wait for memory in the
+// middle of the address arithmetic
+__device__ __forceinline__ unsigned pixel_index(int y, int W, int x) { return __umul24((unsigned)y, (unsigned)W) + (unsigned)x; }
+__device__ __forceinline__ void st_f32(float* __restrict__ base, unsigned byte_off, float v) {
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
 // 12 floats starting at a 16-byte aligned LDS address
 __device__ __forceinline__ void load12(const float* __restrict__ row, float (&v)[12]) {
     const float4* p = reinterpret_cast<const float4*>(row);
@@ -67,86 +80,113 @@ __global__ void __launch_bounds__(256) ssim_stats_kernel(const float* __restrict
                                                          int gy, Win win, float scale /* dL/dS per element */,
                                                          float* __restrict__ dmaps, float* __restrict__ partial,
                                                          float* __restrict__ gt_stats) {
-    // The kernel was bound by VALU issue (62 % busy, rocprofv3 PMC), so the maps are staged as
-    // packed pairs with the products formed ONCE per staged pixel, and both filter passes run
-    // v_pk_fma_f32 on the pairs.  pair = (x, y) and (x^2, y^2) in MODE 0, (x, x^2) in MODE 1,
-    // (y, y^2) in MODE 2; the fifth map xy is a plain float (MODE 0 and 1).
-    __shared__ v2f s_a[SI][SI + 1];
-    __shared__ v2f s_b[MODE == 0 ? SI : 1][SI + 1];
-    __shared__ float s_x_y[MODE == 2 ? 1 : SI][SI + 1];
-    __shared__ v2f h_a[SI][ST + 1];
-    __shared__ v2f h_b[MODE == 0 ? SI : 1][ST + 1];
-    __shared__ float h_xy[MODE == 2 ? 1 : SI][ST + 1];
-    const int lb = xcd_logical_block(blockIdx.x, gx * gy * 3);
+    // The kernel is bound by VALU issue, so the maps are staged as packed pairs with the products formed ONCE per
+    // staged pixel, and both filter passes run v_pk_fma_f32 on the pairs.  pair = (x, y) and (x^2, y^2) in MODE 0,
+    // (x, x^2) in MODE 1, (y, y^2) in MODE 2; the fifth map xy is a plain float (MODE 0 and 1).
+    // Pitches: a half-wave of the row pass reads two staged rows (8-byte reads: pitch = 16 pairs mod 32 keeps them on
+    // disjoint banks), a wave four rows of the xy map (pitch = 16 floats mod 64 likewise); the row-filtered maps are read
+    // by the column pass the same way with 16 columns, so they are not padded at all.
+    constexpr int APITCH = 48, ROWS = SI + 1;          // row SI: where the lanes past the last staged row write
+    __shared__ __attribute__((aligned(16))) v2f s_a[ROWS][APITCH];
+    __shared__ __attribute__((aligned(16))) v2f s_b[MODE == 0 ? ROWS : 1][APITCH];
+    __shared__ __attribute__((aligned(16))) float s_x_y[MODE == 2 ? 1 : ROWS][APITCH];
+    __shared__ __attribute__((aligned(16))) v2f h_a[SI][ST];
+    __shared__ __attribute__((aligned(16))) v2f h_b[MODE == 0 ? SI : 1][ST];
+    __shared__ __attribute__((aligned(16))) float h_xy[MODE == 2 ? 1 : SI][ST];
+    const int lb = __builtin_amdgcn_readfirstlane(xcd_logical_block(blockIdx.x, gx * gy * 3));
     const int c = lb % 3, tile = lb / 3;
     const int bx = tile % gx, by = tile / gx;
     const int x0 = bx * ST - SR, y0 = by * ST - SR;
     const int tid = threadIdx.x;
+    const unsigned plane_b = (unsigned)H * (unsigned)W * 4u;       // bytes of a plane (the launcher checks 36 HW < 2^32)
     // MODE 1: the cached statistics of this lane's own pixel, requested before anything else (read where they are
     // used, after the column pass, the two loads were a full memory round trip at the end of the workgroup's life)
     float mu2_own = 0.f, e22_own = 0.f;
     if (MODE == 1) {
         const int opx = bx * ST + (tid & 15), opy = by * ST + (tid >> 4);
         if (opx < W && opy < H) {
-            const size_t opix = (size_t)opy * W + opx;
-            mu2_own = gt_stats[(size_t)(2 * c) * H * W + opix];
-            e22_own = gt_stats[(size_t)(2 * c + 1) * H * W + opix];
+            const unsigned ob = (pixel_index(opy, W, opx)) * 4u + 2u * c * plane_b;
+            mu2_own = ld_f32(gt_stats, ob);
+            e22_own = ld_f32(gt_stats, ob + plane_b);
         }
     }
-    // Staging: ALL of a lane's loads (three staged pixels x render, target, mask) are issued before the first is used.
-    // Written as a loop with a load, a test and a store per pass, the compiler waited for memory in every pass: six
-    // dependent round trips in the life of a workgroup, which is what these kernels' duration was made of.  Addresses
-    // outside the image are clamped to pixel 0 and the value replaced afterwards.
-    constexpr int NS = (SI * SI + 255) / 256;
-    const size_t plane_s = (size_t)H * W;
+    // Staging.  A lane owns ONE staged column (32 lanes across, 26 in use) and every eighth row: four passes whose
+    // addresses differ by a constant, with 32-bit byte offsets from uniform bases.  ALL of a lane's loads are issued
+    // before the first is used and nothing below branches: written as a loop with a load, a test and a store per pass,
+    // the compiler waited for memory in every pass -- six dependent round trips in the life of a workgroup, which is what
+    // this kernel's duration was made of.  Addresses outside the image are clamped to pixel 0 and the value replaced.
+    constexpr int NS = 4;
+    const int sq = tid & 31, srg = tid >> 5;
+    const int sx = x0 + sq;
+    const bool in_x = sq < SI && sx >= 0 && sx < W;
+    const unsigned c_plane_b = (unsigned)c * plane_b;
     float xs[NS], ys[NS];
     int kb[NS];
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
-        const int i = min(tid + 256 * j, SI * SI - 1);
-        const int r = i / SI, q = i - r * SI;
-        const int x = x0 + q, y = y0 + r;
-        const bool in = x >= 0 && y >= 0 && x < W && y < H;
-        const size_t pix = in ? (size_t)y * W + x : 0;
-        xs[j] = MODE == 2 ? 0.f : render[(size_t)c * plane_s + pix];
-        ys[j] = gt_rgb[pix * 3 + c];
+        const int y = y0 + srg + 8 * j;
+        const bool in = in_x && (srg + 8 * j) < SI && (unsigned)y < (unsigned)H;
+        const unsigned pix = in ? pixel_index(y, W, sx) : 0u;
+        const unsigned pix4 = pix << 2;
+        xs[j] = MODE == 2 ? 0.f : ld_f32(render, pix4 + c_plane_b);
+        ys[j] = ld_f32(gt_rgb, pix4 + (pix4 << 1) + 4u * c);
         kb[j] = KEEP ? (int)keep[pix] : 1;
     }
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
-        // (no branch here either, or the last pass's loads sink into it: lanes past the end write the pad column)
-        const int i = tid + 256 * j;
-        int r = i / SI, q = i - r * SI;
-        const int x = x0 + q, y = y0 + r;
-        const bool k = x >= 0 && y >= 0 && x < W && y < H && kb[j] != 0;
+        const int y = y0 + srg + 8 * j;
+        const bool k = in_x && (srg + 8 * j) < SI && (unsigned)y < (unsigned)H && kb[j] != 0;
         const float xv = k ? xs[j] : 0.f, yv = k ? ys[j] : 0.f;
-        if (i >= SI * SI) { r = tid & 15; q = SI; }
+        const int r = min(srg + 8 * j, SI);              // rows past the end -> the spare row (columns >= 26: padding)
         if (MODE == 0) {
-            s_a[r][q] = (v2f){xv, yv};
-            s_b[r][q] = (v2f){xv * xv, yv * yv};
+            s_a[r][sq] = (v2f){xv, yv};
+            s_b[r][sq] = (v2f){xv * xv, yv * yv};
         } else if (MODE == 1) {
-            s_a[r][q] = (v2f){xv, xv * xv};
+            s_a[r][sq] = (v2f){xv, xv * xv};
         } else {
-            s_a[r][q] = (v2f){yv, yv * yv};
+            s_a[r][sq] = (v2f){yv, yv * yv};
         }
-        if (MODE != 2) s_x_y[r][q] = xv * yv;
+        if (MODE != 2) s_x_y[r][sq] = xv * yv;
     }
     __syncthreads();
-    for (int i = tid; i < SI * ST; i += 256) {
-        const int r = i / ST, q = i - r * ST;
-        v2f a_a = {0.f, 0.f}, a_b = {0.f, 0.f};
-        float a_xy = 0.f;
+    // row pass: a lane produces TWO adjacent outputs of a row from twelve staged pixels read once (six 16-byte reads of
+    // pairs, six 8-byte reads of xy) -- 26 x 8 = 208 lanes, one pass, a quarter of the LDS reads of one output per lane
+    if (tid < SI * 8) {
+        const int r = tid >> 3, q = (tid & 7) * 2;
+        v2f A[12], B[12];
+        float X[12];
+#pragma unroll
+        for (int k = 0; k < 12; k += 2) {
+            const float4 t = *reinterpret_cast<const float4*>(&s_a[r][q + k]);
+            A[k] = (v2f){t.x, t.y};
+            A[k + 1] = (v2f){t.z, t.w};
+            if (MODE == 0) {
+                const float4 u = *reinterpret_cast<const float4*>(&s_b[r][q + k]);
+                B[k] = (v2f){u.x, u.y};
+                B[k + 1] = (v2f){u.z, u.w};
+            }
+            if (MODE != 2) {
+                const float2 u = *reinterpret_cast<const float2*>(&s_x_y[r][q + k]);
+                X[k] = u.x;
+                X[k + 1] = u.y;
+            }
+        }
+        v2f a_a[2] = {{0.f, 0.f}, {0.f, 0.f}}, a_b[2] = {{0.f, 0.f}, {0.f, 0.f}};
+        float a_xy[2] = {0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < SW; ++k) {
             const float w = win.w[k];
             const v2f w2 = {w, w};
-            a_a = __builtin_elementwise_fma(w2, s_a[r][q + k], a_a);
-            if (MODE == 0) a_b = __builtin_elementwise_fma(w2, s_b[r][q + k], a_b);
-            if (MODE != 2) a_xy = fmaf(w, s_x_y[r][q + k], a_xy);
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                a_a[o] = __builtin_elementwise_fma(w2, A[o + k], a_a[o]);
+                if (MODE == 0) a_b[o] = __builtin_elementwise_fma(w2, B[o + k], a_b[o]);
+                if (MODE != 2) a_xy[o] = fmaf(w, X[o + k], a_xy[o]);
+            }
         }
-        h_a[r][q] = a_a;
-        if (MODE == 0) h_b[r][q] = a_b;
-        if (MODE != 2) h_xy[r][q] = a_xy;
+        *reinterpret_cast<float4*>(&h_a[r][q]) = make_float4(a_a[0].x, a_a[0].y, a_a[1].x, a_a[1].y);
+        if (MODE == 0) *reinterpret_cast<float4*>(&h_b[r][q]) = make_float4(a_b[0].x, a_b[0].y, a_b[1].x, a_b[1].y);
+        if (MODE != 2) *reinterpret_cast<float2*>(&h_xy[r][q]) = make_float2(a_xy[0], a_xy[1]);
     }
     __syncthreads();
     const int lx = tid & 15, ly = tid >> 4;
@@ -163,10 +203,10 @@ __global__ void __launch_bounds__(256) ssim_stats_kernel(const float* __restrict
             if (MODE == 0) fb = __builtin_elementwise_fma(w2, h_b[ly + k][lx], fb);
             if (MODE != 2) e12 = fmaf(w, h_xy[ly + k][lx], e12);
         }
-        const size_t plane = (size_t)H * W, pix = (size_t)py * W + px;
+        const unsigned pb = (pixel_index(py, W, px)) * 4u;
         if (MODE == 2) {
-            gt_stats[(size_t)(2 * c) * plane + pix] = fa.x;          // mu2
-            gt_stats[(size_t)(2 * c + 1) * plane + pix] = fa.y;      // E[y^2]
+            st_f32(gt_stats, pb + 2u * c * plane_b, fa.x);                    // mu2
+            st_f32(gt_stats, pb + (2u * c + 1u) * plane_b, fa.y);             // E[y^2]
             return;
         }
         float mu1, mu2, e11, e22;
@@ -181,15 +221,18 @@ __global__ void __launch_bounds__(256) ssim_stats_kernel(const float* __restrict
         const float s1 = e11 - mu1s, s2 = e22 - mu2s, s12 = e12 - mu12;
         const float A1 = 2.f * mu12 + SSIM_C1, A2 = 2.f * s12 + SSIM_C2;
         const float B1 = mu1s + mu2s + SSIM_C1, B2 = s1 + s2 + SSIM_C2;
-        const float inv = 1.f / (B1 * B2);
+        // two hardware reciprocals (1 ulp) instead of three IEEE divisions (~10 VALU instructions each): B1 >= C1,
+        // B2 ~ C2 + variances, nowhere near the denormals
+        const float r1 = __builtin_amdgcn_rcpf(B1), r2 = __builtin_amdgcn_rcpf(B2);
+        const float inv = r1 * r2;
         sval = A1 * A2 * inv;
-        const float d_e11 = -sval / B2;
+        const float d_e11 = -sval * r2;
         const float d_e12 = 2.f * A1 * inv;
-        const float d_mu1 = 2.f * mu2 * (A2 - A1) * inv - 2.f * mu1 * sval * (1.f / B1 - 1.f / B2);
-        float* base = dmaps + (size_t)c * 3 * plane;
-        base[pix] = scale * d_mu1;
-        base[plane + pix] = scale * d_e11;
-        base[2 * plane + pix] = scale * d_e12;
+        const float d_mu1 = 2.f * mu2 * (A2 - A1) * inv - 2.f * mu1 * sval * (r1 - r2);
+        const unsigned mb = pb + 3u * c * plane_b;       // dmaps[c][3][H][W]
+        st_f32(dmaps, mb, scale * d_mu1);
+        st_f32(dmaps, mb + plane_b, scale * d_e11);
+        st_f32(dmaps, mb + 2u * plane_b, scale * d_e12);
     }
     if (MODE == 2) return;
     float v[1] = {sval};
@@ -211,11 +254,12 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(
     const uint8_t* __restrict__ keep, const float* __restrict__ depth_ab, const float* __restrict__ dmaps, int W, int H,
     int gx, int gy, Win win, float mse_scale /* lambda_rgb * 2/(3HW) */, float depth_scale /* lambda_depth/(HW) */,
     float* __restrict__ d_render, float* __restrict__ err_px, float* __restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) float sm[3][SI][SP];
+    __shared__ __attribute__((aligned(16))) float sm[3][SI + 1][SP];   // row SI: where lanes past the last row write
     __shared__ __attribute__((aligned(16))) float hz[3][SI][HP];
     const int tid = threadIdx.x;
     const size_t plane = (size_t)H * W;
-    const int lb = xcd_logical_block(blockIdx.x, gx * gy * 4);
+    const unsigned plane_b = (unsigned)H * (unsigned)W * 4u;           // (the launcher checks 36 HW < 2^32)
+    const int lb = __builtin_amdgcn_readfirstlane(xcd_logical_block(blockIdx.x, gx * gy * 4));
     const int ch = lb & 3, tile = lb >> 2;
     const int bx = tile % gx, by = tile / gx;
     if (ch == 3) {
@@ -271,7 +315,6 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(
         return;
     }
     const int x0 = bx * ST - SR, y0 = by * ST - SR;
-    const float* base = dmaps + (size_t)ch * 3 * plane;
     // the column-pass lanes fetch their own pixels' x, y now: issued last, the two loads would sit
     // at the end of the workgroup's life with nothing left to overlap them
     float own_x[2] = {0.f, 0.f}, own_y[2] = {0.f, 0.f};
@@ -283,38 +326,39 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(
         for (int o = 0; o < 2; ++o) {
             const int py = by * ST + r0 + o;
             if (px < W && py < H) {
-                const size_t pix = (size_t)py * W + px;
+                const unsigned pix = pixel_index(py, W, px);
                 own_kb[o] = KEEP ? (int)keep[pix] : 1;
-                own_x[o] = render[ch * plane + pix];
-                own_y[o] = gt_rgb[pix * 3 + ch];
+                own_x[o] = ld_f32(render, pix * 4u + ch * plane_b);
+                own_y[o] = ld_f32(gt_rgb, pix * 12u + ch * 4u);
             }
         }
     }
-    // staging: 26 rows x 28 columns (columns 26, 27 are zero padding for the 16-byte row reads) of the three maps, all
-    // nine loads of a lane in flight together (ssim_stats_kernel explains why)
-    constexpr int SQ = 28, NG = (SI * SQ + 255) / 256;
+    // staging: 26 rows x 28 columns (columns 26, 27 are zero padding for the 16-byte row reads) of the three maps.  A
+    // lane owns one column (32 across) and every eighth row, four passes, all twelve loads in flight together and no
+    // branch below (ssim_stats_kernel explains why)
+    constexpr int NG = 4;
+    const int sq = tid & 31, srg = tid >> 5;
+    const int sx = x0 + sq;
+    const bool in_x = sq < SI && sx >= 0 && sx < W;
+    const unsigned map_b = 3u * ch * plane_b;
     float dm[NG][3];
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
-        const int i = min(tid + 256 * j, SI * SQ - 1);
-        const int r = i / SQ, q = i - r * SQ;
-        const int x = x0 + q, y = y0 + r;
-        const bool in = q < SI && x >= 0 && y >= 0 && x < W && y < H;
-        const size_t p = in ? (size_t)y * W + x : 0;
-        dm[j][0] = base[p];
-        dm[j][1] = base[plane + p];
-        dm[j][2] = base[2 * plane + p];
+        const int y = y0 + srg + 8 * j;
+        const bool in = in_x && (srg + 8 * j) < SI && (unsigned)y < (unsigned)H;
+        const unsigned pb = (in ? (pixel_index(y, W, sx)) << 2 : 0u) + map_b;
+        dm[j][0] = ld_f32(dmaps, pb);
+        dm[j][1] = ld_f32(dmaps, pb + plane_b);
+        dm[j][2] = ld_f32(dmaps, pb + 2u * plane_b);
     }
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
-        const int i = tid + 256 * j;
-        int r = i / SQ, q = i - r * SQ;
-        const int x = x0 + q, y = y0 + r;
-        const bool in = q < SI && x >= 0 && y >= 0 && x < W && y < H;
-        if (i >= SI * SQ) { r = tid & 15; q = SQ + 4; }      // lanes past the end: a pad column nobody reads
-        sm[0][r][q] = in ? dm[j][0] : 0.f;
-        sm[1][r][q] = in ? dm[j][1] : 0.f;
-        sm[2][r][q] = in ? dm[j][2] : 0.f;
+        const int y = y0 + srg + 8 * j;
+        const bool in = in_x && (srg + 8 * j) < SI && (unsigned)y < (unsigned)H;
+        const int r = min(srg + 8 * j, SI);               // (columns 28..31 land in the pitch's padding)
+        sm[0][r][sq] = in ? dm[j][0] : 0.f;
+        sm[1][r][sq] = in ? dm[j][1] : 0.f;
+        sm[2][r][sq] = in ? dm[j][2] : 0.f;
     }
     __syncthreads();
     // row pass: item = (map, row, group of 4 columns): 312 items
@@ -355,13 +399,12 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(
         for (int o = 0; o < 2; ++o) {
             const int py = by * ST + r0 + o;
             if (px < W && py < H) {
-                const size_t pix = (size_t)py * W + px;
                 float out = 0.f;
                 if (own_kb[o] != 0) {
                     const float x = own_x[o], y = own_y[o];
                     out = g[0][o] + 2.f * x * g[1][o] + y * g[2][o] + mse_scale * (x - y);
                 }
-                d_render[ch * plane + pix] = out;
+                st_f32(d_render, (pixel_index(py, W, px)) * 4u + ch * plane_b, out);
             }
         }
     }
@@ -430,6 +473,8 @@ static int loss_launch(const float* render, const float* gt_rgb, const float* gt
     if (W <= 0 || H <= 0 || !render || !gt_rgb || !d_render || !err_px || !workspace) return GFL_ERR_INVALID;
     if (lambda_depth != 0.f && (!gt_depth || !depth_ab)) return GFL_ERR_INVALID;
     if (workspace_bytes < gfl_loss_workspace_bytes(W, H)) return GFL_ERR_WORKSPACE;
+    if ((uint64_t)W * (uint64_t)H * 36u >= (1ull << 32) || W >= (1 << 24) || H >= (1 << 24))
+        return GFL_ERR_INVALID;                                      // the kernels' 32-bit byte offsets
     hipStream_t s = (hipStream_t)stream;
     const int gx = (W + ST - 1) / ST, gy = (H + ST - 1) / ST;
     float* dmaps = (float*)workspace;
@@ -471,6 +516,7 @@ int gfl_loss_fwd_bwd_partials(const float* render, const float* gt_rgb, const fl
 
 int gfl_loss_prepare_gt(const float* gt_rgb, const uint8_t* keep, int W, int H, float* gt_stats, gfl_stream_t stream) {
     if (W <= 0 || H <= 0 || !gt_rgb || !gt_stats) return GFL_ERR_INVALID;
+    if ((uint64_t)W * (uint64_t)H * 36u >= (1ull << 32) || W >= (1 << 24) || H >= (1 << 24)) return GFL_ERR_INVALID;
     const int gx = (W + ST - 1) / ST, gy = (H + ST - 1) / ST;
     static const Win win = make_window();
     auto stats = keep ? ssim_stats_kernel<2, true> : ssim_stats_kernel<2, false>;
