@@ -30,7 +30,10 @@
 namespace gfl {
 
 constexpr int BIN_BLOCK = 512;
-constexpr int WIDE_TILES = 16;   // splats covering more tiles are binned by a whole wave
+#ifndef GFL_WIDE_TILES
+#define GFL_WIDE_TILES 16
+#endif
+constexpr int WIDE_TILES = GFL_WIDE_TILES;   // splats covering more tiles are binned by a whole wave
 constexpr int ROW = 16;   // floats per params row
 constexpr int REC = 12;   // floats per rec row
 #ifndef GFL_PG_STRIDE
@@ -39,6 +42,20 @@ constexpr int REC = 12;   // floats per rec row
 constexpr int PG = GFL_PG_STRIDE;   // floats per pair_grad row (12 live; 16 = one 64-byte sector per row)
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// analysis build only (make TRACE=1, tools/phase_trace.py): time stamps of the phases of the latency-bound launches,
+// one row of eight per wave.  kernel 0 = preprocess, 1 = column scan, 2 = scatter, 3 = per-splat backward + Adam
+#ifdef GFL_TRACE
+constexpr int PHASE_WAVES = 4096;
+__device__ long long g_phase_trace[4 * PHASE_WAVES * 8];
+#define GFL_PHASE(kernel, slot)                                                                                      \
+    do {                                                                                                             \
+        const int w_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                                          \
+        if ((threadIdx.x & 63) == 0 && w_ < PHASE_WAVES) g_phase_trace[((kernel) * PHASE_WAVES + w_) * 8 + (slot)] = wall_clock64(); \
+    } while (0)
+#else
+#define GFL_PHASE(kernel, slot) do {} while (0)
+#endif
 
 // pose [qx,qy,qz,qw,tx,ty,tz] -> camera (trainer.py:115-121)
 __device__ __forceinline__ Cam cam_from_pose(const float* __restrict__ intr, const float* __restrict__ pose) {
@@ -90,11 +107,6 @@ __device__ __forceinline__ Splat splat_from_row(const float4& a, const float4& b
     return s;
 }
 
-__device__ __forceinline__ Splat load_splat(const float* __restrict__ params, int i, bool activated = false) {
-    const float4* row = reinterpret_cast<const float4*>(params + (size_t)i * ROW);
-    return splat_from_row(row[0], row[1], row[2], row[3], activated);
-}
-
 // squared radius of the disc outside which alpha < 1/255 for every pixel, with a
 // safety margin so that a culled (splat, tile) pair is skipped by the blend as well
 __device__ __forceinline__ float alpha_cutoff(float o, float lam) {
@@ -136,15 +148,27 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
     // scale_rows_mode != 0 (lambda_scale): count the rows the scale term averages over, per block
     extern __shared__ int32_t hist[];
     const int T = gx * gy;
+    GFL_PHASE(0, 0);
+    // the splat's row first: its latency (1.1 us of the launch's 8, tools/phase_trace.py) then overlaps the clearing of
+    // the histogram, the barrier and the camera's scalar loads instead of following them
+    const int i = blockIdx.x * BIN_BLOCK + threadIdx.x;
+    float4 row_v[4];
+    unsigned own_flags = 0;
+    if (i < N) {
+        const float4* prow = reinterpret_cast<const float4*>(params + (size_t)i * ROW);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) row_v[q] = prow[q];
+        if (scale_rows_mode && row_flags) own_flags = row_flags[i];
+    }
     for (int t = threadIdx.x; t < T; t += BIN_BLOCK) hist[t] = 0;
     __syncthreads();
+    GFL_PHASE(0, 1);
     const Cam c = op_mode ? load_cam(intr, extr_out) : cam_from_pose(intr, pose);
     if (!op_mode && blockIdx.x == 0 && threadIdx.x == 0) {
         extr_out[0] = c.r00; extr_out[1] = c.r01; extr_out[2] = c.r02; extr_out[3] = c.t0;
         extr_out[4] = c.r10; extr_out[5] = c.r11; extr_out[6] = c.r12; extr_out[7] = c.t1;
         extr_out[8] = c.r20; extr_out[9] = c.r21; extr_out[10] = c.r22; extr_out[11] = c.t2;
     }
-    const int i = blockIdx.x * BIN_BLOCK + threadIdx.x;
     float u = 0.f, v = 0.f, cutoff = 0.f;
     int wx0 = 0, wy0 = 0, wnx = 0, wnt = 0;      // rectangle of a "wide" splat (walked by the wave below)
     int woff = -1;                               // its offset in the slot pool (more than SLOT_MAX tiles)
@@ -153,10 +177,15 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
     Proj p = {};
     float cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (i < N) {
-        s = load_splat(params, i, op_mode != 0);
+        s = splat_from_row(row_v[0], row_v[1], row_v[2], row_v[3], op_mode != 0);
+#ifdef GFL_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GFL_PHASE(0, 2);
+#endif
         p = project_fwd(c, s.x, s.y, s.z, W, H, nearest, extent);
         if (p.vis) cov3d_fwd(s.s, s.q, cov);
     }
+    GFL_PHASE(0, 3);
     Ewa e = {};
     if (EWA_MFMA) e = ewa_fwd_mfma(c, p.vis, p.px, p.py, p.pz, cov, W, H);       // (the whole wave: no divergence here)
     if (i < N) {
@@ -189,7 +218,7 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
         r4[0] = make_float4(u, v, A, B);
         r4[1] = make_float4(C, s.o, s.c[0], s.c[1]);
         r4[2] = make_float4(s.c[2], depth, cutoff, __int_as_float(rad));
-        in_scale_rows = scale_rows_mode && scale_row(u, v, W, H, row_flags ? row_flags[i] : 0, scale_rows_mode);
+        in_scale_rows = scale_rows_mode && scale_row(u, v, W, H, own_flags, scale_rows_mode);
         int4* iv = reinterpret_cast<int4*>(slot_inv + (size_t)i * SLOT_MAX);
         const int4 none = make_int4(-1, -1, -1, -1);
         // only the slots of the splat's own tile rectangle are ever read (gather of the backward)
@@ -208,6 +237,7 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
             }
         }
     }
+    GFL_PHASE(0, 4);
     {
         // splats covering many tiles: the whole wave counts their tiles, 64 at a time
         const int lane = threadIdx.x & 63;
@@ -237,9 +267,12 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
             scale_cnt[blockIdx.x] = tot;
         }
     }
+    GFL_PHASE(0, 5);
     __syncthreads();
+    GFL_PHASE(0, 6);
     int32_t* row = hist_g + (size_t)blockIdx.x * T;
     for (int t = threadIdx.x; t < T; t += BIN_BLOCK) row[t] = hist[t];
+    GFL_PHASE(0, 7);
 }
 
 // Columns of hist -> exclusive per-block bases (in place) and per-tile totals.
@@ -261,6 +294,7 @@ __global__ void __launch_bounds__(256) bin_colscan_kernel(int32_t* __restrict__ 
     if (blockIdx.x == 0)
         for (int c = threadIdx.x; c < n_pull; c += 256) pull_counters[c] = 0;
     __shared__ int32_t gsum[CS_GROUPS][CS_TILES];
+    GFL_PHASE(1, 0);
     const int tl = threadIdx.x % CS_TILES, rg = threadIdx.x / CS_TILES;
     const int t = blockIdx.x * CS_TILES + tl;
     const int R = (nblk + CS_GROUPS - 1) / CS_GROUPS;
@@ -275,8 +309,10 @@ __global__ void __launch_bounds__(256) bin_colscan_kernel(int32_t* __restrict__ 
             for (int k = 0; k < CS_CHUNK; ++k) total += v[k];
         }
     }
+    GFL_PHASE(1, 1);
     gsum[rg][tl] = total;
     __syncthreads();
+    GFL_PHASE(1, 2);
     int run = 0, all = 0;
 #pragma unroll
     for (int g = 0; g < CS_GROUPS; ++g) {
@@ -297,6 +333,7 @@ __global__ void __launch_bounds__(256) bin_colscan_kernel(int32_t* __restrict__ 
             }
         }
     }
+    GFL_PHASE(1, 3);
 }
 
 static_assert(SCHED_BLOCK == BIN_BLOCK, "the tile scheduler runs as one extra block of the scatter launch");
@@ -329,15 +366,38 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* _
         return;
     }
     const int32_t* base_row = hist_g + (size_t)blockIdx.x * T;
+    GFL_PHASE(2, 0);
+    // The launch has about one wave per SIMD: a load that is issued where its value is needed costs a full round trip
+    // with nothing to hide it (tools/phase_trace.py: tile totals 0.9 us, then this block's bases 1.3 us, then the splat
+    // record 0.5 us, one after the other).  So everything a lane will need is requested here, together.
+    const int i = blockIdx.x * BIN_BLOCK + threadIdx.x;
+    float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p2 = p0;
+    if (i < N) {
+        const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)i * REC);
+        p0 = r4[0]; p2 = r4[2];
+    }
     {
         // every block scans the T tile totals itself (a few elements per thread); block 0
         // publishes the exclusive offsets for the tile sort / blend kernels
         const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
         const int per = (T + BIN_BLOCK - 1) / BIN_BLOCK;
         const int t0 = tid * per;
+        constexpr int PER_MAX = 8;                   // tiles per lane held in registers (T <= 4096)
+        int cnt[PER_MAX], bas[PER_MAX];
         int local = 0;
-        for (int k = 0; k < per; ++k)
-            if (t0 + k < T) local += tile_counts[t0 + k];
+        if (per <= PER_MAX) {
+#pragma unroll
+            for (int k = 0; k < PER_MAX; ++k) {
+                const bool ok = k < per && t0 + k < T;
+                cnt[k] = ok ? tile_counts[t0 + k] : 0;
+                bas[k] = ok ? base_row[t0 + k] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < PER_MAX; ++k) local += cnt[k];
+        } else {
+            for (int k = 0; k < per; ++k)
+                if (t0 + k < T) local += tile_counts[t0 + k];
+        }
         int sc = local;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -345,30 +405,46 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* _
             if (lane >= off) sc += n;
         }
         if (lane == 63) wsum[wid] = sc;
+        GFL_PHASE(2, 1);
         __syncthreads();
         int wprefix = 0;
         for (int w = 0; w < wid; ++w) wprefix += wsum[w];
         int run = wprefix + sc - local;
-        for (int k = 0; k < per; ++k) {
-            const int t = t0 + k;
-            if (t < T) {
-                cursor[t] = run + base_row[t];
-                if (blockIdx.x == 0) tile_offsets[t] = run;
-                run += tile_counts[t];
+        if (per <= PER_MAX) {
+#pragma unroll
+            for (int k = 0; k < PER_MAX; ++k) {
+                const int t = t0 + k;
+                if (k < per && t < T) {
+                    cursor[t] = run + bas[k];
+                    if (blockIdx.x == 0) tile_offsets[t] = run;
+                    run += cnt[k];
+                }
+            }
+        } else {
+            for (int k = 0; k < per; ++k) {
+                const int t = t0 + k;
+                if (t < T) {
+                    cursor[t] = run + base_row[t];
+                    if (blockIdx.x == 0) tile_offsets[t] = run;
+                    run += tile_counts[t];
+                }
             }
         }
         if (blockIdx.x == 0 && tid == BIN_BLOCK - 1) tile_offsets[T] = run;
     }
+    GFL_PHASE(2, 2);
     __syncthreads();
-    const int i = blockIdx.x * BIN_BLOCK + threadIdx.x;
+    GFL_PHASE(2, 3);
     float u = 0.f, v = 0.f, cutoff = 0.f, depth = 0.f;
     int rad = 0;
     if (i < N) {
-        const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)i * REC);
-        const float4 p0 = r4[0], p2 = r4[2];
         rad = __float_as_int(p2.w);
         u = p0.x; v = p0.y; cutoff = p2.z; depth = p2.y;
     }
+#ifdef GFL_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GFL_PHASE(2, 4);
+#endif
     int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
     if (rad > 0) tile_rect(u, v, rad, gx, gy, x0, x1, y0, y1);
     const int nx = x1 - x0, nt = nx * (y1 - y0);
@@ -386,6 +462,7 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* _
                 else *overflow = 1;
             }
     }
+    GFL_PHASE(2, 5);
     const int lane = threadIdx.x & 63;
     unsigned long long todo = __ballot(wide);
     while (todo) {
@@ -403,6 +480,7 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* _
             else *overflow = 1;
         }
     }
+    GFL_PHASE(2, 6);
 }
 
 // ------------------------------------------------------------------- blend (C = 4)
@@ -1206,6 +1284,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
         if (threadIdx.x == 0) *ns.valid = 1;
         return;
     }
+    GFL_PHASE(3, 0);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int e_step = OP ? 0 : *d_step;              // (the tail of the LAST workgroup advances it)
     float scale_w = 0.f;                              // lambda_scale / rows of the scale term
@@ -1233,6 +1312,10 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
     // the parameter row and both Adam moments are requested before the gather so that their
     // latency overlaps it (the launch has about one wave per SIMD: nothing else would hide it)
     float4 prow_v[4], mrow_v[4], vrow_v[4];
+    float rec_C = 0.f;
+    unsigned own_flags = 0;
+    float own_flow_w = 0.f, own_still_w = 0.f, own_still_t[3] = {0.f, 0.f, 0.f};    // (OP: own_flow_w = dL/d depth,
+    float2 own_flow_t = make_float2(0.f, 0.f);                                      //  own_flow_t = dL/d uv of the caller)
     if (i < N) {
         const float4* prow = reinterpret_cast<const float4*>(params + (size_t)i * ROW);
         const float4* mrow = reinterpret_cast<const float4*>(adam_m + (size_t)i * ROW);
@@ -1247,6 +1330,28 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
         }
         const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)i * REC);
         rp0 = r4[0]; rp2 = r4[2];
+        rec_C = rec[(size_t)i * REC + 4];
+        // the per-row side inputs of the regularisers too: read where they are used, deep inside the chain rule, each
+        // was a round trip of its own (joint stages: chain rule 3.5 us against 2.3 without them, tools/phase_trace.py)
+        if (!OP) {
+            if (row_flags) own_flags = row_flags[i];
+            if (flow_w) {
+                own_flow_w = flow_w[i];
+                own_flow_t = reinterpret_cast<const float2*>(flow_target)[i];
+            }
+            if (still_w) {
+                own_still_w = still_w[i];
+                own_still_t[0] = still_target[3 * i]; own_still_t[1] = still_target[3 * i + 1];
+                own_still_t[2] = still_target[3 * i + 2];
+            }
+        } else {
+            if (d_uv_in) own_flow_t = reinterpret_cast<const float2*>(d_uv_in)[i];
+            if (d_depth_in) own_flow_w = d_depth_in[i];
+        }
+#ifdef GFL_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GFL_PHASE(3, 1);
+#endif
         {
             const int rad = __float_as_int(rp2.w);
             if (rad > 0) {
@@ -1289,6 +1394,10 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
             }
         }
     }
+#ifdef GFL_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GFL_PHASE(3, 2);
+#endif
     // ---- wave-cooperative gather for the few splats with more than SLOT_MAX tiles: their list
     // positions sit in the slot pool (offset encoded in the first slot); rows are wave-summed
     {
@@ -1321,13 +1430,18 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
             }
         }
     }
+    GFL_PHASE(3, 3);
     if (i < N) {
         const Cam c = OP ? load_cam(intr, pose) : cam_from_pose(intr, pose);
+#ifdef GFL_TRACE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        GFL_PHASE(3, 4);
+#endif
         const Splat s = splat_from_row(prow_v[0], prow_v[1], prow_v[2], prow_v[3], OP);
         if (big) { d0 = d0g; d1 = d1g; d2 = d2g; }
         {
             // moments of the backward blend -> du dv dA dB dC (blend_bwd_terms)
-            const float A = rp0.z, B = rp0.w, C = rec[(size_t)i * REC + 4];
+            const float A = rp0.z, B = rp0.w, C = rec_C;
             const float s0 = d0.x, s1 = d0.y;
             d0.x = fmaf(A, s0, B * s1);
             d0.y = fmaf(C, s1, B * s0);
@@ -1346,21 +1460,20 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
         if (vis) {
             float du = d0.x, dv = d0.y, dd = d2.y;
             if (OP) {                                       // the caller's own use of uv / depth (flow, scale losses)
-                if (d_uv_in) { du += d_uv_in[2 * i]; dv += d_uv_in[2 * i + 1]; }
-                if (d_depth_in) dd += d_depth_in[i];
+                if (d_uv_in) { du += own_flow_t.x; dv += own_flow_t.y; }
+                if (d_depth_in) dd += own_flow_w;
             }
-            if (!OP && scale_w != 0.f &&
-                scale_row(rp0.x, rp0.y, W, H, row_flags ? row_flags[i] : 0, rc.freeze_all ? 2 : 1)) {
+            if (!OP && scale_w != 0.f && scale_row(rp0.x, rp0.y, W, H, own_flags, rc.freeze_all ? 2 : 1)) {
                 // mean over the rows of |scale| / depth (trainer.py:495-502): d/d depth here, d/d scale below
                 const float nrm = sqrtf(s.s[0] * s.s[0] + s.s[1] * s.s[1] + s.s[2] * s.s[2]);
                 dd -= scale_w * nrm / (rp2.y * rp2.y);
                 scale_g = nrm > 0.f ? scale_w / (nrm * rp2.y) : 0.f;
             }
             if (!OP && flow_w) {                            // flow term acts on uv (trainer.py:520-528)
-                const float w = rc.lambda_flow * flow_w[i];
+                const float w = rc.lambda_flow * own_flow_w;
                 if (w != 0.f) {
-                    du += 2.f * w * (rp0.x - flow_target[2 * i]);
-                    dv += 2.f * w * (rp0.y - flow_target[2 * i + 1]);
+                    du += 2.f * w * (rp0.x - own_flow_t.x);
+                    dv += 2.f * w * (rp0.y - own_flow_t.y);
                 }
             }
             const float px = c.r00 * s.x + c.r01 * s.y + c.r02 * s.z + c.t0;
@@ -1420,22 +1533,22 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
 #pragma unroll
         for (int k = 0; k < 3; ++k) g[3 + k] *= (s.raw_s[k] > 0.f) ? 1.f : ((s.raw_s[k] < 0.f) ? -1.f : 0.f);
         if (still_w) {                                      // trainer.py:505-509
-            const float w = rc.lambda_still * still_w[i];
+            const float w = rc.lambda_still * own_still_w;
             if (w != 0.f) {
-                const float ax = s.x - still_target[3 * i], ay = s.y - still_target[3 * i + 1],
-                            az = s.z - still_target[3 * i + 2];
+                const float ax = s.x - own_still_t[0], ay = s.y - own_still_t[1], az = s.z - own_still_t[2];
                 const float n = sqrtf(ax * ax + ay * ay + az * az);
                 if (n != 0.f) { g[0] += w * ax / n; g[1] += w * ay / n; g[2] += w * az / n; }
             }
         }
         // gradient control (trainer.py:535-551)
         if (rc.freeze_rgb) { g[11] = 0.f; g[12] = 0.f; g[13] = 0.f; }
-        if (row_flags && (row_flags[i] & 1)) { g[0] = 0.f; g[1] = 0.f; g[2] = 0.f; }
+        if (own_flags & 1u) { g[0] = 0.f; g[1] = 0.f; g[2] = 0.f; }
         if (rc.freeze_all) {
 #pragma unroll
             for (int k = 0; k < 14; ++k) g[k] = 0.f;
         }
         // Adam over the 64-byte row
+        GFL_PHASE(3, 5);
         if (!rc.freeze_all) {
         float step_size, isb2;
         adam_scalars(ac, e_step, ac.lr, step_size, isb2);
@@ -1461,12 +1574,14 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
         }
         }
     }
+    GFL_PHASE(3, 6);
     if (!OP && tail.ticket) {
         block_reduce_store<12, REDUCE_BLOCK, true>(e, partial);
         camera_tail(tail, partial, ns.rows, e_step);
     } else {
         block_reduce_store<12, REDUCE_BLOCK>(e, partial);
     }
+    GFL_PHASE(3, 7);
 }
 
 // camera + depth affine: fold the extr partials, chain to the pose, Adam, step += 1
@@ -2076,6 +2191,9 @@ int gfl_fit_iteration(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stre
 #ifdef GFL_TRACE
 int gfl_debug_read_fwd_trace(long long* out, int n_tiles) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gfl::g_fwd_trace), (size_t)n_tiles * 8 * sizeof(long long));
+}
+int gfl_debug_read_phase_trace(long long* out, int n_values) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gfl::g_phase_trace), (size_t)n_values * sizeof(long long));
 }
 int gfl_debug_read_bwd_trace(long long* out, int n_tiles) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gfl::g_bwd_trace), (size_t)n_tiles * 8 * sizeof(long long));

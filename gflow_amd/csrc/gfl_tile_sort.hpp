@@ -9,7 +9,7 @@
 // Bitonic network; a compare-exchange partner is
 //   - in the same lane            when the stride is below E        (register swap),
 //   - in the same wave            when it is below 64 E             (DPP / permlane swap, no LDS),
-//   - in another wave otherwise   (a few steps per sort)            (4 KB LDS exchange buffer).
+//   - in another wave otherwise   (a few steps per sort)            (16 KB LDS exchange buffer, four keys per barrier pair).
 // A first version sorted in LDS with a barrier per pass: a single 300-key tile then cost ~25 us
 // of barrier latency and set the duration of the whole launch.
 #pragma once
@@ -63,6 +63,9 @@ __device__ __forceinline__ void exchange_in_wave(unsigned long long (&key)[E], i
     }
 }
 
+constexpr int SORT_THREADS = 512;
+constexpr int SORT_XB = 4;         // keys of a lane exchanged through LDS per pair of barriers (16 KB of LDS)
+
 template <int E>
 __device__ __forceinline__ void sort_tile_regs(unsigned long long* __restrict__ seg, int n, int npow,
                                                unsigned long long* __restrict__ sk, unsigned long long (&key)[E]) {
@@ -83,17 +86,24 @@ __device__ __forceinline__ void sort_tile_regs(unsigned long long* __restrict__ 
     for (int k = 2; k <= npow; k <<= 1) {
         const int j0 = k >> 1;
         for (int j = j0; j >= 64 * E; j >>= 1) {
+            // partner in another wave: through LDS, up to SORT_XB of the lane's keys per pair of barriers (one key per
+            // pair made the 2 048-key tiles -- six such steps of 4 keys each, 48 barriers -- the tail of the launch)
             const int tj = j / E;
             const bool lower = (tid & tj) == 0;
+            constexpr int XB = E < SORT_XB ? E : SORT_XB;
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
+            for (int e0 = 0; e0 < E; e0 += XB) {
                 __syncthreads();
-                sk[tid] = key[e];
+#pragma unroll
+                for (int e = 0; e < XB; ++e) sk[e * SORT_THREADS + tid] = key[e0 + e];
                 __syncthreads();
-                const unsigned long long other = sk[tid ^ tj];
-                const bool up = ((tid * E + e) & k) == 0;
-                const bool take_min = lower == up;
-                key[e] = ((key[e] < other) == take_min) ? key[e] : other;
+#pragma unroll
+                for (int e = 0; e < XB; ++e) {
+                    const unsigned long long other = sk[e * SORT_THREADS + (tid ^ tj)];
+                    const bool up = ((tid * E + e0 + e) & k) == 0;
+                    const bool take_min = lower == up;
+                    key[e0 + e] = ((key[e0 + e] < other) == take_min) ? key[e0 + e] : other;
+                }
             }
         }
         if (j0 >= 32 * E) exchange_in_wave<E, 32>(key, k, tid);
@@ -143,7 +153,6 @@ __device__ __forceinline__ void sort_tile_and_emit(unsigned long long* __restric
 
 // Register budget: 64 VGPRs (eight waves per SIMD).  With a 16-keys-per-lane variant in the same kernel the compiler
 // needed 95 VGPRs; up to 8 keys per lane it needs 50.  Lists beyond 4096 keys are sorted in global memory.
-constexpr int SORT_THREADS = 512;
 __global__ void __launch_bounds__(SORT_THREADS, 8) bin_tile_sort_kernel(const int32_t* __restrict__ offsets, int K_cap,
                                                                         unsigned long long* __restrict__ keys,
                                                                         int32_t* __restrict__ ids,
@@ -151,7 +160,7 @@ __global__ void __launch_bounds__(SORT_THREADS, 8) bin_tile_sort_kernel(const in
                                                                         const float* __restrict__ slot_rec,
                                                                         int32_t* __restrict__ slot_inv,
                                                                         int32_t* __restrict__ slot_pool, int gx, int gy) {
-    __shared__ unsigned long long sk[SORT_THREADS];      // cross-wave exchange buffer
+    __shared__ unsigned long long sk[SORT_XB * SORT_THREADS];      // cross-wave exchange buffer
     // XCD x sorts one contiguous range of tiles (the dispatcher places workgroup b on XCD b % 8): the records the slot
     // table needs (uv, radius of every key's splat) are those of neighbouring tiles; with block = tile every XCD pulled
     // all of them through its own L2 (22 MB read for 3.9 MB of keys, rocprofv3 FETCH_SIZE)
