@@ -53,6 +53,7 @@ SIGNATURES = {
     "gfl_step_increment": (c_int, [_P, _P]),
     "gfl_tile_sort_only": (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),
     "gfl_tile_sort_with_slots": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "gfl_tile_sort_ordered": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "gfl_fit_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "gfl_fit_forward": (c_int, [_P, _P, _P]),          # struct pointers; typed in gflow_amd/fused.py
     "gfl_fit_backward_step": (c_int, [_P, _P, _P]),

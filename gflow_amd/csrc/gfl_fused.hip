@@ -342,6 +342,104 @@ __device__ __forceinline__ bool sched_xcd_usable(const Sched& sc, int T, int blo
     return sc.xcd && T <= SCHED_PLAN_TILES && sc.nq % 8 == 0 && sc.nq / 8 <= 64 && sc.nq <= block;
 }
 
+// The order the tile sort's workgroups take the tiles in (one workgroup of the scatter launch, beside the scatter's own):
+// inside every XCD's run of tiles (the sort keeps workgroup b's tile on XCD b % 8, gfl_tile_sort.hpp) the tiles with
+// more than twice the mean list length first, both classes in their old order -- a stable partition from two scans
+// (list lengths -> offsets, heavy flags -> ranks).  {tile, start, end} per position: the sort reads ONE 16-byte item.
+__device__ void build_sort_order(const int32_t* __restrict__ tile_counts, int T, int4* __restrict__ sort_order,
+                                 int32_t* __restrict__ wsum /* [BIN_BLOCK / 64] */) {
+    __shared__ int32_t hsum[BIN_BLOCK / 64], hstart[9];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int per = (T + BIN_BLOCK - 1) / BIN_BLOCK;
+    const int t0 = tid * per;
+    constexpr int PER_MAX = 8;
+    if (per > PER_MAX) {                                 // more than 4096 tiles: the plain order (one lane; never hot)
+        if (tid == 0) {
+            int run = 0;
+            for (int t = 0; t < T; ++t) {
+                const int c = tile_counts[t];
+                sort_order[t] = make_int4(t, run, run + c, 0);
+                run += c;
+            }
+        }
+        return;
+    }
+    int cnt[PER_MAX];
+    int local = 0;
+#pragma unroll
+    for (int k = 0; k < PER_MAX; ++k) {
+        cnt[k] = (k < per && t0 + k < T) ? tile_counts[t0 + k] : 0;
+        local += cnt[k];
+    }
+    int sc = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int n = __shfl_up(sc, off);
+        if (lane >= off) sc += n;
+    }
+    if (lane == 63) wsum[wid] = sc;
+    __syncthreads();
+    int run = sc - local, total = 0;
+    for (int w = 0; w < BIN_BLOCK / 64; ++w) {
+        run += w < wid ? wsum[w] : 0;
+        total += wsum[w];
+    }
+    const int thr = max(2 * (total / max(T, 1)), 64);
+    int lh = 0;
+#pragma unroll
+    for (int k = 0; k < PER_MAX; ++k) lh += cnt[k] > thr ? 1 : 0;
+    int hs = lh;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int n = __shfl_up(hs, off);
+        if (lane >= off) hs += n;
+    }
+    if (lane == 63) hsum[wid] = hs;
+    __syncthreads();
+    int H = hs - lh;                                     // heavy tiles before this lane's first tile
+    for (int w = 0; w < wid; ++w) H += hsum[w];
+    // XCD x owns the tiles [start(x), start(x + 1)): start(x) = x q + min(x, r) (xcd_logical_block)
+    const int q = T >> 3, r = T & 7, big = r * (q + 1);
+    auto start_of = [&](int x) { return x < r ? x * (q + 1) : big + (x - r) * q; };
+    if (tid < 9) {
+        // heavy tiles before each XCD's run: found by the lane that owns the run's first tile, below; runs that are empty
+        // (fewer than eight tiles) keep the total
+        int all = 0;
+        for (int w = 0; w < BIN_BLOCK / 64; ++w) all += hsum[w];
+        hstart[tid] = all;
+    }
+    __syncthreads();
+    int x = t0 < big ? t0 / (q + 1) : r + (q ? (t0 - big) / q : 0);       // (one division per lane; a lane's tiles cross
+    int next = x < 7 ? start_of(x + 1) : T;                                //  at most one boundary)
+    {
+        int Hk = H, xk = x, nk = next;
+#pragma unroll
+        for (int k = 0; k < PER_MAX; ++k) {
+            const int t = t0 + k;
+            if (k < per && t < T) {
+                if (t == nk) { ++xk; nk = xk < 7 ? start_of(xk + 1) : T; }
+                if (t == start_of(xk)) hstart[xk] = Hk;
+                Hk += cnt[k] > thr ? 1 : 0;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER_MAX; ++k) {
+        const int t = t0 + k;
+        if (k < per && t < T) {
+            if (t == next) { ++x; next = x < 7 ? start_of(x + 1) : T; }
+            const int sx = start_of(x);
+            const int hx = hstart[x], nh = (x < 7 ? hstart[x + 1] : hstart[8]) - hx;      // heavy tiles of this run
+            const bool heavy = cnt[k] > thr;
+            const int hr = H - hx;
+            sort_order[sx + (heavy ? hr : nh + (t - sx) - hr)] = make_int4(t, run, run + cnt[k], 0);
+            H += heavy ? 1 : 0;
+            run += cnt[k];
+        }
+    }
+}
+
 __global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* __restrict__ rec, int N, int gx, int gy,
                                                                   const int32_t* __restrict__ hist_g,
                                                                   const int32_t* __restrict__ tile_counts,
@@ -349,10 +447,15 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* _
                                                                   unsigned long long* __restrict__ keys,
                                                                   int32_t* __restrict__ overflow,
                                                                   Sched sched_bwd, Sched sched_fwd,
-                                                                  const int32_t* __restrict__ sched_valid) {
+                                                                  const int32_t* __restrict__ sched_valid,
+                                                                  int4* __restrict__ sort_order) {
     extern __shared__ int32_t cursor[];
     __shared__ int32_t wsum[BIN_BLOCK / 64];
     const int T = gx * gy;
+    if (sort_order && blockIdx.x == gridDim.x - 3) {     // (a workgroup of its own: in workgroup 0 it lengthened the launch)
+        build_sort_order(tile_counts, T, sort_order, wsum);
+        return;
+    }
     if (blockIdx.x >= gridDim.x - 2) {
         // Two extra workgroups build the blend kernels' tile queues -- but only while there is no schedule yet: from
         // the first backward on, the queues of iteration i + 1 are built at the END of iteration i, by two extra
@@ -1747,6 +1850,16 @@ static bool next_sched_enabled() {
     return v == 1;
 }
 
+// GFL_SORT_ORDER=0: the tile sort takes the tiles in their own order (rounds 1-3), not every XCD's longest lists first
+static bool sort_heavy_first() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GFL_SORT_ORDER");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 // list length from which the forward blend walks a queue's first tile as four blocks (GFL_FWD_SPLIT_MIN overrides)
 static int fwd_split_min() {
     static int v = -1;
@@ -1797,7 +1910,8 @@ size_t gfl_fit_workspace_bytes(int cap, int K_cap, int W, int H) {
            + up256(2 * SCHED_MAX_QUEUES * sizeof(int32_t))                          // ... queue lengths
            + up256(gfl_loss_workspace_bytes(W, H)) + 256
            + up256((size_t)6 * W * H * sizeof(float))                                  // SSIM statistics of the target
-           + up256((size_t)fit_nblk(cap > 0 ? cap : 1) * sizeof(int32_t));             // rows of the scale term per block
+           + up256((size_t)fit_nblk(cap > 0 ? cap : 1) * sizeof(int32_t))              // rows of the scale term per block
+           + up256(T * 4 * sizeof(int32_t));                                           // the tile sort's order
 }
 
 struct FitWs {
@@ -1817,6 +1931,7 @@ struct FitWs {
     size_t loss_ws_bytes;
     float* gt_stats;         // [3][2][H][W] conv(y), conv(y^2) of the current target (gfl_fit_prepare_targets)
     int32_t* scale_cnt;      // [blocks of the preprocess launch] rows of the scale term (lambda_scale)
+    int4* sort_order;        // [T] {tile, start, end, 0}: the order the tile sort takes the tiles in (fused_scatter_kernel)
 };
 
 static FitWs carve(const gfl_fit_state* st) {
@@ -1871,6 +1986,7 @@ static FitWs carve(const gfl_fit_state* st) {
     w.loss_ws_bytes = up256(gfl_loss_workspace_bytes(st->W, st->H));
     w.gt_stats = (float*)((char*)p + w.loss_ws_bytes + 256);
     w.scale_cnt = (int32_t*)((char*)w.gt_stats + up256((size_t)6 * st->W * st->H * sizeof(float)));
+    w.sort_order = (int4*)((char*)w.scale_cnt + up256((size_t)fit_nblk(st->cap > 0 ? st->cap : 1) * sizeof(int32_t)));
     return w;
 }
 
@@ -1933,14 +2049,18 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
     }
     {
         StageScope p(ST_SCATTER, s);
-        fused_scatter_kernel<<<nblk + 2, BIN_BLOCK, lds, s>>>(st->rec, st->N, gx, gy, w.hist, w.tile_counts,
+        fused_scatter_kernel<<<nblk + 2 + (sort_heavy_first() ? 1 : 0), BIN_BLOCK, lds, s>>>(st->rec, st->N, gx, gy, w.hist, w.tile_counts,
                                                               st->tile_offsets, st->K_cap, w.keys, st->overflow, w.sched, w.sched_fwd,
-                                                              w.sched_valid);
+                                                              w.sched_valid, sort_heavy_first() ? w.sort_order : nullptr);
     }
     {
         StageScope p(ST_TILE_SORT, s);
-        rc = gfl_tile_sort_with_slots(st->tile_offsets, st->W, st->H, st->K_cap, w.keys, st->ids, st->tile_range, st->rec,
-                                      w.slot_inv, w.slot_pool, stream);
+        if (sort_heavy_first())
+            rc = gfl_tile_sort_ordered((const int32_t*)w.sort_order, st->W, st->H, st->K_cap, w.keys, st->ids, st->tile_range,
+                                       st->rec, w.slot_inv, w.slot_pool, stream);
+        else
+            rc = gfl_tile_sort_with_slots(st->tile_offsets, st->W, st->H, st->K_cap, w.keys, st->ids, st->tile_range, st->rec,
+                                          w.slot_inv, w.slot_pool, stream);
     }
     if (rc) return rc;
     {

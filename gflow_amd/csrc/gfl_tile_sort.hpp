@@ -17,8 +17,8 @@
 namespace gfl {
 
 #ifdef GFL_TRACE
-__device__ long long g_sort_trace[16384 * 4];   // analysis build: start / keys loaded / sorted / done
-#define SORT_TRACE(slot) if (threadIdx.x == 0 && blockIdx.x < 16384) g_sort_trace[blockIdx.x * 4 + (slot)] = wall_clock64()
+__device__ long long g_sort_trace[16384 * 4];   // analysis build: start / keys loaded / sorted / done, one row per tile
+#define SORT_TRACE(slot) if (threadIdx.x == 0 && blockIdx.x < 16384) g_sort_trace[sort_trace_row * 4 + (slot)] = wall_clock64()
 #else
 #define SORT_TRACE(slot)
 #endif
@@ -68,7 +68,8 @@ constexpr int SORT_XB = 4;         // keys of a lane exchanged through LDS per p
 
 template <int E>
 __device__ __forceinline__ void sort_tile_regs(unsigned long long* __restrict__ seg, int n, int npow,
-                                               unsigned long long* __restrict__ sk, unsigned long long (&key)[E]) {
+                                               unsigned long long* __restrict__ sk, unsigned long long (&key)[E],
+                                               int sort_trace_row) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -90,7 +91,7 @@ __device__ __forceinline__ void sort_tile_regs(unsigned long long* __restrict__ 
             // pair made the 2 048-key tiles -- six such steps of 4 keys each, 48 barriers -- the tail of the launch)
             const int tj = j / E;
             const bool lower = (tid & tj) == 0;
-            constexpr int XB = E < SORT_XB ? E : SORT_XB;
+            constexpr int XB = E < SORT_XB ? E : (E > 4 ? 2 : SORT_XB);     // (E = 8 with four in flight spills registers)
 #pragma unroll
             for (int e0 = 0; e0 < E; e0 += XB) {
                 __syncthreads();
@@ -137,16 +138,41 @@ __device__ __forceinline__ void sort_tile_and_emit(unsigned long long* __restric
                                                    int32_t* __restrict__ slot_inv, int32_t* __restrict__ slot_pool,
                                                    int gx, int gy) {
     unsigned long long key[E];
-    sort_tile_regs<E>(seg, n, npow, sk, key);
+    const int sort_trace_row = tile;
+    (void)sort_trace_row;
+    sort_tile_regs<E>(seg, n, npow, sk, key, tile);
     SORT_TRACE(2);
     const int tid = threadIdx.x;
+    // from here on only the splat ids are live (the depth halves of the keys would keep E more registers busy: at the
+    // 64-register budget the compiler then re-used the address registers of one record load for the next -- a wait for
+    // memory between every two loads of the loop below)
+    int gid[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int idx = tid * E + e;
-        if (idx < n) {
-            const int g = (int32_t)(unsigned)(key[e] & 0xffffffffull);
-            ids[start + idx] = g;
-            if (slot_inv) write_slot(slot_rec, slot_inv, slot_pool, g, tile, gx, gy, start + idx);
+    for (int e = 0; e < E; ++e) gid[e] = tid * E + e < n ? (int32_t)(unsigned)(key[e] & 0xffffffffull) : -1;
+    const int tx = tile % gx, ty = tile / gx;
+    // the slot table needs (u, v, radius) of every key's splat: the records of up to four keys are requested before the
+    // first is used (one record, one store per trip was E dependent round trips: 5.6 us at the end of the longest tile's
+    // workgroup, tools/sort_trace.py --fit)
+    constexpr int EB = E < 4 ? E : 4;
+#pragma unroll
+    for (int e0 = 0; e0 < E; e0 += EB) {
+        float2 uv[EB];
+        int rr[EB];
+        if (slot_inv) {
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                const float* r = slot_rec + (size_t)max(gid[e0 + e], 0) * 12;
+                uv[e] = *reinterpret_cast<const float2*>(r);
+                rr[e] = __float_as_int(r[11]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const int g = gid[e0 + e], pos = start + tid * E + e0 + e;
+            if (g >= 0) {
+                ids[pos] = g;
+                if (slot_inv) write_slot(uv[e].x, uv[e].y, rr[e], slot_inv, slot_pool, g, tx, ty, gx, gy, pos);
+            }
         }
     }
 }
@@ -159,15 +185,29 @@ __global__ void __launch_bounds__(SORT_THREADS, 8) bin_tile_sort_kernel(const in
                                                                         int32_t* __restrict__ tile_range,
                                                                         const float* __restrict__ slot_rec,
                                                                         int32_t* __restrict__ slot_inv,
-                                                                        int32_t* __restrict__ slot_pool, int gx, int gy) {
+                                                                        int32_t* __restrict__ slot_pool, int gx, int gy,
+                                                                        const int4* __restrict__ order) {
     __shared__ unsigned long long sk[SORT_XB * SORT_THREADS];      // cross-wave exchange buffer
     // XCD x sorts one contiguous range of tiles (the dispatcher places workgroup b on XCD b % 8): the records the slot
     // table needs (uv, radius of every key's splat) are those of neighbouring tiles; with block = tile every XCD pulled
     // all of them through its own L2 (22 MB read for 3.9 MB of keys, rocprofv3 FETCH_SIZE)
-    const int tile = xcd_logical_block((int)blockIdx.x, (int)gridDim.x);
+    // `order` (fused iteration): the XCD's tiles with the longest lists first -- {tile, start, end} per position, written
+    // by the scatter launch.  Four 512-lane workgroups fit a CU at a time and a launch has six per CU: a 600-key tile
+    // that started in the second round (4-6 us in) was the end of the launch (tools/sort_trace.py).
+    const int lb = xcd_logical_block((int)blockIdx.x, (int)gridDim.x);
+    int tile = lb, start, end;
+    if (order) {
+        const int4 it = order[lb];
+        tile = it.x;
+        start = min(it.y, K_cap);
+        end = min(it.z, K_cap);
+    } else {
+        start = min(offsets[tile], K_cap);
+        end = min(offsets[tile + 1], K_cap);
+    }
+    const int sort_trace_row = tile;
+    (void)sort_trace_row;
     SORT_TRACE(0);
-    const int start = min(offsets[tile], K_cap);
-    const int end = min(offsets[tile + 1], K_cap);
     const int n = end - start;
     if (threadIdx.x == 0) {
         tile_range[2 * tile] = n > 0 ? start : 0;
@@ -201,7 +241,10 @@ __global__ void __launch_bounds__(SORT_THREADS, 8) bin_tile_sort_kernel(const in
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const int g = (int32_t)(unsigned)(seg[i] & 0xffffffffull);
             ids[start + i] = g;
-            if (slot_inv) write_slot(slot_rec, slot_inv, slot_pool, g, tile, gx, gy, start + i);
+            if (slot_inv) {
+                const float* r = slot_rec + (size_t)g * 12;
+                write_slot(r[0], r[1], __float_as_int(r[11]), slot_inv, slot_pool, g, tile % gx, tile / gx, gx, gy, start + i);
+            }
         }
     }
 }

@@ -331,6 +331,12 @@ int gfl_tile_sort_only(const int32_t* tile_offsets, int T, int K_cap, void* keys
 int gfl_tile_sort_with_slots(const int32_t* tile_offsets, int W, int H, int K_cap, void* keys, int32_t* ids,
                              int32_t* tile_range, const float* rec, int32_t* slot_inv, int32_t* slot_pool,
                              gfl_stream_t stream);
+/* same, with the order the workgroups take the tiles in given by the caller: order[T][4] = {tile, start, end, 0} per
+ * position (16-byte aligned; positions are assigned to the XCDs in contiguous runs, T / 8 each, like the tiles without it).
+ * gfl_fit_iteration's scatter launch writes it with every XCD's longest lists first: their workgroups then start with the
+ * launch instead of in its second round.  Any permutation that keeps a tile inside its XCD's run is as good for the result. */
+int gfl_tile_sort_ordered(const int32_t* order, int W, int H, int K_cap, void* keys, int32_t* ids, int32_t* tile_range,
+                          const float* rec, int32_t* slot_inv, int32_t* slot_pool, gfl_stream_t stream);
 
 /* ---- optional per-stage timing of the fused iteration ---------------------------
  * HIP events are recorded on the launch stream around the stages whose bit is set in
