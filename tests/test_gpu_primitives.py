@@ -118,3 +118,89 @@ def test_block_culling_never_drops_a_visible_pixel(box):
     print(f"box {box}: {let_through} boxes let through for {needed} with a visible pixel ({let_through / needed:.3f}x)")
     assert let_through <= 1.06 * needed, (let_through, needed)               # measured 1.02x (continuous box, margins)
 
+
+
+def test_tile_sort_in_any_order_of_the_tiles():
+    """gfl_tile_sort_ordered (the fused iteration's sort: every XCD's longest lists first) against
+    gfl_tile_sort_with_slots on the same keys: ids, tile ranges and the slot table bit-identical, for a random
+    permutation of the tiles inside every XCD's run and with lists of every register tier (1 ... 2 500 keys)."""
+    import numpy as np
+    from gflow_amd import _lib as L
+    lib = L.load()
+    dev = torch.device("cuda", 0)
+    W, H, SLOT_MAX = 160, 96, 32
+    gx, gy = 10, 6
+    T = gx * gy
+    g = torch.Generator().manual_seed(11)
+    n = 4000
+    # every splat covers a 3 x 3 block of tiles around its own (radius 16: [u - 16, u + 16 + 15] / 16)
+    cx = torch.randint(1, gx - 1, (n,), generator=g)
+    cy = torch.randint(1, gy - 1, (n,), generator=g)
+    rec = torch.zeros(n, 12)
+    rec[:, 0] = cx * 16 + 8.0
+    rec[:, 1] = cy * 16 + 8.0
+    rec[:, 11] = torch.full((n,), 16, dtype=torch.int32).view(torch.float32)
+    depth = (1 + torch.rand(n, generator=g)).float()
+    depth[::9] = depth[0]                                   # ties: the id decides
+    lists = [[] for _ in range(T)]
+    for i in range(n):
+        for ty in range(int(cy[i]) - 1, int(cy[i]) + 2):
+            for tx in range(int(cx[i]) - 1, int(cx[i]) + 2):
+                lists[ty * gx + tx].append(i)
+    # ... and one tile far longer than the rest (the splats of its whole neighbourhood a second time would break the
+    # uniqueness of (splat, tile): thin the others out instead)
+    for t in range(T):
+        if t != 3 * gx + 4:
+            lists[t] = lists[t][: max(1, len(lists[t]) // (1 + t % 5))]
+    lens = np.array([len(l) for l in lists])
+    assert lens.max() > 1024 and lens.min() >= 1
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    K = int(offsets[-1])
+    dbits = depth.view(torch.int32).numpy().astype(np.uint64)
+    keys = np.zeros(K, dtype=np.uint64)
+    rng = np.random.default_rng(3)
+    for t in range(T):
+        idx = np.array(lists[t], dtype=np.uint64)
+        rng.shuffle(idx)
+        keys[offsets[t]:offsets[t + 1]] = (dbits[idx.astype(np.int64)] << np.uint64(32)) | idx
+    # order: a random permutation of the tiles inside every XCD's run (the runs of xcd_logical_block)
+    q, r = T >> 3, T & 7
+    order = np.zeros((T, 4), dtype=np.int32)
+    for x in range(8):
+        s0 = x * q + min(x, r)
+        ln = q + (1 if x < r else 0)
+        perm = s0 + rng.permutation(ln)
+        for j, t in enumerate(perm):
+            order[s0 + j] = (t, offsets[t], offsets[t + 1], 0)
+
+    def run(ordered):
+        k = torch.from_numpy(keys.view(np.int64).copy()).to(dev)
+        ids = torch.full((K,), -7, dtype=torch.int32, device=dev)
+        tr = torch.full((T, 2), -7, dtype=torch.int32, device=dev)
+        slot = torch.full((n, SLOT_MAX), -1, dtype=torch.int32, device=dev)
+        rec_d = rec.to(dev)
+        if ordered:
+            o = torch.from_numpy(order).to(dev)
+            L.check(lib.gfl_tile_sort_ordered(L.ptr(o), W, H, K, L.ptr(k), L.ptr(ids), L.ptr(tr), L.ptr(rec_d), L.ptr(slot),
+                                              None, L.stream()), "sort ordered")
+        else:
+            off = torch.from_numpy(offsets).to(dev)
+            L.check(lib.gfl_tile_sort_with_slots(L.ptr(off), W, H, K, L.ptr(k), L.ptr(ids), L.ptr(tr), L.ptr(rec_d),
+                                                 L.ptr(slot), None, L.stream()), "sort")
+        torch.cuda.synchronize()
+        return ids.cpu(), tr.cpu(), slot.cpu()
+
+    ids0, tr0, slot0 = run(False)
+    ids1, tr1, slot1 = run(True)
+    assert torch.equal(tr0, tr1) and torch.equal(ids0, ids1) and torch.equal(slot0, slot1)
+    # and the plain one is right: every list ascending in (depth, id), every pair's position in its splat's slot row
+    for t in (0, 3 * gx + 4, T - 1):
+        seg = ids0[offsets[t]:offsets[t + 1]].long()
+        d = depth[seg]
+        assert bool(((d[1:] > d[:-1]) | ((d[1:] == d[:-1]) & (seg[1:] > seg[:-1]))).all())
+        assert sorted(seg.tolist()) == sorted(lists[t])
+    t = 3 * gx + 4
+    pos = int(offsets[t]) + 5
+    gidx = int(ids0[pos])
+    local = (t // gx - (int(cy[gidx]) - 1)) * 3 + (t % gx - (int(cx[gidx]) - 1))
+    assert int(slot0[gidx, local]) == pos
