@@ -262,6 +262,24 @@ class FitEngine:
         return self._state
 
     # -------------------------------------------------------------------- calls
+    def snapshot_ring(self, rows):
+        """(rows, 3, H, W, 3) uint8 on the device: where a train() call keeps its snapshots until its end
+        (trainer.make_stepper).  One ring per engine, grown on demand; the current stream waits for the copy that emptied
+        it last (``snapshot_ring_copied``)."""
+        ring = getattr(self, "_snap_ring", None)
+        if ring is None or ring.shape[0] < rows:
+            ring = torch.empty(int(rows), 3, self.H, self.W, 3, dtype=torch.uint8, device=self.dev)
+            self._snap_ring = ring
+        done = getattr(self, "_snap_ring_done", None)
+        if done is not None:
+            torch.cuda.current_stream().wait_event(done)
+        return ring[:rows]
+
+    def snapshot_ring_copied(self):
+        """call on the stream that has just been given the ring's device-to-host copy"""
+        self._snap_ring_done = torch.cuda.Event()
+        self._snap_ring_done.record()
+
     def forward(self):
         L.check(self.lib.gfl_fit_forward(ctypes.byref(self.state()), ctypes.byref(self.hp), L.stream()), "fit forward")
 

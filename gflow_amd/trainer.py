@@ -578,7 +578,7 @@ class SimpleGaussian:
 
         st = _Stepper()
         st.frames, st.frames_depth, st.frames_center, st.log = [], [], [], []
-        st.pin = st.copy_stream = st.pin_hold = None
+        st.pin = st.copy_stream = st.pin_hold = st.ring = None
         st.iteration = 0
         st.move_mask, st.camera_only = move_mask, camera_only
         tentative = hasattr(self, "still_mask_tentative") and camera_only
@@ -596,34 +596,30 @@ class SimpleGaussian:
                 self.rasterisations_done += 1                # the reference's extra render of the moving set
             if snap:
                 # the three images of THIS iteration's forward (render, records and lists are untouched by the
-                # backward) behind the iteration, in the same graph launch; the engine's image buffer is free again
-                # once the previous snapshot's copy has left it
-                if getattr(eng, "snap_copy_done", None) is not None:
-                    torch.cuda.current_stream().wait_event(eng.snap_copy_done)
+                # backward) behind the iteration, in the same graph launch
                 imgs = eng.iteration(use_graph=self.use_graph, snapshot=True)
-                # ... and on their way to the host at once, on a copy stream into pinned memory: the reference blocks
-                # on three device-to-host copies here; 150 images per first-frame fit cost ~40 ms as one pageable copy
+                # They stay on the DEVICE until the end of this train() call (a ring of uint8 images in HBM: 3.7 MB each at
+                # 480p, 50 per call) and leave for page-locked memory in ONE copy then.  A copy to the host while the
+                # iterations run holds up whatever kernel is running beside it for as long as it lasts -- 65 us, every
+                # tenth iteration (tools/snapshot_timeline.sh, tools/d2h_probe.py: a chain of short kernels gets +57 us
+                # per 74 us copy); at the end of the call it runs beside the host's set-up of the next stage, when the
+                # device has little else to do.  (The reference blocks on three device-to-host copies right here.)
                 k = len(st.frames)
                 if st.pin is None or k >= st.pin.shape[0]:
-                    # (k >= rows: a stepper that is run for more than ``iterations`` steps gets a larger block)
+                    # (k >= rows: a stepper that is run for more than ``iterations`` steps gets larger blocks)
                     n_snaps = max((iterations + snapshot_interval - 1) // snapshot_interval, 2 * k, 1)
                     block = _PINNED.take(n_snaps * 3 * H * W * 3)
                     pin = block[0][:n_snaps * 3 * H * W * 3].view(n_snaps, 3, H, W, 3)
                     hold = _PINNED.hold(block, st)                   # ... while this stepper lives
                     _PINNED.release(block)
+                    ring = eng.snapshot_ring(n_snaps)                # (waits, on the stream, for the last call's copy)
                     if st.pin is not None:
-                        st.copy_stream.synchronize()
-                        pin[:k].copy_(st.pin[:k])
+                        ring[:k].copy_(st.ring[:k])
                         st.frames, st.frames_depth, st.frames_center = ([pin[j, c] for j in range(k)] for c in range(3))
                         st.pin_hold()
-                    st.pin_block, st.pin, st.pin_hold = block, pin, hold
+                    st.pin_block, st.pin, st.pin_hold, st.ring = block, pin, hold, ring
                     st.copy_stream = _copy_stream(dev)
-                st.copy_stream.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(st.copy_stream):
-                    # (a 32-workgroup copy kernel of our own instead of the runtime's blit was measured: no faster, round 3)
-                    st.pin[k].copy_(imgs, non_blocking=True)
-                    eng.snap_copy_done = torch.cuda.Event()
-                    eng.snap_copy_done.record()
+                st.ring[k].copy_(imgs)
                 st.frames.append(st.pin[k, 0])
                 st.frames_depth.append(st.pin[k, 1])
                 st.frames_center.append(st.pin[k, 2])
@@ -812,8 +808,15 @@ class SimpleGaussian:
         self.last_render = st.last_render.clone()
         if save_ckpt:
             self.save_checkpoint(ckpt_name=ckpt_name)
-        # the snapshots stayed on the device as uint8 images: ONE copy to the host per list here, not three
+        # the snapshots stayed on the device as uint8 images: ONE copy to the host here, not three
         # blocking copies every 10th iteration (trainer.py:573-582)
+        if getattr(st, "pin", None) is not None and st.frames:
+            k = len(st.frames)
+            st.copy_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st.copy_stream):
+                st.pin[:k].copy_(st.ring[:k], non_blocking=True)
+                self.engine.snapshot_ring_copied()                   # (an event: the ring is free again after it)
+            st.ring.record_stream(st.copy_stream)                    # (should the engine replace it by a larger one)
         if getattr(st, "copy_stream", None) is not None:
             if not lazy_images:
                 st.copy_stream.synchronize()         # fused path: the images are already in pinned host memory

@@ -44,17 +44,18 @@ FU.FitEngine.snapshot = timed("    snapshot (3 images, device)", FU.FitEngine.sn
 orig_it = FU.FitEngine.iteration
 
 
-def it(self, use_graph=False, count=1):
+def it(self, use_graph=False, count=1, snapshot=False):
+    gkey = ("snap", count) if snapshot else count
     will_capture = use_graph and self._launched and not FU.PROFILE["mask"] and (
-        self._graph_key != bytes(self.state()) + bytes(self.hp) or count not in self._graphs)
+        self._graph_key != bytes(self.state()) + bytes(self.hp) or gkey not in self._graphs)
     if will_capture:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        orig_it(self, use_graph, count)
+        r = orig_it(self, use_graph, count, snapshot)
         torch.cuda.synchronize()
-        add(f"    graph capture + first replay (count={count})", time.perf_counter() - t0)
-        return
-    orig_it(self, use_graph, count)
+        add(f"    graph capture + first replay (count={count}, snapshot={snapshot})", time.perf_counter() - t0)
+        return r
+    return orig_it(self, use_graph, count, snapshot)
 
 
 FU.FitEngine.iteration = it
