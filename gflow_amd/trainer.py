@@ -619,7 +619,8 @@ class SimpleGaussian:
                         st.pin_hold()
                     st.pin_block, st.pin, st.pin_hold, st.ring = block, pin, hold, ring
                     st.copy_stream = _copy_stream(dev)
-                st.ring[k].copy_(imgs)
+                # (an elementwise kernel: ``copy_`` goes through the runtime's blit kernel, 47 us for these 3.7 MB)
+                torch.bitwise_or(imgs, 0, out=st.ring[k])
                 st.frames.append(st.pin[k, 0])
                 st.frames_depth.append(st.pin[k, 1])
                 st.frames_center.append(st.pin[k, 2])
