@@ -951,6 +951,104 @@ __device__ __forceinline__ void blend_bwd_terms(const float4& p0, const float4& 
 __device__ long long g_bwd_trace[16384 * 8];
 #endif
 
+struct AdamCfg {
+    float lr, b1, b2, eps, lr_end_factor;
+    int total_iters;
+};
+
+__device__ __forceinline__ void adam_scalars(const AdamCfg& a, int e, float lr, float& step_size, float& inv_sqrt_bc2) {
+    const float t = (float)(e + 1);
+    if (a.total_iters > 0) lr *= 1.f + (a.lr_end_factor - 1.f) * (float)min(e, a.total_iters) / (float)a.total_iters;
+    step_size = lr / (1.f - powf(a.b1, t));
+    inv_sqrt_bc2 = 1.f / sqrtf(1.f - powf(a.b2, t));
+}
+
+__device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, const AdamCfg& a, float step_size,
+                                             float inv_sqrt_bc2) {
+    m = fmaf(a.b1, m, (1.f - a.b1) * g);
+    v = fmaf(a.b2, v, (1.f - a.b2) * g * g);
+    const float denom = sqrtf(v) * inv_sqrt_bc2 + a.eps;
+    return p - step_size * (m / denom);
+}
+
+// Iterations that do not move the camera (lr_camera = 0: the first frame and every joint stage, three quarters of a clip's
+// iterations; or nothing is stepped any more after a densification) need no pose gradient, and what is left of the
+// camera / depth-affine launch -- fold the loss partials into sums[], step the depth affine, advance the step counter --
+// depends on the loss launch only.  One workgroup of the BACKWARD BLEND launch does it before its first tile (the per-splat
+// launch that follows reads the counter one too high and is told so): a launch less per iteration, and no reduction of
+// the twelve extrinsic partials in the per-splat launch.
+struct LossTail {
+    int enabled;
+    const float* p_ssim; int n_ssim;        // SSIM partials of the loss launch
+    const float* p_grad; int n_grad;        // [n_grad][4] = {sum mse_px, sum depth term, d/d depth_a, d/d depth_b}
+    float* depth_ab; float* ab_m; float* ab_v;
+    float* sums;                            // [8]
+    AdamCfg ac_ab;
+    int step_affine;                        // hp->step_camera (after a densification nothing is stepped)
+    int32_t* d_step;
+    float* d_extr_out;                      // [12]: zeros (not computed in such an iteration)
+};
+
+__device__ void loss_tail(const LossTail& t) {
+    constexpr int NV = 5;                   // mse, ssim, depth, d/da, d/db
+    constexpr int B = 256;
+    __shared__ float red[B / 64][NV];
+    __shared__ float ge[NV];
+    float ab[2] = {0.f, 0.f}, abm[2] = {0.f, 0.f}, abv[2] = {0.f, 0.f};
+    int e_step = 0;
+    if (threadIdx.x == 0) {                 // thread 0 needs these after the reduction: request them now
+        e_step = *t.d_step;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { ab[k] = t.depth_ab[k]; abm[k] = t.ab_m[k]; abv[k] = t.ab_v[k]; }
+    }
+    float acc[NV] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r0 = threadIdx.x; r0 < t.n_ssim; r0 += 8 * B) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (r0 + u * B < t.n_ssim) ? t.p_ssim[r0 + u * B] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[1] += v[u];
+    }
+    for (int r0 = threadIdx.x; r0 < t.n_grad; r0 += 4 * B) {
+        float4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            q[u] = (r0 + u * B < t.n_grad) ? reinterpret_cast<const float4*>(t.p_grad)[r0 + u * B]
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc[0] += q[u].x; acc[2] += q[u].y; acc[3] += q[u].z; acc[4] += q[u].w; }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const float s = wave_sum_to_lane63(acc[k]);
+        if (lane == 63) red[wid][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        float x = 0.f;
+#pragma unroll
+        for (int w = 0; w < B / 64; ++w) x += red[w][threadIdx.x];
+        ge[threadIdx.x] = x;
+        t.sums[threadIdx.x] = x;            // sums[0..4] as gfl_loss_fwd_bwd documents
+    }
+    if (threadIdx.x >= NV && threadIdx.x < NV + 3) t.sums[threadIdx.x] = 0.f;
+    if (threadIdx.x >= 16 && threadIdx.x < 28) t.d_extr_out[threadIdx.x - 16] = 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (t.step_affine) {
+            float ss, isb;
+            adam_scalars(t.ac_ab, e_step, t.ac_ab.lr, ss, isb);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                t.depth_ab[k] = adam_update(ab[k], ge[3 + k], abm[k], abv[k], t.ac_ab, ss, isb);
+                t.ab_m[k] = abm[k]; t.ab_v[k] = abv[k];
+            }
+        }
+        *t.d_step = e_step + 1;
+    }
+}
+
 __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __restrict__ rec,
                                                               const int32_t* __restrict__ ids,
                                                               const int32_t* __restrict__ tile_range, float bg, int W,
@@ -960,7 +1058,11 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
                                                               float* __restrict__ pair_grad, TileQueue queue,
                                                               int32_t* __restrict__ tile_work,
                                                               const float* __restrict__ ckpt,
-                                                              const float* __restrict__ render) {
+                                                              const float* __restrict__ render, LossTail ltail) {
+    // (see LossTail.  The workgroup that holds the LAST pre-assigned slot of queue 0 does it before its first item: ~3 us
+    //  that the seven other workgroups of its queue absorb.  A workgroup of its own behind the others only started when one
+    //  of them -- all persistent -- had finished: +1 us at the end of the launch.)
+    if (ltail.enabled && blockIdx.x == gridDim.x - queue.nq) loss_tail(ltail);
     // No global atomics: the four waves of the tile combine their per-splat sums in LDS and the
     // tile writes ONE 48-byte row per (splat, tile) pair at the pair's list position with plain,
     // coalesced stores.  The per-splat kernel gathers its rows afterwards (deterministic).
@@ -1194,25 +1296,7 @@ __global__ void __launch_bounds__(256) footprint_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------- preprocess backward + Adam (A13)
-struct AdamCfg {
-    float lr, b1, b2, eps, lr_end_factor;
-    int total_iters;
-};
-
-__device__ __forceinline__ void adam_scalars(const AdamCfg& a, int e, float lr, float& step_size, float& inv_sqrt_bc2) {
-    const float t = (float)(e + 1);
-    if (a.total_iters > 0) lr *= 1.f + (a.lr_end_factor - 1.f) * (float)min(e, a.total_iters) / (float)a.total_iters;
-    step_size = lr / (1.f - powf(a.b1, t));
-    inv_sqrt_bc2 = 1.f / sqrtf(1.f - powf(a.b2, t));
-}
-
-__device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, const AdamCfg& a, float step_size,
-                                             float inv_sqrt_bc2) {
-    m = fmaf(a.b1, m, (1.f - a.b1) * g);
-    v = fmaf(a.b2, v, (1.f - a.b2) * g * g);
-    const float denom = sqrtf(v) * inv_sqrt_bc2 + a.eps;
-    return p - step_size * (m / denom);
-}
+// (AdamCfg, adam_scalars, adam_update: above, beside loss_tail)
 
 struct RegCfg {                 // per-splat regularisers (trainer.py:490-530)
     float lambda_scale;         // lambda_scale (the row count divides it in the kernel)
@@ -1222,6 +1306,8 @@ struct RegCfg {                 // per-splat regularisers (trainer.py:490-530)
     float lambda_still;         // lambda_still (per-row weight in still_w carries 1/count)
     int freeze_rgb;             // trainer.py:537-540
     int freeze_all;             // camera_only, trainer.py:548-551
+    int no_pose_grad;           // the camera does not move in this iteration (LossTail): the step counter has been advanced
+                                // already, the twelve extrinsic partials are not reduced
 };
 
 // Camera + depth-affine step as the TAIL of the per-splat kernel (round 3; it used to be a launch of its own: one
@@ -1389,7 +1475,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
     }
     GFL_PHASE(3, 0);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int e_step = OP ? 0 : *d_step;              // (the tail of the LAST workgroup advances it)
+    const int e_step = OP ? 0 : *d_step - (rc.no_pose_grad ? 1 : 0);   // (the camera launch advances it -- or already has: LossTail)
     float scale_w = 0.f;                              // lambda_scale / rows of the scale term
     if (!OP && rc.lambda_scale != 0.f) {
         __shared__ int32_t s_rows;
@@ -1678,7 +1764,9 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
         }
     }
     GFL_PHASE(3, 6);
-    if (!OP && tail.ticket) {
+    if (!OP && rc.no_pose_grad) {
+        // nobody reads the extrinsic partials of this iteration
+    } else if (!OP && tail.ticket) {
         block_reduce_store<12, REDUCE_BLOCK, true>(e, partial);
         camera_tail(tail, partial, ns.rows, e_step);
     } else {
@@ -1845,6 +1933,16 @@ static bool next_sched_enabled() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("GFL_SCHED_NEXT");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+// GFL_POSE_FROZEN_FAST=0: iterations that do not move the camera keep the camera launch and the pose gradient (rounds 1-3)
+static bool pose_frozen_fast() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GFL_POSE_FROZEN_FAST");
         v = (e && e[0] == '0') ? 0 : 1;
     }
     return v == 1;
@@ -2187,7 +2285,7 @@ int gfl_render_bwd(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float
         const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters + w.sched.nq, w.sched.nq, w.sched.cap_q};
         fused_blend_bwd_kernel<<<blend_grid(T), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx,
                                                              st->final_T, st->n_contrib, d_render, w.pair_grad, q,
-                                                             w.sched.work, w.ckpt, st->render);
+                                                             w.sched.work, w.ckpt, st->render, LossTail{});
     }
     const int rows = reduce_rows(st->N > 0 ? st->N : 1);
     RegCfg rcfg = {};
@@ -2225,12 +2323,27 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
                                               &p_grad, &n_grad, stream);
     }
     if (rc) return rc;
+    AdamCfg ac = {hp->lr, hp->beta1, hp->beta2, hp->eps, hp->lr_end_factor, hp->total_iters};
+    AdamCfg ac_cam = ac;
+    ac_cam.lr = hp->lr_camera;
+    // The camera does not move in this iteration (see LossTail): no pose gradient, no camera launch.  step_camera = 2 asks
+    // for the gradient (d_extr) although nothing is stepped with it; GFL_POSE_FROZEN_FAST=0 switches the short cut off.
+    const bool frozen = pose_frozen_fast() && hp->step_camera != 2 && (hp->step_camera == 0 || hp->lr_camera == 0.f) &&
+                        camera_own_launch();
+    LossTail lt = {};
+    if (frozen) {
+        lt.enabled = 1;
+        lt.p_ssim = p_ssim; lt.n_ssim = n_ssim; lt.p_grad = p_grad; lt.n_grad = n_grad;
+        lt.depth_ab = st->depth_ab; lt.ab_m = st->depth_ab_m; lt.ab_v = st->depth_ab_v;
+        lt.sums = st->sums; lt.ac_ab = ac; lt.step_affine = hp->step_camera != 0;
+        lt.d_step = st->step; lt.d_extr_out = st->d_extr;
+    }
     {
         StageScope p(ST_BLEND_BWD, s);
         const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters + w.sched.nq, w.sched.nq, w.sched.cap_q};
-        fused_blend_bwd_kernel<<<blend_grid(T), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx,
-                                                             st->final_T, st->n_contrib, st->d_render, w.pair_grad, q,
-                                                             w.sched.work, w.ckpt, st->render);
+        fused_blend_bwd_kernel<<<blend_grid(T), 256, 0, s>>>(
+            st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx, st->final_T, st->n_contrib, st->d_render, w.pair_grad, q,
+            w.sched.work, w.ckpt, st->render, lt);
     }
     const int rows = reduce_rows(st->N > 0 ? st->N : 1);
     RegCfg rcfg;
@@ -2241,9 +2354,7 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
     rcfg.lambda_still = hp->lambda_still;
     rcfg.freeze_rgb = hp->freeze_rgb;
     rcfg.freeze_all = hp->freeze_all_splats;
-    AdamCfg ac = {hp->lr, hp->beta1, hp->beta2, hp->eps, hp->lr_end_factor, hp->total_iters};
-    AdamCfg ac_cam = ac;
-    ac_cam.lr = hp->lr_camera;
+    rcfg.no_pose_grad = frozen ? 1 : 0;
     // the camera / depth-affine step: a launch of its own, or (GFL_CAMERA_TAIL=1) the tail of the per-splat launch
     const bool own_launch = camera_own_launch();
     CamTail tail = {};
@@ -2262,11 +2373,11 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
             st->tile_range, w.slot_inv, gx, gy, st->N, st->W, st->H, st->flow_target, st->flow_w, st->still_target,
             st->still_w, st->row_flags, rcfg, ac, st->step, w.partial, nullptr, nullptr, nullptr, w.scale_cnt, tail, ns);
     }
-    if (own_launch) {
+    if (own_launch && !frozen) {
         StageScope p(ST_CAMERA, s);
         fused_camera_adam_kernel<<<1, 1024, 0, s>>>(w.partial, rows, p_ssim, n_ssim, p_grad, n_grad, st->pose, st->pose_m,
                                                     st->pose_v, st->depth_ab, st->depth_ab_m, st->depth_ab_v, st->sums,
-                                                    ac_cam, ac, hp->step_camera, st->step, st->d_extr);
+                                                    ac_cam, ac, hp->step_camera != 0, st->step, st->d_extr);
     }
     return check_launch();
 }

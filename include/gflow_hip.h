@@ -279,7 +279,12 @@ typedef struct gfl_fit_hyper {
     int32_t freeze_all_splats; /* camera_only, trainer.py:548-551: every splat gradient is zeroed.  The rows and their Adam moments
                                 * are then left untouched (not read, not written): what Adam does with zero gradients and
                                 * the zero moments a fresh optimiser starts from (trainer.py:383) */
-    int32_t step_camera;       /* 0 after densification replaced the optimiser (trainer.py:951) */
+    int32_t step_camera;       /* 1: pose and depth affine are stepped; 0: neither (after densification replaced the
+                                * optimiser, trainer.py:951).  While the camera cannot move -- 0, or 1 with lr_camera == 0 (the
+                                * first frame and every joint stage) -- an iteration computes no pose gradient and has no camera
+                                * launch: d_extr is set to zero, the pose moments stay as they are; loss sums, depth affine
+                                * and step counter as always.  2 = as 1, and the gradient (d_extr, pose moments) is wanted
+                                * although lr_camera is 0. */
 } gfl_fit_hyper;
 
 size_t gfl_fit_workspace_bytes(int cap, int K_cap, int W, int H);

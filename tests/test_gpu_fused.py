@@ -532,3 +532,37 @@ def test_fused_iteration_on_odd_sizes_matches_operator_path(W, H, N):
     assert torch.isfinite(eng.params[:N]).all() and torch.isfinite(eng.render).all()
     assert not torch.equal(eng.params[:N], before)
     assert sum(q.numel() for q in eng.schedule()) == eng.T
+
+
+def test_iterations_that_do_not_move_the_camera_take_the_short_cut_with_the_same_result(setup):
+    """lr_camera = 0 (first frame, joint stages): no camera launch, no pose gradient -- the loss sums, the depth affine and
+    the step counter come from a workgroup of the backward blend launch (LossTail, gfl_fused.hip).  Against the same
+    iterations with the gradient asked for (step_camera = 2: the camera launch as before): rows, moments, depth
+    affine, loss sums and step counter agree (the two folds add the same partials in trees of different width), the
+    pose does not move in either, and only the long way round reports d_extr."""
+    s, raw, img, dep = setup
+    lam = dict(lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0)
+    fast = _engine(raw, s, img, dep, pose=POSE, lr=2e-3, lr_camera=0.0, total_iters=6, **lam)
+    slow = _engine(raw, s, img, dep, pose=POSE, lr=2e-3, lr_camera=0.0, total_iters=6, **lam)
+    slow.hp.step_camera = 2
+    n = raw["xyz"].shape[0]
+    for it in range(4):
+        fast.iteration()
+        slow.iteration()
+        assert int(fast.step.item()) == int(slow.step.item()) == it + 1
+        np.testing.assert_allclose(fast.sums[:5].cpu().numpy(), slow.sums[:5].cpu().numpy(), rtol=2e-6)
+    assert torch.equal(fast.pose.cpu(), POSE) and torch.equal(slow.pose.cpu(), POSE)
+    np.testing.assert_allclose(fast.depth_ab.cpu().numpy(), slow.depth_ab.cpu().numpy(), rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(fast.ab_m.cpu().numpy(), slow.ab_m.cpu().numpy(), rtol=1e-4, atol=1e-9)
+    assert not torch.equal(fast.depth_ab.cpu(), torch.tensor([1.0, 0.0]))          # ... and it did step
+    err = (fast.params[:n, :14] - slow.params[:n, :14]).abs().max().item()
+    assert err < 1e-6, f"rows differ by {err:.2e}"
+    err_m = (fast.adam_m[:n, :14] - slow.adam_m[:n, :14]).abs().max().item()
+    scale = slow.adam_m[:n, :14].abs().max().item()
+    assert err_m < 1e-5 * scale
+    assert float(slow.d_extr.abs().max()) > 0.0 and float(fast.d_extr.abs().max()) == 0.0
+    # nothing is stepped any more after a densification (trainer.py:941-951): the depth affine stays, the counter runs
+    fast.hp.step_camera = 0
+    ab0 = fast.depth_ab.clone()
+    fast.iteration()
+    assert torch.equal(fast.depth_ab, ab0) and int(fast.step.item()) == 5
