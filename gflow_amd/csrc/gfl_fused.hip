@@ -1982,7 +1982,16 @@ static int blend_queues() {
 }
 
 // workgroups of a blend launch: up to 8 per queue (all resident), fewer for small tile grids
+// (GFL_FWD_WG / GFL_BWD_WG: fewer workgroups per CU than fit -- the rest of a queue is then pulled as workgroups finish)
+static int env_wg(const char* name, int dflt) {
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : 0;
+    return v > 0 && v < dflt ? v : dflt;
+}
+
 static int blend_grid(int T, int max_per_cu = BLEND_WG_PER_CU) {
+    static const int fwd_wg = env_wg("GFL_FWD_WG", FWD_WG_PER_CU), bwd_wg = env_wg("GFL_BWD_WG", BLEND_WG_PER_CU);
+    max_per_cu = max_per_cu == FWD_WG_PER_CU ? fwd_wg : bwd_wg;
     const int nq = blend_queues();
     int per = (T + nq - 1) / nq + 1;
     if (per > max_per_cu) per = max_per_cu;
