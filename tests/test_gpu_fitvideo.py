@@ -2,6 +2,7 @@
 state (flow warp of moving splats, still/moving labels), the camera-only phase with the
 tentative-moving footprint, the flow / still terms, occlusion-mask densification, and hipGraph
 capture of the fused iteration."""
+import numpy as np
 import pytest
 import torch
 
@@ -273,3 +274,37 @@ def test_move_seg_covers_the_moving_splats():
     assert (seg[gt] > 0).mean() > 0.8 and (seg[~gt] > 0).mean() < 0.1, ((seg[gt] > 0).mean(), (seg[~gt] > 0).mean())
     er = tr.move_seg_erode
     assert er.shape == seg.shape and not bool(((er > 0) & (seg == 0)).any()) and 0 < (er > 0).sum() < (seg > 0).sum()
+
+
+def test_snapshots_returned_by_train_are_the_renders_of_their_iterations():
+    """The snapshot images stay on the device until the end of ``train()`` (a ring in HBM) and reach the host in one copy:
+    the list ``train()`` returns must hold, slot by slot, what was rendered at iterations 0, 8, 16 -- checked on the last
+    one against an identically seeded fit stopped at iteration 16 and rendered there (every slot must also differ from
+    its neighbours: a ring that kept overwriting one slot would pass a test of the last image alone)."""
+    from gflow_amd import synthetic as S
+    from gflow_amd.trainer import SimpleGaussian
+    import gflow_amd.render as R
+    f = S.make_clip(1, 96, 128, seed=6)[0]
+    kw = dict(lr=4e-3, lambda_rgb=1.0, lambda_depth=1e-2, lambda_var=1.0, densify_interval=0, move_mask=f["move_mask"])
+
+    def make():
+        tr = SimpleGaussian(f["image"], f["depth"], num_points=1500, device=DEV, seed=0)
+        tr.load_camera(focal=f["focal"], pp=f["pp"])
+        tr.init_gaussians_from_image(f["image"], f["depth"], num_points=1500)
+        return tr
+
+    a = make()
+    frames, centers, depths = a.train(iterations=17, snapshot_interval=8, **kw)[:3]
+    assert len(frames) == len(centers) == len(depths) == 3
+    for lst in (frames, centers, depths):
+        assert all(im.shape == (96, 128, 3) and im.dtype == np.uint8 for im in lst)
+    assert np.abs(frames[0].astype(int) - frames[1].astype(int)).mean() > 0.5      # the fit moved between the snapshots
+    assert np.abs(frames[1].astype(int) - frames[2].astype(int)).mean() > 0.1
+    b = make()
+    b.make_stepper(iterations=17, snapshot_interval=0, **kw).run(16)     # (the same LinearLR schedule, stopped at 16)
+    b.engine.forward()
+    torch.cuda.synchronize()
+    want = R.render2img(b.engine.render[:3])
+    diff = np.abs(frames[2].astype(int) - want.astype(int))
+    # (two fits with the same seed differ by the order of the backward's LDS atomics: a grey level here and there)
+    assert diff.mean() < 0.2 and (diff <= 2).mean() > 0.995, (diff.mean(), diff.max())
