@@ -1049,6 +1049,10 @@ __device__ void loss_tail(const LossTail& t) {
     }
 }
 
+// GEOM_ONLY: the camera-only stage (freeze_all_splats) -- every splat gradient is zeroed afterwards, and the pose gradient
+// needs only the five moments and the depth feature's gradient of a pair: the opacity / colour sums are neither formed
+// nor reduced (six values through the wave reduce-scatter instead of ten, 16 VALU ops instead of 27 per unit).
+template <bool GEOM_ONLY>
 __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __restrict__ rec,
                                                               const int32_t* __restrict__ ids,
                                                               const int32_t* __restrict__ tile_range, float bg, int W,
@@ -1073,7 +1077,9 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
     __shared__ int32_t s_ticket;
     __shared__ int32_t s_simd[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int comp = reduce_scatter10_component(lane);     // the component this lane adds into acc[][]
+    // the component this lane adds into acc[][] (GEOM_ONLY: the sixth value is the depth feature's gradient, column 9)
+    const int comp6 = reduce_scatter6_component(lane);
+    const int comp = GEOM_ONLY ? (comp6 == 5 ? 9 : comp6) : reduce_scatter10_component(lane);
     // Which SIMD is this wave on?  The scheduler plans which SIMD walks which 8x8 block of every item (gfl_sched.hpp,
     // "block plan"); the plan is followed only if the workgroup's four waves sit on four different SIMDs (they do: the
     // dispatcher deals a workgroup's waves round the SIMDs), otherwise wave k walks block k.
@@ -1209,7 +1215,13 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
                 // (an interleaved two-splat version of this body was measured slower, twice)
                 float v[10];
                 blend_bwd_terms(p0, p1, p2, fx, fy, valid, alpha, G, g0, g1, g2, g3, T, S, v);
-                const float mine = wave_reduce_scatter10(v, lane);
+                float mine;
+                if (GEOM_ONLY) {
+                    const float v6[6] = {v[0], v[1], v[2], v[3], v[4], v[9]};
+                    mine = wave_reduce_scatter6(v6, lane);
+                } else {
+                    mine = wave_reduce_scatter10(v, lane);
+                }
                 if (comp >= 0) atomicAdd(&acc[j][comp], mine);
             }
         }
@@ -1677,8 +1689,10 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
                 float gcov[6], ex, ey, ez;
                 ewa_bwd(c, f, px, py, cov, d0.z, d0.w, d1.x, gcov, ex, ey, ez, e);
                 gx_ += ex; gy_ += ey; gz_ += ez;
-                float ds[3], dq[4];
-                cov3d_bwd(s.s, s.q, gcov, ds, dq);
+                // (camera-only stage: the pose gradient is complete with ewa_bwd and cam_grad_to_world; what follows --
+                //  scale / rotation gradients, the blended attributes, the regularisers -- would be zeroed at the end)
+                float ds[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
+                if (OP || !rc.freeze_all) cov3d_bwd(s.s, s.q, gcov, ds, dq);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) g[3 + k] = ds[k];
                 if (OP) {
@@ -1700,7 +1714,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
             o4[1] = make_float4(g[4], g[5], g[6], g[7]);
             o4[2] = make_float4(g[8], g[9], d1.y, d1.z);
             o4[3] = make_float4(d1.w, d2.x, 0.f, 0.f);
-        } else {
+        } else if (!rc.freeze_all) {
         // blended attributes: opacity = sigmoid(10 x), rgb = sigmoid(x)
         g[10] = d1.y * 10.f * s.o * (1.f - s.o);
         g[11] = d1.z * s.c[0] * (1.f - s.c[0]);
@@ -1933,6 +1947,16 @@ static bool next_sched_enabled() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("GFL_SCHED_NEXT");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+// GFL_BWD_GEOM_ONLY=0: the camera-only stage runs the full backward blend (opacity / colour sums formed, reduced and dropped)
+static bool bwd_geom_only() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GFL_BWD_GEOM_ONLY");
         v = (e && e[0] == '0') ? 0 : 1;
     }
     return v == 1;
@@ -2292,9 +2316,9 @@ int gfl_render_bwd(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float
     {
         StageScope p(ST_BLEND_BWD, s);
         const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters + w.sched.nq, w.sched.nq, w.sched.cap_q};
-        fused_blend_bwd_kernel<<<blend_grid(T), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx,
-                                                             st->final_T, st->n_contrib, d_render, w.pair_grad, q,
-                                                             w.sched.work, w.ckpt, st->render, LossTail{});
+        fused_blend_bwd_kernel<false><<<blend_grid(T), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx,
+                                                                    st->final_T, st->n_contrib, d_render, w.pair_grad, q,
+                                                                    w.sched.work, w.ckpt, st->render, LossTail{});
     }
     const int rows = reduce_rows(st->N > 0 ? st->N : 1);
     RegCfg rcfg = {};
@@ -2350,9 +2374,9 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
     {
         StageScope p(ST_BLEND_BWD, s);
         const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters + w.sched.nq, w.sched.nq, w.sched.cap_q};
-        fused_blend_bwd_kernel<<<blend_grid(T), 256, 0, s>>>(
-            st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx, st->final_T, st->n_contrib, st->d_render, w.pair_grad, q,
-            w.sched.work, w.ckpt, st->render, lt);
+        auto kern = (hp->freeze_all_splats && bwd_geom_only()) ? fused_blend_bwd_kernel<true> : fused_blend_bwd_kernel<false>;
+        kern<<<blend_grid(T), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx, st->final_T, st->n_contrib,
+                                           st->d_render, w.pair_grad, q, w.sched.work, w.ckpt, st->render, lt);
     }
     const int rows = reduce_rows(st->N > 0 ? st->N : 1);
     RegCfg rcfg;
