@@ -190,6 +190,45 @@ __device__ __forceinline__ int reduce_scatter6_component(int lane) {
     return sel == 0 ? 2 * odd + hi : ((sel == 1 && odd == 0) ? 4 + hi : -1);
 }
 
+// ... and for SEVEN (later frames: the colours are frozen, trainer.py:537-540 -- the moments, the opacity's and the depth
+// feature's gradient remain): eight slots {c0 .. c6, 0}, 8 -> 4 -> 2 values, then the two folded over a row: 18 VALU ops.
+// Afterwards lanes with bit 0 clear hold component 2 * odd + hi, lanes with bit 0 set component 4 + hi in even rows and
+// component 6 in row (hi = 0, odd = 1).
+__device__ __forceinline__ void permlane32_swap_x4(float (&a)[4], float (&b)[4]) {
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\t"
+        "v_permlane32_swap_b32 %3, %7"
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+}
+__device__ __forceinline__ float wave_reduce_scatter7(const float (&v)[7], int lane) {
+    float w[4];
+    {
+        float a[4] = {v[0], v[2], v[4], v[6]}, b[4] = {v[1], v[3], v[5], 0.f};
+        permlane32_swap_x4(a, b);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) w[m] = a[m] + b[m];   // lanes 0-31: component 2m, lanes 32-63: component 2m+1
+    }
+    float x[2];
+    {
+        float a[2] = {w[0], w[2]}, b[2] = {w[1], w[3]};
+        permlane16_swap_x2(a, b);
+        x[0] = a[0] + b[0];                                // even rows: w0, odd rows: w1
+        x[1] = a[1] + b[1];                                // even rows: w2, odd rows: w3
+    }
+#define GFL_DPP(val, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (val)), ctrl, 0xF, 0xF, true))
+    const bool b0 = lane & 1;
+    const float keep = b0 ? x[1] : x[0], send = b0 ? x[0] : x[1];
+    float t = keep + GFL_DPP(send, 0xB1);                  // quad_perm [1,0,3,2]
+    t += GFL_DPP(t, 0x4E);                                 // quad_perm [2,3,0,1]
+    t += GFL_DPP(t, 0x124);                                // row_ror:4
+    t += GFL_DPP(t, 0x128);                                // row_ror:8
+#undef GFL_DPP
+    return t;
+}
+__device__ __forceinline__ int reduce_scatter7_component(int lane) {
+    const int hi = lane >> 5, odd = (lane >> 4) & 1, sel = lane & 15;
+    return sel == 0 ? 2 * odd + hi : (sel == 1 ? (odd == 0 ? 4 + hi : (hi == 0 ? 6 : -1)) : -1);
+}
+
 // Deterministic block-level reduction of NV values -> one partial row per block.
 // partial[blockIdx.x * NV + k]; a second tiny kernel folds the rows in order.
 // AGENT: the row is stored with agent-scope atomic stores (write-through), for a reader in ANOTHER workgroup of the

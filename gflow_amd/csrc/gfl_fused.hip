@@ -1049,10 +1049,11 @@ __device__ void loss_tail(const LossTail& t) {
     }
 }
 
-// GEOM_ONLY: the camera-only stage (freeze_all_splats) -- every splat gradient is zeroed afterwards, and the pose gradient
-// needs only the five moments and the depth feature's gradient of a pair: the opacity / colour sums are neither formed
-// nor reduced (six values through the wave reduce-scatter instead of ten, 16 VALU ops instead of 27 per unit).
-template <bool GEOM_ONLY>
+// SUMS: how many of the ten per-pair sums somebody reads.  10: the first frame.  7: later frames, whose colours are frozen
+// (freeze_rgb, trainer.py:537-540) -- the three colour sums are neither formed nor reduced (18 VALU ops in the wave
+// reduce-scatter instead of 27 per unit).  6: the camera-only stage (freeze_all_splats) -- every splat gradient is zeroed
+// afterwards, and the pose gradient needs only the five moments and the depth feature's gradient (16 ops).
+template <int SUMS>
 __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __restrict__ rec,
                                                               const int32_t* __restrict__ ids,
                                                               const int32_t* __restrict__ tile_range, float bg, int W,
@@ -1077,9 +1078,9 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
     __shared__ int32_t s_ticket;
     __shared__ int32_t s_simd[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // the component this lane adds into acc[][] (GEOM_ONLY: the sixth value is the depth feature's gradient, column 9)
-    const int comp6 = reduce_scatter6_component(lane);
-    const int comp = GEOM_ONLY ? (comp6 == 5 ? 9 : comp6) : reduce_scatter10_component(lane);
+    // the component this lane adds into acc[][] (SUMS 6 / 7: the last value is the depth feature's gradient, column 9)
+    const int comp_few = SUMS == 6 ? reduce_scatter6_component(lane) : reduce_scatter7_component(lane);
+    const int comp = SUMS == 10 ? reduce_scatter10_component(lane) : (comp_few == SUMS - 1 ? 9 : comp_few);
     // Which SIMD is this wave on?  The scheduler plans which SIMD walks which 8x8 block of every item (gfl_sched.hpp,
     // "block plan"); the plan is followed only if the workgroup's four waves sit on four different SIMDs (they do: the
     // dispatcher deals a workgroup's waves round the SIMDs), otherwise wave k walks block k.
@@ -1216,9 +1217,12 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
                 float v[10];
                 blend_bwd_terms(p0, p1, p2, fx, fy, valid, alpha, G, g0, g1, g2, g3, T, S, v);
                 float mine;
-                if (GEOM_ONLY) {
+                if (SUMS == 6) {
                     const float v6[6] = {v[0], v[1], v[2], v[3], v[4], v[9]};
                     mine = wave_reduce_scatter6(v6, lane);
+                } else if (SUMS == 7) {
+                    const float v7[7] = {v[0], v[1], v[2], v[3], v[4], v[5], v[9]};
+                    mine = wave_reduce_scatter7(v7, lane);
                 } else {
                     mine = wave_reduce_scatter10(v, lane);
                 }
@@ -1952,7 +1956,7 @@ static bool next_sched_enabled() {
     return v == 1;
 }
 
-// GFL_BWD_GEOM_ONLY=0: the camera-only stage runs the full backward blend (opacity / colour sums formed, reduced and dropped)
+// GFL_BWD_GEOM_ONLY=0: every stage runs the full backward blend (sums that nobody reads formed, reduced and dropped)
 static bool bwd_geom_only() {
     static int v = -1;
     if (v < 0) {
@@ -2316,7 +2320,7 @@ int gfl_render_bwd(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float
     {
         StageScope p(ST_BLEND_BWD, s);
         const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters + w.sched.nq, w.sched.nq, w.sched.cap_q};
-        fused_blend_bwd_kernel<false><<<blend_grid(T), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx,
+        fused_blend_bwd_kernel<10><<<blend_grid(T), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx,
                                                                     st->final_T, st->n_contrib, d_render, w.pair_grad, q,
                                                                     w.sched.work, w.ckpt, st->render, LossTail{});
     }
@@ -2374,7 +2378,9 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
     {
         StageScope p(ST_BLEND_BWD, s);
         const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters + w.sched.nq, w.sched.nq, w.sched.cap_q};
-        auto kern = (hp->freeze_all_splats && bwd_geom_only()) ? fused_blend_bwd_kernel<true> : fused_blend_bwd_kernel<false>;
+        auto kern = !bwd_geom_only() ? fused_blend_bwd_kernel<10>
+                    : (hp->freeze_all_splats ? fused_blend_bwd_kernel<6>
+                                             : (hp->freeze_rgb ? fused_blend_bwd_kernel<7> : fused_blend_bwd_kernel<10>));
         kern<<<blend_grid(T), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx, st->final_T, st->n_contrib,
                                            st->d_render, w.pair_grad, q, w.sched.work, w.ckpt, st->render, lt);
     }
