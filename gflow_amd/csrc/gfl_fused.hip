@@ -621,7 +621,7 @@ __device__ long long g_fwd_trace[16384 * 8];     // analysis build: per-tile tim
 // apply_float_colormap(depth, "turbo", non_zero=True) for one value (color.py:24-44): mm = ordered-uint encodings of
 // min over the non-zero values and max over all (cmap_range_kernel, gfl_loss.hip)
 __device__ __forceinline__ float3 cmap_nonzero_lookup(float v, const unsigned* __restrict__ mm, const float* __restrict__ lut) {
-    const unsigned k0 = mm[0], k1 = mm[1];
+    const unsigned k0 = ~mm[0], k1 = mm[1];          // (the minimum is kept complemented: both words start from zero)
     const float lo = (k0 == 0xffffffffu) ? 0.f : __uint_as_float((k0 & 0x80000000u) ? (k0 & 0x7fffffffu) : ~k0);
     const float hi = __uint_as_float((k1 & 0x80000000u) ? (k1 & 0x7fffffffu) : ~k1) - lo;
     float x = (v - lo) / (hi + 1e-5f);
@@ -2225,7 +2225,8 @@ int gfl_fit_forward(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream
 
 namespace gfl {
 // min over the non-zero / max over all depths of the records, as ordered-uint keys (the range of
-// apply_float_colormap(non_zero=True), color.py:28-31; same encoding as cmap_range_kernel of gfl_loss.hip)
+// apply_float_colormap(non_zero=True), color.py:28-31; the encoding of cmap_range_kernel of gfl_loss.hip, the minimum
+// COMPLEMENTED so that both words are initialised by the one memset that also clears the snapshot's pull counters)
 __global__ void __launch_bounds__(256) rec_depth_range_kernel(const float* __restrict__ rec, int N, unsigned* __restrict__ mm) {
     unsigned lo = 0xffffffffu, hi = 0u;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
@@ -2241,7 +2242,7 @@ __global__ void __launch_bounds__(256) rec_depth_range_kernel(const float* __res
         hi = max(hi, (unsigned)__shfl_xor((int)hi, off));
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicMin(&mm[0], lo);
+        atomicMax(&mm[0], ~lo);
         atomicMax(&mm[1], hi);
     }
 }
@@ -2265,7 +2266,7 @@ __global__ void __launch_bounds__(256) snapshot_u8_kernel(const float* __restric
 
 size_t gfl_fit_snapshot_workspace_bytes(int N, int W, int H) {
     if (N < 0 || W <= 0 || H <= 0) return 0;
-    return 256 + 2 * up256((size_t)4 * W * H * sizeof(float)) +
+    return 256 + up256(2 * SCHED_MAX_QUEUES * sizeof(int32_t)) + 2 * up256((size_t)4 * W * H * sizeof(float)) +
            up256((size_t)W * H * sizeof(float)) + up256((size_t)W * H * sizeof(int32_t));
 }
 
@@ -2280,21 +2281,22 @@ int gfl_fit_snapshot(const gfl_fit_state* st, const gfl_fit_hyper* hp, const flo
     const int P = st->W * st->H;
     const FitWs w = carve(st);
     char* p = (char*)workspace;
+    // head of the workspace, cleared by ONE memset: the depth range's two words and a set of queue pull counters for each
+    // of the two composites (four memset launches of ~6 us each before: a snapshot every tenth iteration)
     unsigned* mm = (unsigned*)p;                 p += 256;
+    int32_t* pull = (int32_t*)p;                 p += up256(2 * SCHED_MAX_QUEUES * sizeof(int32_t));
+    const size_t head_bytes = (size_t)(p - (char*)workspace);
     float* img_dc = (float*)p;                   p += up256((size_t)4 * P * sizeof(float));
     float* img_c = (float*)p;                    p += up256((size_t)4 * P * sizeof(float));
     float* fT = (float*)p;                       p += up256((size_t)P * sizeof(float));
     int32_t* nc = (int32_t*)p;
-    rc = check(hipMemsetAsync(mm, 0xff, 4, s));
-    if (!rc) rc = check(hipMemsetAsync(mm + 1, 0, 4, s));
+    rc = check(hipMemsetAsync(workspace, 0, head_bytes, s));
     if (rc) return rc;
     // (few blocks: a thousand waves hitting the two result words with atomics took 23 us)
     if (st->N > 0) rec_depth_range_kernel<<<min((st->N + 255) / 256, 32), 256, 0, s>>>(st->rec, st->N, mm);
-    const TileQueue q = {w.sched_fwd.list, w.sched_fwd.count, w.sched.counters, w.sched.nq, w.sched.cap_q};
     for (int mode = 1; mode <= 2; ++mode) {
-        // the forward launch of the iteration (and the first pass here) used up the queues' pull counters
-        rc = check(hipMemsetAsync(w.sched.counters, 0, (size_t)w.sched.nq * sizeof(int32_t), s));
-        if (rc) return rc;
+        // (the forward launch of the iteration used up the engine's own pull counters)
+        const TileQueue q = {w.sched_fwd.list, w.sched_fwd.count, pull + (mode - 1) * SCHED_MAX_QUEUES, w.sched.nq, w.sched.cap_q};
         fused_blend_fwd_kernel<<<blend_grid(T, FWD_WG_PER_CU), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H,
                                                                             gx, mode == 1 ? img_dc : img_c, fT, nc, q, w.ckpt,
                                                                             mode, mm, lut, fwd_split_min(), w.sched_fwd.work,
