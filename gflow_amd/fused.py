@@ -96,9 +96,12 @@ class FitEngine:
         f32 = dict(dtype=torch.float32, device=self.dev)
         i32 = dict(dtype=torch.int32, device=self.dev)
         H_, W_ = self.H, self.W
-        self.pose = torch.tensor([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], **f32)
+        # (fills, not torch.tensor(..., device=): a copy from pageable memory stops the host until the device is idle)
+        self.pose = torch.zeros(7, **f32)
+        self.pose[3:4].fill_(1.0)
         self.pose_m, self.pose_v = torch.zeros(7, **f32), torch.zeros(7, **f32)
-        self.depth_ab = torch.tensor([1.0, 0.0], **f32)
+        self.depth_ab = torch.zeros(2, **f32)
+        self.depth_ab[0:1].fill_(1.0)
         self.ab_m, self.ab_v = torch.zeros(2, **f32), torch.zeros(2, **f32)
         self.intr = torch.zeros(4, **f32)
         self.extr = torch.zeros(12, **f32)
