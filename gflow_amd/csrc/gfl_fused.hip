@@ -2306,6 +2306,61 @@ int gfl_fit_snapshot(const gfl_fit_state* st, const gfl_fit_hyper* hp, const flo
     return check_launch();
 }
 
+}  // extern "C"
+
+namespace gfl {
+// Everything gfl_fit_snapshot reads of a forward -- records, sorted ids, tile ranges, the rgb planes of the render, the
+// forward's tile queues -- copied from one engine to another in ONE launch (gfl_fit_snapshot_stage).  The number of ids
+// is a device value (tile_offsets[T]).
+struct StageSeg { const uint32_t* src; uint32_t* dst; unsigned n; };      // n: 32-bit words
+struct StageCopy { StageSeg seg[7]; const int32_t* k_ptr; unsigned ids_cap; };
+__global__ void __launch_bounds__(256) snapshot_stage_kernel(StageCopy c) {
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+#pragma unroll
+    for (int sgi = 0; sgi < 7; ++sgi) {
+        const StageSeg sg = c.seg[sgi];
+        unsigned n = sg.n;
+        if (sgi == 0) n = min((unsigned)max(*c.k_ptr, 0), c.ids_cap);      // segment 0: the ids
+        const unsigned n4 = n >> 2;
+        const uint4* s4 = reinterpret_cast<const uint4*>(sg.src);
+        uint4* d4 = reinterpret_cast<uint4*>(sg.dst);
+        for (unsigned i = tid; i < n4; i += stride) d4[i] = s4[i];
+        for (unsigned i = (n4 << 2) + tid; i < n; i += stride) sg.dst[i] = sg.src[i];
+    }
+}
+}  // namespace gfl
+
+extern "C" {
+
+int gfl_fit_snapshot_stage(const gfl_fit_state* src, const gfl_fit_state* dst, gfl_stream_t stream) {
+    if (!src || !dst || !src->workspace || !dst->workspace || !src->rec || !dst->rec || !src->ids || !dst->ids ||
+        !src->tile_range || !dst->tile_range || !src->render || !dst->render || !src->tile_offsets)
+        return GFL_ERR_INVALID;
+    if (src->W != dst->W || src->H != dst->H || src->N != dst->N || dst->N > dst->cap || src->N > src->cap)
+        return GFL_ERR_INVALID;
+    if (src->workspace_bytes < gfl_fit_workspace_bytes(src->cap, src->K_cap, src->W, src->H) ||
+        dst->workspace_bytes < gfl_fit_workspace_bytes(dst->cap, dst->K_cap, dst->W, dst->H))
+        return GFL_ERR_WORKSPACE;
+    const int gx = (src->W + GFL_TILE - 1) / GFL_TILE, gy = (src->H + GFL_TILE - 1) / GFL_TILE, T = gx * gy;
+    const size_t P = (size_t)src->W * src->H;
+    const FitWs a = carve(src), b = carve(dst);
+    if (a.sched_fwd.nq != b.sched_fwd.nq || a.sched_fwd.cap_q != b.sched_fwd.cap_q) return GFL_ERR_INVALID;
+    StageCopy c;
+    c.k_ptr = src->tile_offsets + T;
+    c.ids_cap = (unsigned)min(src->K_cap, dst->K_cap);
+    c.seg[0] = {(const uint32_t*)src->ids, (uint32_t*)dst->ids, 0u};
+    c.seg[1] = {(const uint32_t*)src->rec, (uint32_t*)dst->rec, (unsigned)((size_t)src->N * REC)};
+    c.seg[2] = {(const uint32_t*)src->tile_range, (uint32_t*)dst->tile_range, (unsigned)(2 * T)};
+    c.seg[3] = {(const uint32_t*)src->render, (uint32_t*)dst->render, (unsigned)(3 * P)};
+    c.seg[4] = {(const uint32_t*)a.sched_fwd.list, (uint32_t*)b.sched_fwd.list,
+                (unsigned)((size_t)a.sched_fwd.nq * a.sched_fwd.cap_q)};
+    c.seg[5] = {(const uint32_t*)a.sched_fwd.count, (uint32_t*)b.sched_fwd.count, (unsigned)a.sched_fwd.nq};
+    // (first_slot -- which queue holds a tile as its first item: where the forward kernel leaves its checkpoints)
+    c.seg[6] = {(const uint32_t*)a.sched.first_slot, (uint32_t*)b.sched.first_slot, (unsigned)T};
+    snapshot_stage_kernel<<<1024, 256, 0, (hipStream_t)stream>>>(c);
+    return check_launch();
+}
+
 int gfl_render_fwd(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream) {
     if (st && st->foot_flags) return GFL_ERR_INVALID;
     return fit_forward_impl(st, hp, stream, 1);

@@ -112,7 +112,8 @@ def fit_clip(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, 
     return drive()
 
 
-def fit_clip_steps(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, log=None, load_extr=True, chunk=None):
+def fit_clip_steps(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, log=None, load_extr=True, chunk=None,
+                   async_snapshots=True):
     """fit_clip as a generator: yields after every ``chunk`` iterations of a stage (None: never) and returns the metrics
     dict.  The caller owns the stream the work is enqueued on (fit_clips_concurrent gives every clip its own)."""
     from .trainer import SimpleGaussian
@@ -123,6 +124,7 @@ def fit_clip_steps(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=
     f0 = frames[0]
     tr = SimpleGaussian(f0["image"], f0["depth"], num_points=c["num_points"], background=c["background"],
                         device=device, seed=seed, fused=fused)
+    tr.async_snapshots = bool(async_snapshots)       # (trainer.py: snapshots composed beside the next iterations, or behind theirs)
     tr.load_camera(focal=f0["focal"], pp=f0["pp"])
     if load_extr and f0.get("extr") is not None:
         tr.load_camera(extr=f0["extr"])
@@ -188,7 +190,10 @@ def fit_clips_concurrent(clips, device, cfg=None, seeds=None, snapshot_interval=
     streams = [torch.cuda.Stream(device=dev) for _ in range(n)]
     for s in streams:
         s.wait_stream(cur)
-    gens = [fit_clip_steps(clips[i], dev, cfg, seed=seeds[i], snapshot_interval=snapshot_interval, chunk=chunk)
+    # (a lone fit takes its snapshots on a side stream; several fits already fill each other's gaps, and a side stream + shadow
+    #  engine per clip cost them more than they give)
+    gens = [fit_clip_steps(clips[i], dev, cfg, seed=seeds[i], snapshot_interval=snapshot_interval, chunk=chunk,
+                           async_snapshots=n == 1)
             for i in range(n)]
     results = [None] * n
     live = list(range(n))

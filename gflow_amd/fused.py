@@ -361,14 +361,15 @@ class FitEngine:
             return self._snap_out
         return None
 
-    def snapshot(self):
+    def snapshot(self, out=None):
         """(3, H, W, 3) uint8 on the device: rgb, depth_map_color, center of the last forward (gfl_fit_snapshot).
-        Only AFTER the iteration's backward."""
+        Only AFTER the iteration's backward.  ``out``: a contiguous (3, H, W, 3) uint8 tensor to write into."""
         from .color import lut
         need = self.lib.gfl_fit_snapshot_workspace_bytes(self.N, self.W, self.H)
         if getattr(self, "_snap_ws", None) is None or self._snap_ws.numel() < need:
             self._snap_ws = torch.empty(int(need * 1.5), dtype=torch.uint8, device=self.dev)
-        out = torch.empty(3, self.H, self.W, 3, dtype=torch.uint8, device=self.dev)
+        if out is None:
+            out = torch.empty(3, self.H, self.W, 3, dtype=torch.uint8, device=self.dev)
         L.check(self.lib.gfl_fit_snapshot(ctypes.byref(self.state()), ctypes.byref(self.hp), L.ptr(lut("turbo", self.dev)),
                                           L.ptr(out), L.ptr(self._snap_ws), self._snap_ws.numel(), L.stream()), "snapshot")
         return out

@@ -196,6 +196,7 @@ class SimpleGaussian:
         (gflow_amd/fused.py); ``fused=False`` composes the msplat-compatible autograd operators
         the way the reference does (slower, same results)."""
         self.fused = bool(fused)
+        self.async_snapshots = True      # snapshots composed on a side stream from a copy of the forward's state (make_stepper)
         self.use_graph = True          # replay the fused iteration as a hipGraph when nothing else happens in it
         self.engine = None
         self.device = torch.device(device if device is not None else "cuda")
@@ -606,9 +607,12 @@ class SimpleGaussian:
             if tentative:
                 self.rasterisations_done += 1                # the reference's extra render of the moving set
             if snap:
-                # the three images of THIS iteration's forward (render, records and lists are untouched by the
-                # backward) behind the iteration, in the same graph launch
-                imgs = eng.iteration(use_graph=self.use_graph, snapshot=True)
+                # The three images of THIS iteration's forward are composed on a stream of their own, from a COPY of what the
+                # forward left behind (records, sorted ids, tile ranges, the render, the tile queues: 9 MB, one launch --
+                # gfl_fit_snapshot_stage -- into a shadow engine), BESIDE the next iterations instead of between them.  Inside
+                # the iteration's own graph the snapshot cost 115-140 us every tenth iteration, 4-5 % of a clip fit; two
+                # independent chains of launches share the chip well (two clips on one GPU: 1.43x), a fork inside a graph
+                # does not.
                 # They stay on the DEVICE until the end of this train() call (a ring of uint8 images in HBM: 3.7 MB each at
                 # 480p, 50 per call) and leave for page-locked memory in ONE copy then.  A copy to the host while the
                 # iterations run holds up whatever kernel is running beside it for as long as it lasts -- 65 us, every
@@ -625,18 +629,28 @@ class SimpleGaussian:
                     _PINNED.release(block)
                     ring = eng.snapshot_ring(n_snaps)                # (waits, on the stream, for the last call's copy)
                     if st.pin is not None:
+                        if getattr(st, "snap_stream", None) is not None:
+                            torch.cuda.current_stream().wait_stream(st.snap_stream)   # (the shadow engine writes the old ring)
                         ring[:k].copy_(st.ring[:k])
                         st.frames, st.frames_depth, st.frames_center = ([pin[j, c] for j in range(k)] for c in range(3))
                         st.pin_hold()
                     st.pin_block, st.pin, st.pin_hold, st.ring = block, pin, hold, ring
                     st.copy_stream = _copy_stream(dev)
-                # (an elementwise kernel: ``copy_`` goes through the runtime's blit kernel, 47 us for these 3.7 MB)
-                torch.bitwise_or(imgs, 0, out=st.ring[k])
                 st.frames.append(st.pin[k, 0])
                 st.frames_depth.append(st.pin[k, 1])
                 st.frames_center.append(st.pin[k, 2])
+            if snap and not self.async_snapshots:
+                # (several fits sharing the device -- fit_clips_concurrent -- already fill each other's gaps, and a side
+                #  stream and a shadow engine per clip cost them more than they give: 12.7 -> 10.9 frames/s with two clips.
+                #  There the snapshot stays behind the iteration, in the same graph launch; an elementwise kernel moves it
+                #  into the ring: ``copy_`` goes through the runtime's blit kernel, 47 us for these 3.7 MB)
+                imgs = eng.iteration(use_graph=self.use_graph, snapshot=True)
+                torch.bitwise_or(imgs, 0, out=st.ring[k])
             else:
                 eng.iteration(use_graph=self.use_graph)      # one call (or one hipGraph replay)
+                if snap:
+                    self._snapshot_async(st.ring[k], n_rendered)
+                    st.snap_stream = self._snap_stream
             self.rasterisations_done += 1
             self.iterations_done += 1
             rec_now = eng.rec                        # (densification may re-allocate the engine's buffers below)
@@ -747,6 +761,9 @@ class SimpleGaussian:
         self.train_log = st.log
         if self.fused and self.engine is not None:
             self.engine.watch_overflow()          # dropped pairs must not go unnoticed -- without stopping the host here
+            if getattr(st, "snap_stream", None) is not None:
+                with torch.cuda.stream(st.snap_stream):
+                    self._snap_aux.watch_overflow()
         camera_only, move_mask = st.camera_only, kw.get("move_mask")
         if move_mask is not None:
             move_mask = move_mask.to(dev).bool()
@@ -825,6 +842,8 @@ class SimpleGaussian:
         if getattr(st, "pin", None) is not None and st.frames:
             k = len(st.frames)
             st.copy_stream.wait_stream(torch.cuda.current_stream())
+            if getattr(st, "snap_stream", None) is not None:
+                st.copy_stream.wait_stream(st.snap_stream)           # (the shadow engine's last images)
             with torch.cuda.stream(st.copy_stream):
                 st.pin[:k].copy_(st.ring[:k], non_blocking=True)
                 self.engine.snapshot_ring_copied()                   # (an event: the ring is free again after it)
@@ -845,6 +864,35 @@ class SimpleGaussian:
             st.frames, st.frames_depth, st.frames_center, st.pin = [], [], [], None
             st.pin_hold()                            # (the stepper and its closure are a cycle: do not wait for the GC)
         return out
+
+    def _snapshot_async(self, out, n):
+        """The snapshot images of the forward the engine has just run (``n`` rows) into ``out`` ((3, H, W, 3) uint8 on the
+        device), composed by a shadow engine on a side stream from a copy of that forward's state; returns at once.
+        ``self._snap_stream`` is that stream."""
+        import ctypes
+        from .fused import FitEngine
+        from . import _lib as L
+        eng, dev = self.engine, self.device
+        cur = torch.cuda.current_stream()
+        aux = getattr(self, "_snap_aux", None)
+        if aux is None or aux.cap < n or aux.K_cap < eng.K_cap:
+            aux = self._snap_aux = FitEngine(self.W, self.H, max(eng.cap, n), dev, K_cap=eng.K_cap, bg=self.bg)
+            self._snap_stream = torch.cuda.Stream(device=dev)
+            self._snap_done = None
+        side = self._snap_stream
+        if self._snap_done is not None:
+            cur.wait_event(self._snap_done)          # the previous snapshot has read the shadow's buffers (ten iterations ago)
+        aux.set_count(n)
+        aux.hp.bg, aux.hp.nearest, aux.hp.extent = eng.hp.bg, eng.hp.nearest, eng.hp.extent
+        L.check(eng.lib.gfl_fit_snapshot_stage(ctypes.byref(eng.state()), ctypes.byref(aux.state()), L.stream()),
+                "snapshot stage")
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            aux.snapshot(out=out)
+            self._snap_done = torch.cuda.Event()
+            self._snap_done.record(side)
 
     def _render_parts_fused(self):
         """(2, 3, H, W, 3) uint8 on the device: [still splats, moving splats] x [rgb, depth colour, centre blobs] of the

@@ -312,6 +312,11 @@ int gfl_render_bwd(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float
  * of the same lists, the per-splat values are derived while the records are staged), each clamped, scaled by 255 and
  * truncated like render2img (render.py:158-166).  out_u8 [3 images][H][W][3] uint8; lut [256][3] = the turbo table.
  * Call it AFTER the iteration's backward (it reuses the forward's workspace). */
+/* Copies from one engine to another (same image size, same row count N, capacities at least as large) everything
+ * gfl_fit_snapshot reads of a forward: records, sorted ids, tile ranges, the rgb planes of the render and the forward's
+ * tile queues -- one launch, ~9 MB at 480p / 60 000 splats.  The snapshot of iteration i can then be taken from the copy,
+ * on another stream, BESIDE iteration i + 1 (gflow_amd/trainer.py: _snapshot_async) instead of between the two. */
+int gfl_fit_snapshot_stage(const gfl_fit_state* src, const gfl_fit_state* dst, gfl_stream_t stream);
 size_t gfl_fit_snapshot_workspace_bytes(int N, int W, int H);
 int gfl_fit_snapshot(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float* lut, uint8_t* out_u8, void* workspace,
                      size_t workspace_bytes, gfl_stream_t stream);

@@ -276,7 +276,8 @@ def test_move_seg_covers_the_moving_splats():
     assert er.shape == seg.shape and not bool(((er > 0) & (seg == 0)).any()) and 0 < (er > 0).sum() < (seg > 0).sum()
 
 
-def test_snapshots_returned_by_train_are_the_renders_of_their_iterations():
+@pytest.mark.parametrize("async_snapshots", [True, False])
+def test_snapshots_returned_by_train_are_the_renders_of_their_iterations(async_snapshots):
     """The snapshot images stay on the device until the end of ``train()`` (a ring in HBM) and reach the host in one copy:
     the list ``train()`` returns must hold, slot by slot, what was rendered at iterations 0, 8, 16 -- checked on the last
     one against an identically seeded fit stopped at iteration 16 and rendered there (every slot must also differ from
@@ -294,6 +295,9 @@ def test_snapshots_returned_by_train_are_the_renders_of_their_iterations():
         return tr
 
     a = make()
+    # True: composed on a side stream from a copy of the forward's state (gfl_fit_snapshot_stage); False: behind the
+    # iteration, in its graph launch (what several fits sharing a device use)
+    a.async_snapshots = async_snapshots
     frames, centers, depths = a.train(iterations=17, snapshot_interval=8, **kw)[:3]
     assert len(frames) == len(centers) == len(depths) == 3
     for lst in (frames, centers, depths):
