@@ -566,3 +566,26 @@ def test_iterations_that_do_not_move_the_camera_take_the_short_cut_with_the_same
     ab0 = fast.depth_ab.clone()
     fast.iteration()
     assert torch.equal(fast.depth_ab, ab0) and int(fast.step.item()) == 5
+
+
+def test_snapshot_from_a_staged_copy_equals_the_snapshot_in_place(setup):
+    """gfl_fit_snapshot_stage: what a forward left behind (records, ids, tile ranges, render, tile queues) copied into a second
+    engine; gfl_fit_snapshot on the copy -- after the first engine has moved on by two iterations -- gives the images the
+    first engine's own snapshot gave, bit for bit.  Mismatched engines are refused."""
+    import ctypes
+    from gflow_amd import _lib as L
+    s, raw, img, dep = setup
+    a = _engine(raw, s, img, dep, pose=POSE, lr=2e-3, lr_camera=0.0, lambda_rgb=1.0, lambda_depth=0.1)
+    b = _engine(raw, s, img, dep, pose=POSE, lr=2e-3, lr_camera=0.0, lambda_rgb=1.0, lambda_depth=0.1)
+    for _ in range(2):
+        a.iteration()                                    # (the second iteration runs on queues built by the first)
+    want = a.snapshot().clone()
+    b.set_count(a.N)
+    L.check(a.lib.gfl_fit_snapshot_stage(ctypes.byref(a.state()), ctypes.byref(b.state()), L.stream()), "stage")
+    a.iteration(); a.iteration()                          # the source moves on: rows, records, lists and queues change
+    got = b.snapshot()
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert not torch.equal(a.snapshot(), want)
+    b.set_count(a.N - 1)
+    assert a.lib.gfl_fit_snapshot_stage(ctypes.byref(a.state()), ctypes.byref(b.state()), L.stream()) != 0
