@@ -2182,15 +2182,18 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
         bin_colscan_kernel<<<(T + CS_TILES - 1) / CS_TILES, 256, 0, s>>>(w.hist, nblk, T, w.tile_counts, w.pool_counter,
                                                                          w.sched.counters, 2 * w.sched.nq);
     }
+    // (the order of the tile sort is built by one workgroup with up to eight tiles per lane in registers: beyond 4096 tiles
+    //  -- 1080p has 8160 -- the sort takes the tiles in their own order)
+    const bool ordered = sort_heavy_first() && T <= 8 * BIN_BLOCK;
     {
         StageScope p(ST_SCATTER, s);
-        fused_scatter_kernel<<<nblk + 2 + (sort_heavy_first() ? 1 : 0), BIN_BLOCK, lds, s>>>(st->rec, st->N, gx, gy, w.hist, w.tile_counts,
+        fused_scatter_kernel<<<nblk + 2 + (ordered ? 1 : 0), BIN_BLOCK, lds, s>>>(st->rec, st->N, gx, gy, w.hist, w.tile_counts,
                                                               st->tile_offsets, st->K_cap, w.keys, st->overflow, w.sched, w.sched_fwd,
-                                                              w.sched_valid, sort_heavy_first() ? w.sort_order : nullptr);
+                                                              w.sched_valid, ordered ? w.sort_order : nullptr);
     }
     {
         StageScope p(ST_TILE_SORT, s);
-        if (sort_heavy_first())
+        if (ordered)
             rc = gfl_tile_sort_ordered((const int32_t*)w.sort_order, st->W, st->H, st->K_cap, w.keys, st->ids, st->tile_range,
                                        st->rec, w.slot_inv, w.slot_pool, stream);
         else

@@ -180,3 +180,40 @@ def test_config5_720p_200k_with_densification():
     first, last = tr.train_log[0]["total"], tr.train_log[-1]["total"]
     assert last < 0.7 * first, tr.train_log
     assert float(tr.psnr()) > 22.0
+
+
+def test_more_than_4096_tiles_1080p():
+    """Beyond the sizes BASELINE names: 1080 x 1920 has 8 160 tiles -- more than the XCD-local scheduler plans (4 096: the
+    batched LPT of rounds 1-2 takes over) and more than the tile sort's heavy-first order is built for (the sort takes
+    the tiles in their own order).  The fused render against the operator path, and three iterations that reduce the loss
+    with finite parameters (the second and third run on queues built from measured work)."""
+    from gflow_amd import synthetic as S
+    import gflow_amd.render as R
+    H2, W2, N2 = 1080, 1920, 40000
+    frame = S.make_frame(H2, W2, seed=2)
+    raw = S.init_splats(frame, N2, seed=2, grown=True)
+    s = dict(W=W2, H=H2, intr=raw["intr"])
+    eng = _engine({k: raw[k] for k in NAMES}, s, frame["image"], frame["depth"], lr=2e-3, lr_camera=0.0, total_iters=10,
+                  lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0)
+    assert eng.T == 68 * 120
+    eng.forward()
+    eng.check_overflow()
+    act = [a.to(DEV) for a in FO.activate(raw)]
+    og = R.render_multiple([*act, raw["intr"].to(DEV), raw["extr"].to(DEV), 0.0, W2, H2], ["rgb", "depth_map"])
+    close_frac(eng.render, torch.cat([og["rgb"], og["depth_map"]]), 2e-5, 2e-6, bad_frac=1e-4, hard=2e-2,
+               what="1080p fused vs operator path")
+    # (logit of a saturated colour is +inf -- the reference's eps = 1e-15 does not survive float32, trainer.py:229 -- and
+    #  stays +inf: sigmoid gives 1, its derivative 0)
+    finite_in = torch.isfinite(eng.params[:N2]).clone()
+    assert bool(finite_in[:, :11].all())
+    losses = []
+    for _ in range(3):
+        eng.iteration()
+        l_rgb, l_depth = eng.loss_terms()
+        losses.append(float(l_rgb) + 0.1 * float(l_depth))
+    eng.check_overflow()
+    assert losses[2] < losses[0]
+    assert torch.equal(torch.isfinite(eng.params[:N2]), finite_in) and bool(torch.isfinite(eng.adam_m[:N2]).all())
+    # every pair of every tile is in the sorted lists exactly once: the ranges tile the id array
+    tr = eng.tile_range.cpu()
+    assert int((tr[:, 1] - tr[:, 0]).sum()) == eng.K
