@@ -589,3 +589,46 @@ def test_snapshot_from_a_staged_copy_equals_the_snapshot_in_place(setup):
     assert not torch.equal(a.snapshot(), want)
     b.set_count(a.N - 1)
     assert a.lib.gfl_fit_snapshot_stage(ctypes.byref(a.state()), ctypes.byref(b.state()), L.stream()) != 0
+
+
+def test_degenerate_scenes_no_splat_one_splat_everything_culled(setup):
+    """The ends of the range: an engine with NO rows, with ONE row, and with every splat behind the camera (nothing is
+    binned: K = 0).  The render is the background, the iteration runs, the loss is that of the background image, and rows
+    that render nothing keep their values except for what the variance regulariser does to their scales."""
+    from gflow_amd.fused import FitEngine
+    s, raw, img, dep = setup
+    H, W = s["H"], s["W"]
+    mse_bg = float(((0.2 - img) ** 2).mean())
+    # ---- no rows at all
+    eng = FitEngine(W, H, capacity=1024, device=DEV, bg=0.2)
+    eng.intr.copy_(s["intr"].to(DEV))
+    eng.set_targets(img, dep)
+    eng.hp.lambda_rgb, eng.hp.lambda_depth, eng.hp.lr = 1.0, 0.1, 1e-3
+    eng.reset_optimizer()
+    assert eng.N == 0
+    for _ in range(2):
+        eng.iteration()
+    eng.check_overflow()
+    assert eng.K == 0 and int(eng.step.item()) == 2
+    assert torch.allclose(eng.render, torch.full((4, H, W), 0.2, device=DEV))      # (the depth plane is blended over bg as well)
+    assert bool(torch.isfinite(eng.d_render).all()) and bool(torch.isfinite(eng.sums).all())
+    assert abs(float(eng.sums[0]) / (H * W) - mse_bg) < 1e-5 * mse_bg + 1e-7        # sums[0]: the per-pixel mse summed
+    # ---- one row
+    one = {k: v[:1].clone() for k, v in raw.items()}
+    e1 = _engine(one, s, img, dep, pose=POSE, lr=1e-3, lambda_rgb=1.0, lambda_depth=0.1, lambda_var=1.0)
+    p0 = e1.params[:1, :14].clone()
+    e1.iteration(); e1.iteration()
+    e1.check_overflow()
+    assert bool(torch.isfinite(e1.params[:1]).all()) and not torch.equal(e1.params[:1, :14], p0)
+    # ---- every splat behind the camera
+    behind = {k: v.clone() for k, v in raw.items()}
+    behind["xyz"][:, 2] = -behind["xyz"][:, 2].abs() - 1.0
+    e2 = _engine(behind, s, img, dep, lr=1e-3, lambda_rgb=1.0, lambda_depth=0.1, lambda_var=0.0, bg=0.2)
+    n = behind["xyz"].shape[0]
+    q0 = e2.params[:n, :14].clone()
+    e2.iteration(); e2.iteration()
+    e2.check_overflow()
+    assert e2.K == 0
+    assert torch.allclose(e2.render[:3], torch.full((3, H, W), 0.2, device=DEV))
+    assert torch.equal(e2.params[:n, :14], q0)                   # zero gradients, zero moments: Adam does not move a row
+    assert float(e2.depth[:n].abs().max()) == 0.0                # culled: depth 0 (render.py:29)
