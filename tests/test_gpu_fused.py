@@ -632,3 +632,34 @@ def test_degenerate_scenes_no_splat_one_splat_everything_culled(setup):
     assert torch.allclose(e2.render[:3], torch.full((3, H, W), 0.2, device=DEV))
     assert torch.equal(e2.params[:n, :14], q0)                   # zero gradients, zero moments: Adam does not move a row
     assert float(e2.depth[:n].abs().max()) == 0.0                # culled: depth 0 (render.py:29)
+
+
+def test_more_pairs_than_the_lists_hold_is_reported_not_silent(setup):
+    """K_cap smaller than the number of (splat, tile) pairs: the scatter drops the pairs beyond it and raises the sticky
+    overflow flag; ``check_overflow`` / ``watch_overflow`` + ``poll_overflow`` turn it into an error, nothing is written
+    outside the lists (an iteration on the truncated lists still runs and stays finite), and an engine with room
+    renders the same scene without complaint."""
+    from gflow_amd.fused import FitEngine
+    s, raw, img, dep = setup
+    big = _engine(raw, s, img, dep, pose=POSE, lambda_rgb=1.0)
+    big.forward()
+    big.check_overflow()
+    K = big.K
+    assert K > 4000
+    small = FitEngine(s["W"], s["H"], capacity=2 * raw["xyz"].shape[0], device=DEV, K_cap=K // 3)
+    small.set_splats({k: v.to(DEV) for k, v in raw.items()})
+    small.intr.copy_(s["intr"].to(DEV))
+    small.pose.copy_(POSE.to(DEV))
+    small.set_targets(img, None)
+    small.hp.lambda_rgb, small.hp.lr = 1.0, 1e-3
+    small.reset_optimizer()
+    small.iteration()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(small.render).all()) and bool(torch.isfinite(small.params[:small.N]).all())
+    with pytest.raises(RuntimeError, match="K_cap"):
+        small.check_overflow()
+    small.iteration()
+    small.watch_overflow()                       # (non-blocking: the flag travels to pinned memory behind the queue)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="K_cap"):
+        small.poll_overflow()
