@@ -312,3 +312,30 @@ def test_snapshots_returned_by_train_are_the_renders_of_their_iterations(async_s
     diff = np.abs(frames[2].astype(int) - want.astype(int))
     # (two fits with the same seed differ by the order of the backward's LDS atomics: a grey level here and there)
     assert diff.mean() < 0.2 and (diff <= 2).mean() > 0.995, (diff.mean(), diff.max())
+
+
+def test_still_and_moving_part_images_equal_the_operator_path():
+    """The four images train() renders at its end (trainer.py:632-677: rgb and centre blobs of the still and of the moving
+    splats) come from a second fused engine in which the splats outside the set are hidden; against renders of the gathered
+    subsets through the operator path."""
+    from gflow_amd import synthetic as S
+    from gflow_amd.trainer import SimpleGaussian
+    import gflow_amd.render as R
+    f = S.make_clip(1, 96, 128, seed=8)[0]
+    tr = SimpleGaussian(f["image"], f["depth"], num_points=1500, device=DEV, seed=0)
+    tr.load_camera(focal=f["focal"], pp=f["pp"])
+    tr.init_gaussians_from_image(f["image"], f["depth"], num_points=1500)
+    out = tr.train(iterations=12, lr=4e-3, lambda_rgb=1.0, lambda_depth=1e-2, lambda_var=1.0, densify_interval=0,
+                   move_mask=f["move_mask"], snapshot_interval=4)
+    still_rgb, still_center, move_rgb, move_center = out[3:7]
+    n_still, n = int(tr.still_mask.sum()), tr.current_pts_num()
+    assert 0 < n_still < n
+    with torch.no_grad():
+        for sel, rgb_img, centre_img in ((tr.still_mask, still_rgb, still_center), (~tr.still_mask, move_rgb, move_center)):
+            o = R.render_multiple(tr._input_group(sel=sel, detach=True), ["rgb", "center"])
+            for got, want in ((rgb_img, R.render2img(o["rgb"])), (centre_img, R.render2img(o["center"]))):
+                assert got.shape == (96, 128, 3) and got.dtype == np.uint8
+                d = np.abs(np.asarray(got).astype(int) - want.astype(int))
+                assert (d > 1).mean() < 4e-3, (d > 1).mean()
+    # the two sets are different pictures
+    assert np.abs(np.asarray(still_rgb).astype(int) - np.asarray(move_rgb).astype(int)).mean() > 1.0
