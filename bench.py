@@ -7,11 +7,17 @@ Two measurements per rank, both with the inputs resident in HBM and bracketed by
 device synchronisation:
   * the step: K optimisation iterations of the first-frame fit (rasterise forward, photometric + SSIM +
     depth + var loss, rasterise backward, Adam) after W warm-up iterations -> ms_per_step,
-    iterations_per_s and the roofline block of the dominant kernel;
-  * the metric: an actual fit_video fit of one synthetic clip per rank (--clip-frames, default 8; README
-    iteration counts 500 / 150 / 300, image-driven initialisation, densification, camera-only and joint
-    stages, the reference's snapshots every 10th iteration) -> value = frames of all ranks / slowest
-    rank's wall time.  Clips are independent: no data-path collective, "weak" scaling,
+    iterations_per_s and the roofline block of the dominant kernel.  The timed iterations are a PINNED
+    window of that fit -- iterations [STEP_I0, STEP_I0 + STEP_WINDOW) = [12, 32), whatever --steps and
+    --warmup are: the fit runs its first 12 iterations, the engine's state is saved, the warm-up steps
+    run and the state is put back; K > 20 timed steps replay the same 20 iterations (the state is put
+    back after every 20: three elementwise copies of 3.8 MB each per 20 iterations, inside the timed
+    region).  The scene shrinks while it is fitted (K = 250 k pairs at iteration 0, 190 k at 220), so a
+    window that moved with --steps / --warmup timed another workload for every pair of flags;
+  * the metric: an actual fit_video fit of one synthetic clip per rank (--clip-frames, default 60 =
+    BASELINE configs[2]; README iteration counts 500 / 150 / 300, image-driven initialisation,
+    densification, camera-only and joint stages, the reference's snapshots every 10th iteration) ->
+    value = frames of all ranks / slowest rank's wall time.  Clips are independent: no data-path collective, "weak" scaling,
     one all-reduce(SUM) of a small metrics vector and one all-reduce(MAX) of the wall time.
 Rank 0 prints ONE JSON line.
 """
@@ -28,6 +34,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 H, W, N_SPLATS = 480, 854, 60000
+STEP_I0, STEP_WINDOW = 12, 20     # the timed step = iterations [12, 32) of the first-frame fit (see the docstring)
 ITERS_PER_FRAME = (500 + 59 * (150 + 300)) / 60.0
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -56,35 +63,26 @@ def profile_read(lib):
     return {STAGES[i]: tot[i] / cnt[i] for i in range(len(STAGES)) if cnt[i]}
 
 
-def pmc_traffic(kind):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
-    same command (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950); counters cannot be read from inside the process,
-    so the number comes from profiles/pmc_current.json (written by tools/summarise_profile.py)."""
+def pmc_block(kind):
+    """What the committed rocprofv3 counter passes of this same command say about the dominant kernel
+    (profiles/pmc_current.json, written by tools/profile_round.sh -> tools/summarise_profile.py; counters cannot be read
+    from inside the process): ``traffic`` = HBM bytes per launch (FETCH_SIZE and WRITE_SIZE in separate passes,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), and ``secondary`` = the issue bound SURVEY.md 8d
+    asks for beside the HBM bound: VALU wave-instructions per launch, the share of the launch the VALUs were busy
+    (SQ_ACTIVE_INST_VALU quad-cycles x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)) and the lane efficiency of a
+    (splat, 8x8 block) unit (tools/lane_efficiency.py on the same scene)."""
     path = os.path.join(ROOT, "profiles", "pmc_current.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        return {"traffic": float(d["hbm_bytes_per_launch"][kind]),
-                "traffic_source": "profiles/pmc_current.json (" + d.get("tag", "?") + ")"}
+        src = "profiles/pmc_current.json (" + d.get("tag", "?") + ")"
+        out = {"traffic": float(d["hbm_bytes_per_launch"][kind]), "traffic_source": src}
+        v = d.get("valu", {}).get(kind)
+        if v:
+            out["secondary"] = dict(v, bound="valu", source=src)
+        return out
     except (OSError, KeyError, ValueError):
         return {"traffic": None}
-
-
-def clip_fit(dev, rank, frames_n, snapshot_interval):
-    """The metric itself: an actual fit of one synthetic clip through gflow_amd.fit_video.fit_clip
-    (image-driven initialisation, densification, camera-only and joint stages, snapshots, all host
-    work included; clip synthesis and a two-frame warm-up fit excluded).  Returns the clip's
-    metrics dict and the wall seconds of the timed fit."""
-    from gflow_amd import synthetic as S
-    from gflow_amd import fit_video as FV
-    # the clip is resident in HBM before the clock starts (bench contract: inputs already in HBM; fit_clip itself
-    # uploads a host clip as its first act -- 10 MB per frame over PCIe: ~1 ms, noted in DESIGN.md section 5)
-    frames = FV.upload_clip(S.make_clip(frames_n, H, W, seed=rank), dev)
-    cfg = dict(num_points=N_SPLATS)
-    FV.fit_clip(frames[:2], dev, cfg, seed=rank, snapshot_interval=snapshot_interval)      # warm-up
-    torch.cuda.synchronize()
-    return frames, cfg
 
 
 def coresident_fits(dev, frames_n, snapshot_interval, levels=(1, 2, 3)):
@@ -94,7 +92,7 @@ def coresident_fits(dev, frames_n, snapshot_interval, levels=(1, 2, 3)):
     GPUs; one fit alone leaves the chip partly idle (dependent launches, latency-bound kernels, blend tails)."""
     from gflow_amd import synthetic as S
     from gflow_amd import fit_video as FV
-    clips = [FV.upload_clip(S.make_clip(frames_n, H, W, seed=100 + i), dev) for i in range(max(levels))]
+    clips = [FV.upload_clip(S.make_clip(frames_n, H, W, seed=100 + i, device=dev), dev) for i in range(max(levels))]
     cfg = dict(num_points=N_SPLATS)
     FV.fit_clips_concurrent([c[:2] for c in clips], dev, cfg, snapshot_interval=snapshot_interval)      # warm-up
     torch.cuda.synchronize()
@@ -106,7 +104,7 @@ def coresident_fits(dev, frames_n, snapshot_interval, levels=(1, 2, 3)):
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         frames = sum(r["frames"] for r in res)
-        out[str(c)] = {"clips": c, "wall_s": wall, "frames_per_s": frames / wall,
+        out[str(c)] = {"clips": c, "frames_per_clip": frames_n, "wall_s": wall, "frames_per_s": frames / wall,
                        "iterations_per_s": sum(r["iterations"] for r in res) / wall,
                        "psnr_mean_db": sum(r["psnr_sum"] for r in res) / frames}
     base = out[str(levels[0])]["frames_per_s"]
@@ -142,7 +140,9 @@ def cpu_baseline():
                      "phase_ms": {k: v / n * 1000.0 for k, v in timers.items()}}
     dt = out["c2"]["ms_per_step"] / 1000.0
     return {"value": (1.0 / dt) / ITERS_PER_FRAME, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{out['c2']['iterations_timed']} fit iterations (after 3 warm-ups) of the same 480x854 / 60k-splat "
+            "host_cores": os.cpu_count(),
+            "sample": f"{cores} of {os.cpu_count()} host threads (eager PyTorch gets slower beyond 16 on this workload); "
+                      f"{out['c2']['iterations_timed']} fit iterations (after 3 warm-ups) of the same 480x854 / 60k-splat "
                       f"frame with the eager-PyTorch CPU oracle (own restatement; the reference has no CPU rasteriser), "
                       f"{dt * 1000:.0f} ms/iteration; frames/s = iterations/s / {ITERS_PER_FRAME:.2f} iterations per frame; "
                       f"C1-size (10k splats) sample alongside",
@@ -158,7 +158,7 @@ def reduce_and_report(local, dist, red_dev, rank, world, args, backend, size=Non
     clip = local["clip"]
     vec = [local["elapsed"], float(local["steps"]), local["psnr_step"], float(local["K"])]
     if clip is not None:
-        vec += [clip[k] for k in ("frames", "iterations", "rasterisations", "psnr_sum", "splats_final")]
+        vec += [clip[k] for k in ("frames", "iterations", "rasterisations", "psnr_sum", "splats_final")] + [clip.get("clips", 1)]
     stats = torch.tensor(vec, dtype=torch.float64, device=red_dev)
     tmax = torch.tensor([local["elapsed"], local["clip_wall"]], dtype=torch.float64, device=red_dev)
     if dist is not None:
@@ -181,7 +181,7 @@ def reduce_and_report(local, dist, red_dev, rank, world, args, backend, size=Non
         dom = max(roof, key=lambda k: roof[k]["ms"])
         roofline = {"bound": "hbm", "kernel": dom, "achieved": roof[dom]["GBps"], "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": roof[dom]["GBps"] / HBM_PEAK_GBPS}
-        roofline.update(pmc_traffic(dom))
+        roofline.update(pmc_block(dom))
     derived = it_per_s / ITERS_PER_FRAME
     workload = ("configs[1]" if (Hh, Ww, Nn) == (480, 854, 60000) else "other") + f": {Hh}x{Ww}, {Nn} splats"
     if clip is not None:
@@ -191,13 +191,15 @@ def reduce_and_report(local, dist, red_dev, rank, world, args, backend, size=Non
         clip_out = {"frames_per_rank": args.clip_frames, "wall_s": cw, "iterations": iters_all,
                     "iterations_per_s": iters_all / cw, "rasterisations_per_s": float(stats[6].item()) / cw,
                     "psnr_mean_db": float(stats[7].item()) / frames_all,
-                    "splats_final_mean": float(stats[8].item()) / world,
+                    "splats_final_mean": float(stats[8].item()) / max(float(stats[9].item()), 1.0),
                     "snapshot_interval": args.snapshot_interval,
-                    "frames_per_s_extrapolated_to_a_60_frame_clip": (iters_all / cw) / ITERS_PER_FRAME}
-        workload += (f"; value = measured fit_video fit of one {args.clip_frames}-frame synthetic clip per GPU "
-                     f"(iterations 500 first / 150 camera-only + 300 joint per later frame, densification on, "
-                     f"snapshots every {args.snapshot_interval} iterations); ms_per_step = one first-frame fit "
-                     f"iteration (grown footprint, lambda rgb/depth/var = 1/0.1/10)")
+                    "clips_per_rank": int(round(float(stats[9].item()) / world)),
+                    "rank_wall_s": local.get("rank_walls")}
+        workload += (f"; value = measured fit_video fit of one {args.clip_frames}-frame rigid synthetic clip per GPU "
+                     f"(configs[2]: iterations 500 first / 150 camera-only + 300 joint per later frame, densification "
+                     f"on, snapshots every {args.snapshot_interval} iterations); ms_per_step = iterations "
+                     f"[{STEP_I0}, {STEP_I0 + STEP_WINDOW}) of a first-frame fit on the grown scene (lambda rgb/depth/var = "
+                     f"1/0.1/10), the same window for every --steps / --warmup")
     else:
         value, clip_out = derived, None
         workload += "; value DERIVED from the first-frame fit iteration (no clip fit in this run)"
@@ -216,6 +218,8 @@ def reduce_and_report(local, dist, red_dev, rank, world, args, backend, size=Non
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": workload, "iterations_per_frame": ITERS_PER_FRAME, "splat_tile_pairs_K": K_mean,
+                   "step_window": {"iterations": [STEP_I0, STEP_I0 + STEP_WINDOW], "K_first": local.get("K_first"),
+                                   "K_last": local.get("K_last"), "K_mean": local["K"]},
                    "parallelism": f"clip-sharded x{world}", "collective_backend": backend},
         "value_kind": "measured clip fit" if clip is not None else "derived from the step",
         "clip_fit": clip_out,
@@ -259,9 +263,14 @@ def main():
                          "the default and the metric are configs[1]")
     ap.add_argument("--no-clip", action="store_true",
                     help="skip the clip fit; value is then DERIVED from the step (iterations/s / 450.83) and says so")
-    ap.add_argument("--clip-frames", type=int, default=8)
+    ap.add_argument("--clip-frames", type=int, default=60,
+                    help="frames of the clip whose fit is the metric (BASELINE configs[2]: ~60)")
+    ap.add_argument("--clips-per-gpu", type=int, default=1,
+                    help="clips every rank fits AT THE SAME TIME on its GPU (fit_video.fit_clips_concurrent; throughput "
+                         "mode of a node with more clips than GPUs).  The metric is quoted on 1")
     ap.add_argument("--no-coresident", action="store_true",
                     help="skip the secondary table of 1 / 2 / 3 clip fits sharing this GPU (clips_per_gpu)")
+    ap.add_argument("--coresident-frames", type=int, default=8, help="frames per clip of that secondary table")
     ap.add_argument("--snapshot-interval", type=int, default=10,
                     help="snapshots of the clip fit (the reference keeps three images every 10th iteration, "
                          "trainer.py:573-582); 0 = none")
@@ -306,16 +315,34 @@ def main():
     lib = _lib.load()
 
     # -------------------------------------------------------------- the metric
-    # (first: its ~2 s of GPU work also bring the device to its working clocks before the short step timing below)
+    # (first: its seconds of GPU work also bring the device to its working clocks before the short step timing below)
     clip = None
     clip_wall = 0.0
+    rank_walls = None
     if not args.no_clip:
-        frames, cfg = clip_fit(dev, rank, args.clip_frames, args.snapshot_interval)
+        c = max(1, args.clips_per_gpu)
+        clips = [FV.upload_clip(S.make_clip(args.clip_frames, H, W, seed=rank * c + j, device=dev), dev) for j in range(c)]
+        cfg = dict(num_points=N_SPLATS)
+        FV.fit_clip(clips[0][:2], dev, cfg, seed=rank, snapshot_interval=args.snapshot_interval)      # warm-up
         barrier()
         t0 = time.perf_counter()
-        clip = FV.fit_clip(frames, dev, cfg, seed=rank, snapshot_interval=args.snapshot_interval)
+        if c == 1:
+            clip = FV.fit_clip(clips[0], dev, cfg, seed=rank, snapshot_interval=args.snapshot_interval)
+        else:
+            res = FV.fit_clips_concurrent(clips, dev, cfg, seeds=[rank * c + j for j in range(c)],
+                                          snapshot_interval=args.snapshot_interval)
+            clip = {k: sum(r[k] for r in res) for k in res[0]}
+        torch.cuda.synchronize()
+        own_wall = time.perf_counter() - t0
         barrier()
         clip_wall = time.perf_counter() - t0
+        del clips
+        if dist is not None:
+            walls = [None] * world
+            dist.all_gather_object(walls, own_wall)
+            rank_walls = [float(w) for w in walls]
+        else:
+            rank_walls = [own_wall]
 
     # ---------------------------------------------------------------- the step
     # (on a stream of its own, like the clip fit: the default stream is HIP's legacy NULL stream, which synchronises with
@@ -333,8 +360,23 @@ def main():
     kw = dict(lr=4e-3, lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0, move_mask=frame["move_mask"],
               densify_interval=0, snapshot_interval=0)
     stepper = tr.make_stepper(iterations=500, **kw)
-    stepper.run(args.warmup)
-    stepper.run(7)        # (4 + 2 + 1 more untimed steps: the replayed graphs hold one, two or four iterations)
+    eng = tr.engine
+    # the pinned window: iterations [STEP_I0, STEP_I0 + STEP_WINDOW) of this fit, whatever --steps / --warmup are
+    stepper.run(STEP_I0)
+    saved = eng.save_state()
+
+    def run_window(n):
+        """n timed or untimed steps: the window's iterations, over and over"""
+        done = 0
+        while done < n:
+            k = min(STEP_WINDOW, n - done)
+            if done:
+                eng.restore_state(saved)
+            stepper.run(k)
+            done += k
+
+    run_window(max(args.warmup, 7))   # (at least 4 + 2 + 1 untimed steps: the replayed graphs hold one, two or four iterations)
+    eng.restore_state(saved)
     # timed region: exactly K steps, no instrumentation (an event pair between two kernels
     # opens a 5-10 us bubble on the stream, measured with rocprofv3)
     import gc
@@ -342,33 +384,43 @@ def main():
     gc.disable()          # (a generation-2 collection of the interpreter inside a 4 ms timed region is not the kernels' time)
     barrier()
     t0 = time.perf_counter()
-    stepper.run(args.steps)
+    run_window(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
     # the same K steps again with HIP events recorded by the library on the launch stream
-    # around every stage: per-kernel durations for the roofline block
+    # around every stage: per-kernel durations for the roofline block; and the window's pair counts K
     kern_all = {}
+    k_dev = torch.zeros(STEP_WINDOW, dtype=torch.int32, device=dev)
     if not args.no_stage_pass:
         from gflow_amd.fused import set_profile
         set_profile((1 << len(STAGES)) - 1)
-        for _ in range(args.steps):
+        for i in range(args.steps):
+            if i % STEP_WINDOW == 0:
+                eng.restore_state(saved)
             stepper()
+            k_dev[i % STEP_WINDOW:i % STEP_WINDOW + 1].copy_(eng.tile_offsets[eng.T:eng.T + 1])
         torch.cuda.synchronize()
         set_profile(0)
         kern_all = profile_read(lib)
+    else:
+        eng.restore_state(saved)
+        for i in range(min(args.steps, STEP_WINDOW)):
+            stepper()
+            k_dev[i:i + 1].copy_(eng.tile_offsets[eng.T:eng.T + 1])
     kern = {k: kern_all[k] for k in ("blend_fwd", "loss", "blend_bwd") if k in kern_all}
-    K = tr.engine.K if tr.engine is not None else int(tr.last_K)
+    ks = k_dev[:min(args.steps, STEP_WINDOW)].cpu().tolist()
+    K = sum(ks) / len(ks)                  # mean over the window's iterations: what the kernels' average durations belong to
     psnr_step = float(tr.psnr_of(stepper.last_render))
-    del stepper, tr
+    del stepper, tr, eng, saved
 
-    local = {"elapsed": elapsed, "steps": args.steps, "psnr_step": psnr_step, "K": K, "clip": clip,
-             "clip_wall": clip_wall, "kernels_ms": kern, "stage_ms": kern_all}
+    local = {"elapsed": elapsed, "steps": args.steps, "psnr_step": psnr_step, "K": K, "K_first": ks[0], "K_last": ks[-1],
+             "clip": clip, "clip_wall": clip_wall, "rank_walls": rank_walls, "kernels_ms": kern, "stage_ms": kern_all}
     out = reduce_and_report(local, dist, red_dev, rank, world, args, backend)
     if out is not None:
         if world == 1 and not args.no_clip and not args.no_coresident:
             try:
-                out["clips_per_gpu"] = coresident_fits(dev, args.clip_frames, args.snapshot_interval)
+                out["clips_per_gpu"] = coresident_fits(dev, args.coresident_frames, args.snapshot_interval)
             except Exception as e:                   # a secondary table must not cost the line
                 out["clips_per_gpu"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:

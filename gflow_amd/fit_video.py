@@ -80,14 +80,15 @@ def upload_clip(frames, device):
     return out
 
 
-def fit_clip(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, log=None, load_extr=True):
+def fit_clip(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, log=None, load_extr=True, keep=None):
     """Fit one clip; returns the metrics dict of this clip (PSNR summed over its frames).
     ``load_extr`` (default True, like the reference's flag): frames that carry a camera pose
     (``extr``, read from the sequence's camera files) load it before they are fitted
-    (fit_video.py:115-116, :252-253)."""
+    (fit_video.py:115-116, :252-253).  ``keep``: a dict that receives the trainer (``keep["trainer"]``) and the
+    per-frame PSNR as device scalars (``keep["psnr"]``) -- for tests and tools."""
     dev_ = torch.device(device)
     g = fit_clip_steps(frames, device, cfg=cfg, seed=seed, snapshot_interval=snapshot_interval, fused=fused, log=log,
-                       load_extr=load_extr, chunk=None)
+                       load_extr=load_extr, chunk=None, keep=keep)
 
     def drive():
         try:
@@ -113,7 +114,7 @@ def fit_clip(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, 
 
 
 def fit_clip_steps(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, log=None, load_extr=True, chunk=None,
-                   async_snapshots=True):
+                   async_snapshots=True, keep=None):
     """fit_clip as a generator: yields after every ``chunk`` iterations of a stage (None: never) and returns the metrics
     dict.  The caller owns the stream the work is enqueued on (fit_clips_concurrent gives every clip its own)."""
     from .trainer import SimpleGaussian
@@ -141,6 +142,8 @@ def fit_clip_steps(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=
     # (PSNR stays on the device and is read ONCE at the end of the clip: a float() per frame drained the queue between
     #  two frames; with a log callback the caller asked for the numbers as they come)
     psnr_sum = tr.psnr().double()
+    if keep is not None:
+        keep["trainer"], keep["psnr"] = tr, [psnr_sum]
     if log:
         log(f"frame 0: psnr {float(psnr_sum):.2f} dB, splats {tr.current_pts_num()}")
     for i, fr in enumerate(frames[1:], start=1):
@@ -162,6 +165,8 @@ def fit_clip_steps(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=
                                       mask_count=fr.get("occ_count"), move_mask=fr["move_mask"], **common)
         p = tr.psnr()
         psnr_sum = psnr_sum + p.double()
+        if keep is not None:
+            keep["psnr"].append(p)
         if log:
             log(f"frame {i}: psnr {float(p):.2f} dB, splats {tr.current_pts_num()}")
     if tr.engine is not None:

@@ -108,7 +108,7 @@ def test_config3_shape_eight_frame_clip_at_480p_60k():
     frame, densification at 149 / 299 and 0 / 99, flow / still terms, hipGraph replay between the events."""
     from gflow_amd import synthetic as S
     from gflow_amd.fit_video import fit_clip
-    frames = S.make_clip(8, H, W, seed=0)
+    frames = S.make_clip(8, H, W, seed=0, device=DEV)
     logs = []
     m = fit_clip(frames, DEV, dict(num_points=N), seed=0, log=logs.append)
     assert m["frames"] == 8 and m["iterations"] == 500 + 7 * (150 + 300)
@@ -118,33 +118,44 @@ def test_config3_shape_eight_frame_clip_at_480p_60k():
     assert min(psnrs) > 25.0, logs                                 # no frame falls apart along the clip
 
 
-def test_config3_thirty_two_frame_clip_at_480p_60k():
-    """configs[2] at length: a 32-frame 480p / 60k clip with the README iteration counts (500 + 31 x (150 + 300) =
-    14 450 iterations, 62 densification events, 63 train() calls on ONE engine): the pair lists never overflow, the splat
-    count only grows (there is no pruning, trainer.py:841-876 is dead code) and by what the events' formula says, no
-    frame falls apart late in the clip, every parameter stays free of NaN."""
+def test_config3_sixty_frame_clip_at_480p_60k():
+    """configs[2] at its stated length: a 60-frame 480p / 60k clip with the README iteration counts (500 + 59 x (150 + 300)
+    = 27 050 iterations, 118 densification events, 119 train() calls on ONE engine) on the rigid synthetic clip
+    (gflow_amd.synthetic._Scene: translating camera, one moving object, flow / occlusion / move masks that follow from the
+    geometry).  The pair lists never overflow, the splat count only grows (there is no pruning, trainer.py:841-876 is dead
+    code) and by what the events' formula says, every parameter stays free of NaN, and the camera-only stages FIND the
+    camera (it is not given).  PSNR: the first frame is fitted with free colours, 500 iterations and lr 4e-3, every later
+    one with frozen colours (trainer.py:537-540), 300 iterations and lr 1e-3 -- the reference's recipe -- so frame 1 sits
+    ~1.8 dB under frame 0, and from there the clip loses ~0.05 dB per frame as content fitted under the first recipe leaves
+    the image on one side and content fitted under the second enters on the other (2.5 px per frame); the operator path --
+    the reference's loop over the five msplat operators -- does the same (test_gpu_drift.py).  A frame-boundary regression
+    shows as a step in this curve: asserted frame to frame."""
     from gflow_amd import synthetic as S
     from gflow_amd.fit_video import fit_clip
-    n_frames = 32
-    frames = S.make_clip(n_frames, H, W, seed=0)
-    logs = []
-    m = fit_clip(frames, DEV, dict(num_points=N), seed=0, log=logs.append)       # (check_overflow() after every train())
+    n_frames = 60
+    frames = S.make_clip(n_frames, H, W, seed=0, device=DEV)
+    keep = {}
+    m = fit_clip(frames, DEV, dict(num_points=N), seed=0, keep=keep)       # (check_overflow() at the end of the clip)
     assert m["frames"] == n_frames and m["iterations"] == 500 + (n_frames - 1) * (150 + 300)
-    psnrs = [float(l.split("psnr ")[1].split(" dB")[0]) for l in logs]
-    counts = [int(l.split("splats ")[1]) for l in logs]
-    assert len(psnrs) == n_frames
-    assert all(b > a for a, b in zip(counts, counts[1:])), counts              # every later frame appends (occlusion mask)
-    assert counts[0] > N and counts[-1] == m["splats_final"]
+    psnrs = [float(p) for p in keep["psnr"]]
+    tr = keep["trainer"]
+    assert len(psnrs) == n_frames and abs(sum(psnrs) - m["psnr_sum"]) < 1e-2
+    assert m["splats_final"] == tr.current_pts_num() > N
     # per later frame: int(N * occ_ratio * 1.0) at iteration 0 plus int(N * err_ratio * 1.0) at iteration 99
-    occ = [int(N * float(fr["occ_mask"].float().mean()) * 1.0) for fr in frames[1:]]
-    assert all(c1 - c0 >= o for c0, c1, o in zip(counts, counts[1:], occ)), (counts, occ)
-    # (the synthetic clip is a texture that slides across the image, not a rigid 3-D scene: with the colours frozen after
-    #  the first frame, as the reference freezes them, the fit loses ~0.3 dB per frame early on and levels off around
-    #  25.5 dB by frame 56 -- profiles/r03_fit60_psnr.log; what is asserted is that it degrades slowly, never collapses)
-    assert min(psnrs) > 25.0 and sum(psnrs) / n_frames > 28.0, psnrs
-    assert all(b > a - 1.0 for a, b in zip(psnrs, psnrs[1:])), psnrs            # no frame falls off a cliff
-    print(f"[config 3, {n_frames} frames] psnr min {min(psnrs):.2f} mean {sum(psnrs) / n_frames:.2f} dB, "
-          f"splats {counts[0]} -> {counts[-1]}")
+    occ = sum(int(N * float(fr["occ_mask"].float().mean()) * 1.0) for fr in frames[1:])
+    assert m["splats_final"] - N >= occ and m["splats_final"] < 2 * N, (m["splats_final"], occ)
+    assert psnrs[0] > 32.0 and min(psnrs) > 28.5 and sum(psnrs) / n_frames > 30.0, psnrs
+    assert psnrs[1] > psnrs[0] - 2.5, psnrs                                       # the change of recipe
+    assert all(b > a - 0.6 for a, b in zip(psnrs[1:], psnrs[2:])), psnrs            # no frame falls off a cliff
+    assert psnrs[-1] > psnrs[1] - 3.5, psnrs                                        # ~0.05 dB per frame
+    # the camera was found: it moved by -0.01 per frame along x (rotation can stand in for part of a small translation)
+    t = tr.pose.detach().cpu()[4:7]
+    gt = frames[-1]["extr_gt"][:, 3]
+    assert abs(float(t[0]) - float(gt[0])) < 0.25 * abs(float(gt[0])) and abs(float(t[1])) < 0.1 and abs(float(t[2])) < 0.1, (t, gt)
+    for k, v in tr._attributes.items():
+        # (a raw colour may be +inf: a saturated pixel's logit -- the clamp to 1 - 1e-15 of trainer.py:229-232, :929 is a
+        #  no-op in float32 -- which renders as exactly 1 and has a zero gradient; anything else must be finite)
+        assert not bool(torch.isnan(v).any()) and (k == "rgb" or bool(torch.isfinite(v).all())), k
 
 
 def test_config5_720p_200k_with_densification():
