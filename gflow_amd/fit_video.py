@@ -8,11 +8,15 @@ as produced by ``gflow_amd.synthetic.make_clip``: image, depth, flow, move_mask,
 pp); the reference's file readers and video writers are out of scope.
 
 Multi-GPU: clips are independent, frames of one clip are not.  One process per GPU,
-clip i goes to rank i mod world, no data-path collective; at the end ONE all-reduce(SUM) of a small
-metrics vector and ONE all-reduce(MAX) of the wall time (RCCL over xGMI on a node, 32-64 bytes:
-pure latency).
+the clips dealt to the ranks by length (``shard``: longest first, each to the least loaded rank -- the
+reference walks its sequences one after another, benchmark_multi.py:23-37), no data-path collective; at
+the end ONE all-reduce(SUM) of a small metrics vector (which also carries every rank's own wall time in
+a slot of its own) and ONE all-reduce(MAX) of the wall time (RCCL over xGMI on a node, tens of bytes:
+pure latency).  ``--clips-per-gpu c``: a rank fits c of its clips AT THE SAME TIME on its GPU
+(``fit_clips_concurrent``: one fit leaves the chip partly idle) -- the throughput mode of a node with more
+clips than GPUs.
 
-    python -m torch.distributed.run --nproc-per-node 8 -m gflow_amd.fit_video --clips 8 --frames 60
+    python -m torch.distributed.run --nproc-per-node 8 -m gflow_amd.fit_video --clips 24 --frames 60 --clips-per-gpu 3
 """
 import argparse
 import json
@@ -38,20 +42,40 @@ DEFAULTS = dict(num_points=60000, lr=4e-3, lr_camera=0.0, iterations_first=500, 
 METRIC_NAMES = ("psnr_sum", "frames", "iterations", "rasterisations", "clips", "splats_final")
 
 
-def shard(n_items, rank, world):
-    """Indices of the clips rank ``rank`` fits: i with i % world == rank."""
-    return [i for i in range(n_items) if i % world == rank]
+def shard(n_items, rank, world, lengths=None):
+    """Indices of the clips rank ``rank`` fits.  Clips cost what their frames cost (500 iterations for the first, 450 for
+    every other one), and a job lasts as long as its slowest rank: longest-processing-time-first -- the clips in
+    descending length (ties: lower index first), each to the rank with the least work so far (ties: lower rank) -- ends
+    within one clip of the ideal.  Every rank computes the same assignment from the same lengths: nothing is exchanged.
+    ``lengths=None``: all clips equally long (then this is i mod world)."""
+    lengths = [1] * n_items if lengths is None else [int(v) for v in lengths]
+    if len(lengths) != n_items:
+        raise ValueError("shard: one length per clip")
+    load = [0] * world
+    mine = []
+    for i in sorted(range(n_items), key=lambda j: (-lengths[j], j)):
+        r = min(range(world), key=lambda q: (load[q], q))
+        load[r] += lengths[i]
+        if r == rank:
+            mine.append(i)
+    return sorted(mine)
 
 
-def reduce_metrics(local, wall_seconds, dist=None, device="cpu"):
-    """SUM of the metrics vector and MAX of the wall time over all ranks (identity without dist)."""
-    vec = torch.tensor([float(local.get(k, 0.0)) for k in METRIC_NAMES], dtype=torch.float64, device=device)
+def reduce_metrics(local, wall_seconds, dist=None, device="cpu", rank=0, world=1):
+    """SUM of the metrics vector and MAX of the wall time over all ranks (identity without dist).  The vector's tail
+    has one slot per rank: every rank writes its own wall time into its slot, so the one SUM also hands every rank all
+    the ranks' times (``rank_wall_s``: the imbalance of the shard)."""
+    own = [0.0] * world
+    own[rank] = float(wall_seconds)
+    vec = torch.tensor([float(local.get(k, 0.0)) for k in METRIC_NAMES] + own, dtype=torch.float64, device=device)
     wall = torch.tensor([float(wall_seconds)], dtype=torch.float64, device=device)
     if dist is not None and dist.is_initialized():
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
         dist.all_reduce(wall, op=dist.ReduceOp.MAX)
-    out = {k: float(v) for k, v in zip(METRIC_NAMES, vec.tolist())}
+    vals = vec.tolist()
+    out = {k: float(v) for k, v in zip(METRIC_NAMES, vals)}
     out["wall_s"] = float(wall.item())
+    out["rank_wall_s"] = [float(v) for v in vals[len(METRIC_NAMES):]]
     return out
 
 
@@ -225,6 +249,10 @@ def main(argv=None):
     ap.add_argument("--iterations_first", type=int, default=500)
     ap.add_argument("--iterations_after", type=int, default=300)
     ap.add_argument("--iterations_camera", type=int, default=150)
+    ap.add_argument("--frames-list", default=None, help="comma-separated frame counts, one per synthetic clip (clips of "
+                                                        "unequal length: the shard balances them)")
+    ap.add_argument("--clips-per-gpu", type=int, default=1,
+                    help="clips a rank fits at the same time on its GPU (fit_clips_concurrent)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--sequence", action="append", default=None,
                     help="path of a prepared sequence folder (images + the reference's sibling folders, "
@@ -254,33 +282,55 @@ def main(argv=None):
                iterations_after=args.iterations_after, iterations_camera=args.iterations_camera)
     local = {k: 0.0 for k in METRIC_NAMES}
     n_clips = len(args.sequence) if args.sequence else args.clips
+    # how long is every clip?  (every rank must see the same numbers: they decide who fits what)
+    if args.sequence:
+        from . import io as gio
+        lengths = [len(gio.sequence_paths(p)["img"]) for p in args.sequence]
+    elif args.frames_list:
+        lengths = [int(v) for v in args.frames_list.split(",")]
+        if len(lengths) != n_clips:
+            raise SystemExit("--frames-list needs one length per clip")
+    else:
+        lengths = [args.frames] * n_clips
+    mine = shard(n_clips, rank, world, lengths)
     # reading / synthesising the clips is not part of the fit: do it before the clock starts
     t_load = time.perf_counter()
     clips = {}
-    for ci in shard(n_clips, rank, world):
+    for ci in mine:
         if args.sequence:
-            from . import io as gio
             clips[ci] = gio.load_sequence(args.sequence[ci], resize=args.resize)
         else:
-            clips[ci] = S.make_clip(args.frames, args.height, args.width, seed=ci)
+            clips[ci] = upload_clip(S.make_clip(lengths[ci], args.height, args.width, seed=ci, device=dev), dev)
     t_load = time.perf_counter() - t_load
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for ci, frames in clips.items():
-        m = fit_clip(frames, dev, cfg, seed=ci, log=(lambda s: print(f"[rank {rank} clip {ci}] {s}")) if args.verbose else None)
-        for k in METRIC_NAMES:
-            local[k] += m[k]
+    c = max(1, args.clips_per_gpu)
+    order = sorted(clips, key=lambda j: (-lengths[j], j))          # (clips of similar length share the GPU)
+    for g0 in range(0, len(order), c):
+        group = order[g0:g0 + c]
+        if len(group) == 1:
+            ci = group[0]
+            res = [fit_clip(clips[ci], dev, cfg, seed=ci,
+                            log=(lambda s, ci=ci: print(f"[rank {rank} clip {ci}] {s}")) if args.verbose else None)]
+        else:
+            res = fit_clips_concurrent([clips[ci] for ci in group], dev, cfg, seeds=group)
+        for m in res:
+            for k in METRIC_NAMES:
+                local[k] += m[k]
     torch.cuda.synchronize()
-    out = reduce_metrics(local, time.perf_counter() - t0, dist, torch.device("cpu") if (world > 1 and shared) else dev)
+    out = reduce_metrics(local, time.perf_counter() - t0, dist, torch.device("cpu") if (world > 1 and shared) else dev,
+                         rank=rank, world=world)
     if rank == 0:
         out["frames_per_s"] = out["frames"] / out["wall_s"]
         out["iterations_per_s"] = out["iterations"] / out["wall_s"]
         out["psnr_mean_db"] = out["psnr_sum"] / max(out["frames"], 1.0)
         out["n_gpus"] = world
+        out["clips_per_gpu"] = c
         out["load_s_rank0"] = t_load
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    return out if rank == 0 else None
 
 
 if __name__ == "__main__":

@@ -136,6 +136,28 @@ def test_shard_partitions_clips():
         parts = [shard(11, r, world) for r in range(world)]
         assert sorted(sum(parts, [])) == list(range(11))
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    assert [shard(8, r, 4) for r in range(4)] == [[0, 4], [1, 5], [2, 6], [3, 7]]       # equal lengths: i mod world
+
+
+def test_shard_balances_clips_of_unequal_length():
+    """Longest-processing-time-first on the frame counts: the most loaded rank ends within one (longest) clip of the
+    ideal, and much closer than i mod world on an adversarial order."""
+    import random
+    from gflow_amd.fit_video import shard
+    rng = random.Random(0)
+    for world in (2, 4, 8):
+        for trial in range(20):
+            lengths = [rng.choice([8, 20, 40, 60, 80, 100]) for _ in range(rng.randint(world, 5 * world))]
+            parts = [shard(len(lengths), r, world, lengths) for r in range(world)]
+            assert sorted(sum(parts, [])) == list(range(len(lengths)))
+            loads = [sum(lengths[i] for i in p) for p in parts]
+            assert max(loads) - min(loads) <= max(lengths)
+            assert max(loads) <= sum(lengths) / world + max(lengths)
+    # long clips at every world-th position: i mod world puts them all on rank 0
+    lengths = [100, 10, 10, 10] * 4
+    naive = max(sum(lengths[i] for i in range(16) if i % 4 == r) for r in range(4))
+    lpt = max(sum(lengths[i] for i in shard(16, r, 4, lengths)) for r in range(4))
+    assert naive == 400 and lpt == 130
 
 
 def _worker(rank, world, port, q):
@@ -146,7 +168,7 @@ def _worker(rank, world, port, q):
     clips = shard(5, rank, world)
     local = dict(psnr_sum=30.0 * len(clips), frames=4 * len(clips), iterations=100 * len(clips),
                  rasterisations=110 * len(clips), clips=len(clips), splats_final=1000 * (rank + 1))
-    out = reduce_metrics(local, wall_seconds=1.0 + rank, dist=dist)
+    out = reduce_metrics(local, wall_seconds=1.0 + rank, dist=dist, rank=rank, world=world)
     dist.destroy_process_group()
     q.put((rank, out))
 
@@ -166,6 +188,7 @@ def test_two_rank_gloo_reduction():
         o = outs[r]
         assert o["clips"] == 5 and o["frames"] == 20 and o["iterations"] == 500 and o["psnr_sum"] == 150.0
         assert o["wall_s"] == 2.0                               # MAX over ranks
+        assert o["rank_wall_s"] == [1.0, 2.0]                   # every rank's own time, from the same SUM
         assert o["splats_final"] == 3000
 
 

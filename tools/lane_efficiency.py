@@ -1,7 +1,7 @@
 """How many of the lanes the blend kernels spend on a (splat, 8x8 block) unit see the splat at all?  (analysis tool)
 Counts, over the tile lists of the bench scene and of a real first-frame fit, the pixels with alpha >= 1/255 per unit
 and what coarser/finer unit shapes or an exact ellipse test would evaluate.
-    gpurun -- python tools/lane_efficiency.py [--fit]
+    gpurun -- python tools/lane_efficiency.py [--fit] [--json out.json]
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -33,7 +33,8 @@ else:
         tr._attributes[k] = raw[k].to(dev)
     stepper = tr.make_stepper(iterations=500, lr=4e-3, lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0,
                               move_mask=frame["move_mask"], densify_interval=0, snapshot_interval=0)
-    for _ in range(200):
+    # (the middle of bench.py's pinned window, iterations [12, 32) of this fit)
+    for _ in range(bench.STEP_I0 + bench.STEP_WINDOW // 2):
         stepper()
 torch.cuda.synchronize()
 eng = tr.engine
@@ -103,3 +104,13 @@ line("4x4 units with any visible pixel", tot["u4_any"] * 16)
 line("4x4 units with any LIVE pixel", tot["u4_any_live"] * 16)
 line("8x1 rows with any visible pixel", tot["rows8"] * 8)
 line("8x1 rows with any LIVE pixel", tot["rows8_live"] * 8)
+
+if "--json" in sys.argv:
+    import json
+    # the kernels' unit is an 8x8 block that the exact ellipse test lets through (forward: any visible pixel; backward: any
+    # pixel that still needs the splat)
+    json.dump({"blend_fwd": tot["valid"] / (tot["u8_any"] * 64), "blend_bwd": tot["valid_live"] / (tot["u8_any_live"] * 64),
+               "visible_pixel_splat_pairs": tot["valid"], "live_pairs_backward": tot["valid_live"],
+               "units_8x8_forward": tot["u8_any"], "units_8x8_backward": tot["u8_any_live"], "K": K,
+               "scene": "bench scene at iteration %d (middle of the pinned window)" % (bench.STEP_I0 + bench.STEP_WINDOW // 2)},
+              open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)

@@ -1,6 +1,11 @@
-"""Fold the three rocprofv3 passes tools/profile_round.sh wrote into one JSON summary:
-per-kernel average duration (kernel-trace --stats) and HBM bytes per launch (FETCH_SIZE and
-WRITE_SIZE passes; FETCH_SIZE doubled, the gfx950 correction of MI355X_MICROARCH.md 'HBM').
+"""Fold the rocprofv3 passes tools/profile_round.sh wrote into one JSON summary:
+per-kernel average duration (kernel-trace) and HBM bytes per launch (FETCH_SIZE and
+WRITE_SIZE passes; FETCH_SIZE doubled, the gfx950 correction of MI355X_MICROARCH.md 'HBM'), the SQ issue counters.
+
+Every figure is an average over the launches of bench.py's PINNED WINDOW only -- the last WINDOW_LAUNCHES dispatches of
+each kernel: with the driver's flags (--steps 20 --warmup 5 --no-stage-pass) bench.py runs the fit's first 12 iterations,
+7 warm-up steps, and then the window [12, 32) twice (the timed pass and the pass that reads the pair counts) --, so the
+counters belong to the workload the bench line is timed on.  The whole-run --stats table is kept beside it.
 
     python tools/summarise_profile.py gpurun_out/<tag>  > gpurun_out/<tag>_summary.json
 """
@@ -30,6 +35,24 @@ def find(root, pattern):
     return hits[0] if hits else None
 
 
+WINDOW_LAUNCHES = 40
+
+
+def window_durations(root, last=WINDOW_LAUNCHES):
+    """average duration (us) over the last ``last`` dispatches of every kernel, from the per-dispatch kernel trace"""
+    path = find(root, "*kernel_trace.csv")
+    per = defaultdict(list)
+    if path:
+        for r in csv.DictReader(open(path)):
+            per[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    out = {}
+    for k, v in per.items():
+        v.sort()
+        w = v[-last:]
+        out[k] = {"calls": len(w), "avg_us": sum(e - b for b, e in w) / len(w) / 1e3}
+    return out
+
+
 def kernel_stats(root):
     path = find(root, "*kernel_stats.csv")
     out = {}
@@ -44,21 +67,28 @@ def kernel_stats(root):
     return out
 
 
-def counter_avg(root, counter):
+def counter_avg(root, counter, last=WINDOW_LAUNCHES):
+    """average of ``counter`` over the last ``last`` dispatches of every kernel (a dispatch's value may come in several
+    rows -- one per XCD / instance --: they are summed per dispatch first)"""
     path = find(root, "*counter_collection.csv")
-    tot, cnt = defaultdict(float), defaultdict(int)
+    per = defaultdict(lambda: defaultdict(float))
     if path:
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == counter:
-                k = short(r["Kernel_Name"])
-                tot[k] += float(r["Counter_Value"])
-                cnt[k] += 1
-    return {k: tot[k] / cnt[k] for k in tot}
+                per[short(r["Kernel_Name"])][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+    out = {}
+    for k, d in per.items():
+        vals = [d[i] for i in sorted(d)][-last:]
+        out[k] = sum(vals) / len(vals)
+    return out
 
 
 def main():
     root = sys.argv[1]
-    stats = kernel_stats(os.path.join(root, "trace"))
+    whole_run = kernel_stats(os.path.join(root, "trace"))
+    stats = window_durations(os.path.join(root, "trace"))
+    for k, v in stats.items():
+        v["pct"] = whole_run.get(k, {}).get("pct", 0.0)
     fetch = counter_avg(os.path.join(root, "fetch"), "FETCH_SIZE")
     write = counter_avg(os.path.join(root, "write"), "WRITE_SIZE")
     # FETCH_SIZE / WRITE_SIZE are reported in KB
@@ -78,13 +108,36 @@ def main():
             if k in STAGE_OF:
                 sq.setdefault(k, {})[c] = v
     clip = {k: v for k, v in kernel_stats(os.path.join(root, "clip")).items() if k in STAGE_OF or "blend" in k}
+    # the issue bound of every stage: how busy the VALUs were.  SQ_ACTIVE_INST_VALU counts quad-cycles summed over the
+    # chip's 1024 SIMDs; GRBM_GUI_ACTIVE cycles summed over the 8 XCDs.
+    valu = {}
+    for k, c in sq.items():
+        if c.get("GRBM_GUI_ACTIVE") and c.get("SQ_ACTIVE_INST_VALU") is not None:
+            st = STAGE_OF[k]
+            e = valu.setdefault(st, {"insts_per_launch": 0.0, "busy_cycles": 0.0, "avail_cycles": 0.0})
+            e["insts_per_launch"] += c.get("SQ_INSTS_VALU", 0.0)
+            e["busy_cycles"] += 4.0 * c["SQ_ACTIVE_INST_VALU"]
+            e["avail_cycles"] += 1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0
+    for e in valu.values():
+        e["busy_frac"] = e.pop("busy_cycles") / e.pop("avail_cycles")
+    lane = None
+    lane_path = os.path.join(root, "lane_efficiency.json")
+    if os.path.exists(lane_path):
+        lane = json.load(open(lane_path))
+        for st in ("blend_fwd", "blend_bwd"):
+            if st in valu and st in lane:
+                valu[st]["lane_efficiency"] = lane[st]
     print(json.dumps({
         "tag": os.path.basename(os.path.normpath(root)),
-        "command": "python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-stage-pass --no-clip",
-        "method": "rocprofv3 --kernel-trace --stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE (three separate runs); "
-                  "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B), both counters in KB",
+        "command": "python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-stage-pass --no-clip  (the driver's flags)",
+        "method": "rocprofv3 --kernel-trace --stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE; --pmc SQ_* (separate runs); "
+                  "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B), both counters in KB; every figure averaged over "
+                  f"the last {WINDOW_LAUNCHES} launches of the kernel = two passes over bench.py's pinned window",
         "kernels": kernels,
+        "whole_run_stats": {k: v for k, v in whole_run.items() if k in STAGE_OF},
         "hbm_bytes_per_launch": dict(stage_bytes),
+        "valu": valu,
+        "lane_efficiency": lane,
         "sq_counters_per_launch": sq,
         "sq_note": "SQ_* summed over the chip per launch; SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES / SQ_WAIT_INST_ANY count "
                    "quad-cycles, GRBM_GUI_ACTIVE cycles summed over the 8 XCDs (MI355X_MICROARCH.md)",
