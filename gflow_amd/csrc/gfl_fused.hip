@@ -135,36 +135,35 @@ __device__ __forceinline__ bool scale_row(float u, float v, int W, int H, unsign
 }
 
 // ------------------------------------------------------------------ preprocess fwd
+// What one block of splats does for the forward pass -- activations, projection, covariance, EWA, the record a pixel
+// needs, the block's row of the tile histogram -- once the splats' rows are in registers and the LDS histogram is cleared
+// (and a barrier has passed).  Two callers: the stand-alone launch (fused_preprocess_fwd_kernel) and the TAIL of the
+// per-splat backward + Adam launch of the iteration before (round 4, "next preprocess"): there the row is still in
+// registers when Adam has stepped it, and while the camera cannot move the next iteration's preprocess needs nothing else.
+// PARAMS of a block: splats [blockIdx.x * BLOCK, +BLOCK); BLOCK must be BIN_BLOCK (the scatter re-walks the same blocks).
 // EWA_MFMA: the J Sigma J^T contraction on the matrix cores (cov2d_mfma, gfl_math.hpp) instead of 30 FMAs in the lane
 // -- the variant north_star names; selected with GFL_EWA_MFMA=1, measured in DESIGN.md section 4, off by default.
-template <bool EWA_MFMA>
-__global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
-    const float* __restrict__ params, const float* __restrict__ intr, const float* __restrict__ pose, int N, int W, int H,
-    float nearest, float extent, int gx, int gy, float* __restrict__ rec, int32_t* __restrict__ slot_inv,
-    int32_t* __restrict__ hist_g, float* __restrict__ extr_out, int32_t* __restrict__ overflow,
-    int32_t* __restrict__ slot_pool, int32_t* __restrict__ pool_counter, int pool_cap, int op_mode,
-    const uint8_t* __restrict__ row_flags, int scale_rows_mode, int32_t* __restrict__ scale_cnt) {
+struct PreArgs {
+    const float* intr; const float* pose;
+    int N, W, H;
+    float nearest, extent;
+    int gx, gy;
+    float* rec; int32_t* slot_inv; int32_t* hist_g; float* extr_out; int32_t* overflow;
+    int32_t* slot_pool; int32_t* pool_counter; int pool_cap; int op_mode;
+    int scale_rows_mode; int32_t* scale_cnt;
+    int32_t* pre_valid;              // set by a tail that ran the preprocess, checked and cleared by the column scan
+};
+
+template <bool EWA_MFMA, bool PHASES>
+__device__ __forceinline__ void preprocess_block(const PreArgs& a, const float4 (&row_v)[4], unsigned own_flags, int i,
+                                                 int32_t* __restrict__ hist) {
     // op_mode (gfl_render_fwd): activated attributes in the rows, camera = the extrinsic in extr_out
     // scale_rows_mode != 0 (lambda_scale): count the rows the scale term averages over, per block
-    extern __shared__ int32_t hist[];
+    const int N = a.N, W = a.W, H = a.H, gx = a.gx, gy = a.gy;
     const int T = gx * gy;
-    GFL_PHASE(0, 0);
-    // the splat's row first: its latency (1.1 us of the launch's 8, tools/phase_trace.py) then overlaps the clearing of
-    // the histogram, the barrier and the camera's scalar loads instead of following them
-    const int i = blockIdx.x * BIN_BLOCK + threadIdx.x;
-    float4 row_v[4];
-    unsigned own_flags = 0;
-    if (i < N) {
-        const float4* prow = reinterpret_cast<const float4*>(params + (size_t)i * ROW);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) row_v[q] = prow[q];
-        if (scale_rows_mode && row_flags) own_flags = row_flags[i];
-    }
-    for (int t = threadIdx.x; t < T; t += BIN_BLOCK) hist[t] = 0;
-    __syncthreads();
-    GFL_PHASE(0, 1);
-    const Cam c = op_mode ? load_cam(intr, extr_out) : cam_from_pose(intr, pose);
-    if (!op_mode && blockIdx.x == 0 && threadIdx.x == 0) {
+    const Cam c = a.op_mode ? load_cam(a.intr, a.extr_out) : cam_from_pose(a.intr, a.pose);
+    if (!a.op_mode && blockIdx.x == 0 && threadIdx.x == 0) {
+        float* extr_out = a.extr_out;
         extr_out[0] = c.r00; extr_out[1] = c.r01; extr_out[2] = c.r02; extr_out[3] = c.t0;
         extr_out[4] = c.r10; extr_out[5] = c.r11; extr_out[6] = c.r12; extr_out[7] = c.t1;
         extr_out[8] = c.r20; extr_out[9] = c.r21; extr_out[10] = c.r22; extr_out[11] = c.t2;
@@ -177,15 +176,17 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
     Proj p = {};
     float cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (i < N) {
-        s = splat_from_row(row_v[0], row_v[1], row_v[2], row_v[3], op_mode != 0);
+        s = splat_from_row(row_v[0], row_v[1], row_v[2], row_v[3], a.op_mode != 0);
 #ifdef GFL_TRACE
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        GFL_PHASE(0, 2);
+        if (PHASES) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GFL_PHASE(0, 2);
+        }
 #endif
-        p = project_fwd(c, s.x, s.y, s.z, W, H, nearest, extent);
+        p = project_fwd(c, s.x, s.y, s.z, W, H, a.nearest, a.extent);
         if (p.vis) cov3d_fwd(s.s, s.q, cov);
     }
-    GFL_PHASE(0, 3);
+    if (PHASES) GFL_PHASE(0, 3);
     Ewa e = {};
     if (EWA_MFMA) e = ewa_fwd_mfma(c, p.vis, p.px, p.py, p.pz, cov, W, H);       // (the whole wave: no divergence here)
     if (i < N) {
@@ -214,12 +215,12 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
                 }
             }
         }
-        float4* r4 = reinterpret_cast<float4*>(rec + (size_t)i * REC);
+        float4* r4 = reinterpret_cast<float4*>(a.rec + (size_t)i * REC);
         r4[0] = make_float4(u, v, A, B);
         r4[1] = make_float4(C, s.o, s.c[0], s.c[1]);
         r4[2] = make_float4(s.c[2], depth, cutoff, __int_as_float(rad));
-        in_scale_rows = scale_rows_mode && scale_row(u, v, W, H, own_flags, scale_rows_mode);
-        int4* iv = reinterpret_cast<int4*>(slot_inv + (size_t)i * SLOT_MAX);
+        in_scale_rows = a.scale_rows_mode && scale_row(u, v, W, H, own_flags, a.scale_rows_mode);
+        int4* iv = reinterpret_cast<int4*>(a.slot_inv + (size_t)i * SLOT_MAX);
         const int4 none = make_int4(-1, -1, -1, -1);
         // only the slots of the splat's own tile rectangle are ever read (gather of the backward)
 #pragma unroll
@@ -228,16 +229,16 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
         if (wnt > SLOT_MAX) {
             // too many tiles for the slot row: reserve wnt entries of the pool; the row's first
             // entry carries the pool offset as -2 - offset
-            const int off = atomicAdd(pool_counter, wnt);
-            if (off + wnt <= pool_cap) {
+            const int off = atomicAdd(a.pool_counter, wnt);
+            if (off + wnt <= a.pool_cap) {
                 woff = off;
-                slot_inv[(size_t)i * SLOT_MAX] = -2 - off;
+                a.slot_inv[(size_t)i * SLOT_MAX] = -2 - off;
             } else {
-                *overflow = 1;
+                *a.overflow = 1;
             }
         }
     }
-    GFL_PHASE(0, 4);
+    if (PHASES) GFL_PHASE(0, 4);
     {
         // splats covering many tiles: the whole wave counts their tiles, 64 at a time
         const int lane = threadIdx.x & 63;
@@ -251,11 +252,11 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
             for (int q = lane; q < snt; q += 64) {
                 const int tx = sx0 + q % snx, ty = sy0 + q / snx;
                 if (tile_hit2(su, sv, sc, tx, ty)) atomicAdd(&hist[ty * gx + tx], 1);
-                if (soff >= 0) slot_pool[soff + q] = -1;
+                if (soff >= 0) a.slot_pool[soff + q] = -1;
             }
         }
     }
-    if (scale_rows_mode) {
+    if (a.scale_rows_mode) {
         // (no atomics on global memory: one partial per block, folded by every block of the backward kernel)
         const int wcnt = __popcll(__ballot(in_scale_rows));
         __shared__ int32_t s_cnt[BIN_BLOCK / 64];
@@ -264,15 +265,38 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(
         if (threadIdx.x == 0) {
             int tot = 0;
             for (int w = 0; w < BIN_BLOCK / 64; ++w) tot += s_cnt[w];
-            scale_cnt[blockIdx.x] = tot;
+            a.scale_cnt[blockIdx.x] = tot;
         }
     }
-    GFL_PHASE(0, 5);
+    if (PHASES) GFL_PHASE(0, 5);
     __syncthreads();
-    GFL_PHASE(0, 6);
-    int32_t* row = hist_g + (size_t)blockIdx.x * T;
+    if (PHASES) GFL_PHASE(0, 6);
+    int32_t* row = a.hist_g + (size_t)blockIdx.x * T;
     for (int t = threadIdx.x; t < T; t += BIN_BLOCK) row[t] = hist[t];
-    GFL_PHASE(0, 7);
+    if (PHASES) GFL_PHASE(0, 7);
+}
+
+template <bool EWA_MFMA>
+__global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(const float* __restrict__ params, PreArgs a,
+                                                                         const uint8_t* __restrict__ row_flags) {
+    extern __shared__ int32_t hist[];
+    const int T = a.gx * a.gy;
+    GFL_PHASE(0, 0);
+    // the splat's row first: its latency (1.1 us of the launch's 8, tools/phase_trace.py) then overlaps the clearing of
+    // the histogram, the barrier and the camera's scalar loads instead of following them
+    const int i = blockIdx.x * BIN_BLOCK + threadIdx.x;
+    float4 row_v[4] = {};
+    unsigned own_flags = 0;
+    if (i < a.N) {
+        const float4* prow = reinterpret_cast<const float4*>(params + (size_t)i * ROW);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) row_v[q] = prow[q];
+        if (a.scale_rows_mode && row_flags) own_flags = row_flags[i];
+    }
+    for (int t = threadIdx.x; t < T; t += BIN_BLOCK) hist[t] = 0;
+    __syncthreads();
+    GFL_PHASE(0, 1);
+    preprocess_block<EWA_MFMA, true>(a, row_v, own_flags, i, hist);
 }
 
 // Columns of hist -> exclusive per-block bases (in place) and per-tile totals.
@@ -287,8 +311,15 @@ constexpr int CS_GROUPS = 8;
 __global__ void __launch_bounds__(256) bin_colscan_kernel(int32_t* __restrict__ hist_g, int nblk, int T,
                                                          int32_t* __restrict__ tile_counts,
                                                          int32_t* __restrict__ pool_counter,
-                                                         int32_t* __restrict__ pull_counters, int n_pull) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *pool_counter = 0;   // preprocess is done with it
+                                                         int32_t* __restrict__ pull_counters, int n_pull,
+                                                         int32_t* __restrict__ pre_valid, int expect_pre,
+                                                         int32_t* __restrict__ overflow) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *pool_counter = 0;   // preprocess is done with it
+        // this forward has no preprocess launch of its own (expect_pre): the previous iteration's tail must have run it
+        if (expect_pre && *pre_valid == 0) *overflow = 2;
+        *pre_valid = 0;
+    }
     // the pull counters of this iteration's two blend launches (the tile queues themselves may be older: they are
     // rebuilt at the END of an iteration, beside the per-splat launch)
     if (blockIdx.x == 0)
@@ -616,6 +647,7 @@ __device__ __forceinline__ bool splat_alpha2(const float4& p0, const float4& p1,
 
 #ifdef GFL_TRACE
 __device__ long long g_fwd_trace[16384 * 8];     // analysis build: per-tile timeline of the forward blend
+__device__ long long g_fwd_trace2[4096 * 16 * 4]; // ... of a long first tile's sixteen quarter waves: staging ticks, walk ticks, steps, units
 #endif
 
 // apply_float_colormap(depth, "turbo", non_zero=True) for one value (color.py:24-44): mm = ordered-uint encodings of
@@ -727,6 +759,8 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
 #ifdef GFL_TRACE
     const long long trace_t0 = wall_clock64();
     int trace_units = 0;
+    long long trace_stage = 0, trace_walk = 0, trace_mark = trace_t0;
+    int trace_steps = 0;
 #endif
 
     // Tw: working transmittance, set to 0 when the pixel stops (T would fall below 1e-4) so that
@@ -737,6 +771,9 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     const unsigned long long alive0 = __ballot(inside);            // every pixel of the box that is in the image
 
     for (int base = start; base < end; base += FB) {
+#ifdef GFL_TRACE
+        { const long long now = wall_clock64(); trace_walk += now - trace_mark; trace_mark = now; }
+#endif
         if (__syncthreads_and(Tw == 0.f)) break;
         const int idx = base + tid;
         if (idx < end) {
@@ -754,6 +791,9 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
             s_mask[tid] = (unsigned char)block_mask(p0, p1, p2.z, org_x, org_y, bs);
         }
         __syncthreads();
+#ifdef GFL_TRACE
+        { const long long now = wall_clock64(); trace_stage += now - trace_mark; trace_mark = now; }
+#endif
         const int cnt = min(FB, end - base);
         if (__all(Tw == 0.f)) continue;      // this wave is finished; keep meeting the barriers
         for (int c0 = 0; c0 < cnt; c0 += 64) {
@@ -807,6 +847,9 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                 const int row = lane >> 4;
                 while (bits) {
                     units += min((int)__popcll(bits), 4);
+#ifdef GFL_TRACE
+                    ++trace_steps;
+#endif
                     int j[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -902,6 +945,10 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
         if (ck_lane) { c5[0] = T; c5[256] = a0; c5[512] = a1; c5[768] = a2; c5[1024] = a3; }
     }
 #ifdef GFL_TRACE
+    if (blk >= 0 && lane == 0 && tile < 4096) {
+        long long* t2 = g_fwd_trace2 + ((size_t)tile * 16 + blk * 4 + wave) * 4;
+        t2[0] = trace_stage; t2[1] = trace_walk + (wall_clock64() - trace_mark); t2[2] = trace_steps; t2[3] = units;
+    }
     const int trace_done = __popcll(__ballot(Tw == 0.f && inside));
     if (lane == 0 && tile < 16384) {
         unsigned hw, xcc;
@@ -1468,8 +1515,12 @@ struct NextSched {
 // OP = true is the differentiable operator's backward (gfl_render_bwd): the rows hold ACTIVATED attributes, the
 // camera is the extrinsic `pose` points at (12 floats), the caller's dL/d uv and dL/d depth join the gradient, and
 // the 14 gradients are WRITTEN to d_params rows instead of stepping Adam (no regularisers, no masks).
-template <bool OP>
-__global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel(
+// NEXT (round 4): the NEXT iteration's preprocess in the tail of this launch (preprocess_block; BLOCK = BIN_BLOCK then, so
+// that a workgroup's splats are one block of the binning): Adam has just stepped the row in registers, and while the
+// camera cannot move nothing else is needed -- the next iteration starts at the column scan, a launch and 56 N bytes
+// less.  Only plain joint-stage iterations of a multi-iteration call (gfl_fit_iterations) take it.
+template <bool OP, int BLOCK, bool NEXT>
+__global__ void __launch_bounds__(BLOCK) fused_preprocess_bwd_adam_kernel(
     float* __restrict__ params, float* __restrict__ adam_m, float* __restrict__ adam_v, const float* __restrict__ intr,
     const float* pose, const float* __restrict__ rec, float* __restrict__ d_rec,
     const float* __restrict__ pair_grad, const int32_t* __restrict__ slot_pool,
@@ -1478,18 +1529,22 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
     const float* __restrict__ still_w, const uint8_t* __restrict__ row_flags, RegCfg rc, AdamCfg ac,
     const int32_t* d_step, float* partial, const float* __restrict__ d_uv_in,
     const float* __restrict__ d_depth_in, float* __restrict__ d_params, const int32_t* __restrict__ scale_cnt, CamTail tail,
-    NextSched ns) {
+    NextSched ns, PreArgs next) {
+    extern __shared__ int32_t sched_scratch[];           // T ints: the scheduler's scratch, or (NEXT) the tile histogram
     if ((int)blockIdx.x >= ns.rows) {
         // the two workgroups behind the per-splat ones build the NEXT iteration's tile queues (see fused_scatter_kernel)
-        extern __shared__ int32_t sched_scratch[];
         __shared__ SchedLds sched_lds;
-        __shared__ int32_t sched_wsum[REDUCE_BLOCK / 64];
+        __shared__ int32_t sched_wsum[BLOCK / 64];
         const Sched sc = (int)blockIdx.x == ns.rows ? ns.bwd : ns.fwd;
-        schedule_tiles_xcd<REDUCE_BLOCK>(ns.tile_counts, ns.T, sc, sched_scratch, sched_wsum, sched_lds);
+        schedule_tiles_xcd<BLOCK>(ns.tile_counts, ns.T, sc, sched_scratch, sched_wsum, sched_lds);
         if (threadIdx.x == 0) *ns.valid = 1;
         return;
     }
     GFL_PHASE(3, 0);
+    if (NEXT) {
+        // (the barrier that publishes the cleared histogram is the one in front of the tail, below)
+        for (int t = threadIdx.x; t < next.gx * next.gy; t += BLOCK) sched_scratch[t] = 0;
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int e_step = OP ? 0 : *d_step - (rc.no_pose_grad ? 1 : 0);   // (the camera launch advances it -- or already has: LossTail)
     float scale_w = 0.f;                              // lambda_scale / rows of the scale term
@@ -1498,7 +1553,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
         if (threadIdx.x == 0) s_rows = 0;
         __syncthreads();
         int c = 0;
-        for (int b = threadIdx.x; b < rc.scale_blocks; b += REDUCE_BLOCK) c += scale_cnt[b];
+        for (int b = threadIdx.x; b < rc.scale_blocks; b += BLOCK) c += scale_cnt[b];
         if (c) atomicAdd(&s_rows, c);
         __syncthreads();
         scale_w = s_rows > 0 ? rc.lambda_scale / (float)s_rows : 0.f;
@@ -1516,7 +1571,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
     int big_nt = 0;
     // the parameter row and both Adam moments are requested before the gather so that their
     // latency overlaps it (the launch has about one wave per SIMD: nothing else would hide it)
-    float4 prow_v[4], mrow_v[4], vrow_v[4];
+    float4 prow_v[4] = {}, mrow_v[4], vrow_v[4];
     float rec_C = 0.f;
     unsigned own_flags = 0;
     float own_flow_w = 0.f, own_still_w = 0.f, own_still_t[3] = {0.f, 0.f, 0.f};    // (OP: own_flow_w = dL/d depth,
@@ -1774,7 +1829,8 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
         for (int k = 0; k < 14; ++k) pv[k] = adam_update(pv[k], g[k], mv[k], vv[k], ac, step_size, isb2);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            prow[q] = make_float4(pv[4 * q], pv[4 * q + 1], pv[4 * q + 2], pv[4 * q + 3]);
+            prow_v[q] = make_float4(pv[4 * q], pv[4 * q + 1], pv[4 * q + 2], pv[4 * q + 3]);      // the stepped row (NEXT)
+            prow[q] = prow_v[q];
             mrow[q] = make_float4(mv[4 * q], mv[4 * q + 1], mv[4 * q + 2], mv[4 * q + 3]);
             vrow[q] = make_float4(vv[4 * q], vv[4 * q + 1], vv[4 * q + 2], vv[4 * q + 3]);
         }
@@ -1784,13 +1840,20 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
     GFL_PHASE(3, 6);
     if (!OP && rc.no_pose_grad) {
         // nobody reads the extrinsic partials of this iteration
-    } else if (!OP && tail.ticket) {
-        block_reduce_store<12, REDUCE_BLOCK, true>(e, partial);
+    } else if (!OP && tail.ticket && BLOCK == REDUCE_BLOCK) {
+        block_reduce_store<12, BLOCK, true>(e, partial);
         camera_tail(tail, partial, ns.rows, e_step);
     } else {
-        block_reduce_store<12, REDUCE_BLOCK>(e, partial);
+        block_reduce_store<12, BLOCK>(e, partial);
     }
     GFL_PHASE(3, 7);
+    if (NEXT) {
+        // the next iteration's preprocess on the row Adam has just written (prow_v), this workgroup = one binning block
+        static_assert(!NEXT || BLOCK == BIN_BLOCK, "the tail bins one block of BIN_BLOCK splats");
+        __syncthreads();
+        if (threadIdx.x == 0 && blockIdx.x == 0) *next.pre_valid = 1;
+        preprocess_block<false, false>(next, prow_v, own_flags, i, sched_scratch);
+    }
 }
 
 // camera + depth affine: fold the extr partials, chain to the pose, Adam, step += 1
@@ -2046,7 +2109,9 @@ size_t gfl_fit_workspace_bytes(int cap, int K_cap, int W, int H) {
            + up256(gfl_loss_workspace_bytes(W, H)) + 256
            + up256((size_t)6 * W * H * sizeof(float))                                  // SSIM statistics of the target
            + up256((size_t)fit_nblk(cap > 0 ? cap : 1) * sizeof(int32_t))              // rows of the scale term per block
-           + up256(T * 4 * sizeof(int32_t));                                           // the tile sort's order
+           + up256(T * 4 * sizeof(int32_t))                                            // the tile sort's order
+           + up256((size_t)K_cap * sizeof(int32_t))                                    // second slot pool   } iterations take
+           + up256((size_t)fit_nblk(cap > 0 ? cap : 1) * sizeof(int32_t));             // second scale rows  } turns ("next preprocess")
 }
 
 struct FitWs {
@@ -2057,7 +2122,9 @@ struct FitWs {
     float* pair_grad;
     int32_t* slot_inv;
     int32_t* slot_pool;
-    int32_t* pool_counter;
+    int32_t* slot_pool2;     // iterations take turns (parity): the tail of iteration i prepares the pool of iteration i + 1
+    int32_t* pool_counter;   //   while other workgroups of the same launch still gather through the pool of iteration i
+    int32_t* pre_valid;      // != 0: the last per-splat launch ran the next iteration's preprocess in its tail
     int32_t* sched_valid;    // != 0: the tile queues in the workspace were built at the end of the last iteration
     Sched sched;             // tile queues of the backward blend; sched.work persists between calls
     Sched sched_fwd;         // ... and of the forward blend (its own work feedback)
@@ -2066,6 +2133,7 @@ struct FitWs {
     size_t loss_ws_bytes;
     float* gt_stats;         // [3][2][H][W] conv(y), conv(y^2) of the current target (gfl_fit_prepare_targets)
     int32_t* scale_cnt;      // [blocks of the preprocess launch] rows of the scale term (lambda_scale)
+    int32_t* scale_cnt2;     //   (second set, by parity like slot_pool2)
     int4* sort_order;        // [T] {tile, start, end, 0}: the order the tile sort takes the tiles in (fused_scatter_kernel)
 };
 
@@ -2087,6 +2155,7 @@ static FitWs carve(const gfl_fit_state* st) {
     p += up256((size_t)(st->cap > 0 ? st->cap : 1) * SLOT_MAX * sizeof(int32_t));
     w.pool_counter = (int32_t*)p;
     w.sched_valid = w.pool_counter + 16;
+    w.pre_valid = w.pool_counter + 24;
     p += 256;
     w.slot_pool = (int32_t*)p;
     p += up256((size_t)st->K_cap * sizeof(int32_t));
@@ -2122,6 +2191,8 @@ static FitWs carve(const gfl_fit_state* st) {
     w.gt_stats = (float*)((char*)p + w.loss_ws_bytes + 256);
     w.scale_cnt = (int32_t*)((char*)w.gt_stats + up256((size_t)6 * st->W * st->H * sizeof(float)));
     w.sort_order = (int4*)((char*)w.scale_cnt + up256((size_t)fit_nblk(st->cap > 0 ? st->cap : 1) * sizeof(int32_t)));
+    w.slot_pool2 = (int32_t*)((char*)w.sort_order + up256(T * 4 * sizeof(int32_t)));
+    w.scale_cnt2 = (int32_t*)((char*)w.slot_pool2 + up256((size_t)st->K_cap * sizeof(int32_t)));
     return w;
 }
 
@@ -2157,7 +2228,36 @@ static int fit_check(const gfl_fit_state* st, const gfl_fit_hyper* hp) {
 // kernels of gfl_bin.hip / gfl_loss.hip reused through their C entry points
 // (gfl_loss_fwd_bwd, gfl_tile_sort_only: declared in gflow_hip.h)
 
-static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream, int op_mode) {
+// GFL_NEXT_PRE=0: every iteration has its own preprocess launch (rounds 1-3)
+static bool next_pre_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GFL_NEXT_PRE");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+static PreArgs pre_args(const gfl_fit_state* st, const gfl_fit_hyper* hp, const FitWs& w, int gx, int gy, int op_mode,
+                        int parity) {
+    PreArgs a;
+    a.intr = st->intr; a.pose = st->pose;
+    a.N = st->N; a.W = st->W; a.H = st->H;
+    a.nearest = hp->nearest; a.extent = hp->extent;
+    a.gx = gx; a.gy = gy;
+    a.rec = st->rec; a.slot_inv = w.slot_inv; a.hist_g = w.hist; a.extr_out = st->extr; a.overflow = st->overflow;
+    a.slot_pool = parity ? w.slot_pool2 : w.slot_pool; a.pool_counter = w.pool_counter; a.pool_cap = st->K_cap;
+    a.op_mode = op_mode;
+    a.scale_rows_mode = (!op_mode && hp->lambda_scale != 0.f) ? (hp->freeze_all_splats ? 2 : 1) : 0;
+    a.scale_cnt = parity ? w.scale_cnt2 : w.scale_cnt;
+    a.pre_valid = w.pre_valid;
+    return a;
+}
+
+// pre_done: this forward's preprocess has been run by the previous iteration's per-splat launch (its tail).
+// parity: which of the two slot pools / scale-row sets this iteration uses.
+static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream, int op_mode,
+                            int pre_done = 0, int parity = 0) {
     int rc = fit_check(st, hp);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
@@ -2166,21 +2266,17 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
     const int nblk = fit_nblk(st->N > 0 ? st->N : 1);
     const size_t lds = (size_t)T * sizeof(int32_t);
     if (lds > 42 * 1024) return GFL_ERR_INVALID;   // tile grid too large for the LDS histogram (+ 21 KB of scheduler state: 64 KB)
-    {
+    int32_t* slot_pool = parity ? w.slot_pool2 : w.slot_pool;
+    if (!pre_done) {
         StageScope p(ST_PREPROCESS, s);
         auto kern = ewa_on_mfma() ? fused_preprocess_fwd_kernel<true> : fused_preprocess_fwd_kernel<false>;
-        kern<<<nblk, BIN_BLOCK, lds, s>>>(st->params, st->intr, st->pose, st->N, st->W, st->H,
-                                                                hp->nearest, hp->extent, gx, gy, st->rec, w.slot_inv,
-                                                                w.hist, st->extr, st->overflow, w.slot_pool,
-                                                                w.pool_counter, st->K_cap, op_mode, st->row_flags,
-                                                                (!op_mode && hp->lambda_scale != 0.f)
-                                                                    ? (hp->freeze_all_splats ? 2 : 1) : 0,
-                                                                w.scale_cnt);
+        kern<<<nblk, BIN_BLOCK, lds, s>>>(st->params, pre_args(st, hp, w, gx, gy, op_mode, parity), st->row_flags);
     }
     {
         StageScope p(ST_COLSCAN, s);
         bin_colscan_kernel<<<(T + CS_TILES - 1) / CS_TILES, 256, 0, s>>>(w.hist, nblk, T, w.tile_counts, w.pool_counter,
-                                                                         w.sched.counters, 2 * w.sched.nq);
+                                                                         w.sched.counters, 2 * w.sched.nq, w.pre_valid,
+                                                                         pre_done, st->overflow);
     }
     // (the order of the tile sort is built by one workgroup with up to eight tiles per lane in registers: beyond 4096 tiles
     //  -- 1080p has 8160 -- the sort takes the tiles in their own order)
@@ -2195,10 +2291,10 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
         StageScope p(ST_TILE_SORT, s);
         if (ordered)
             rc = gfl_tile_sort_ordered((const int32_t*)w.sort_order, st->W, st->H, st->K_cap, w.keys, st->ids, st->tile_range,
-                                       st->rec, w.slot_inv, w.slot_pool, stream);
+                                       st->rec, w.slot_inv, slot_pool, stream);
         else
             rc = gfl_tile_sort_with_slots(st->tile_offsets, st->W, st->H, st->K_cap, w.keys, st->ids, st->tile_range, st->rec,
-                                          w.slot_inv, w.slot_pool, stream);
+                                          w.slot_inv, slot_pool, stream);
     }
     if (rc) return rc;
     {
@@ -2390,16 +2486,21 @@ int gfl_render_bwd(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float
     {
         StageScope p(ST_PRE_BWD_ADAM, s);
         const NextSched ns = next_sched(w, rows, T);
-        fused_preprocess_bwd_adam_kernel<true><<<rows + next_sched_blocks(w, T), REDUCE_BLOCK, next_sched_lds(w, T), s>>>(
+        fused_preprocess_bwd_adam_kernel<true, REDUCE_BLOCK, false><<<rows + next_sched_blocks(w, T), REDUCE_BLOCK, next_sched_lds(w, T), s>>>(
             st->params, nullptr, nullptr, st->intr, st->extr, st->rec, st->d_rec, w.pair_grad, w.slot_pool, st->tile_range,
             w.slot_inv, gx, gy, st->N, st->W, st->H, nullptr, nullptr, nullptr, nullptr, nullptr, rcfg, ac, nullptr,
-            w.partial, d_uv, d_depth, d_params, nullptr, CamTail{}, ns);
+            w.partial, d_uv, d_depth, d_params, nullptr, CamTail{}, ns, PreArgs{});
         fold_partials_kernel<12><<<1, 256, 0, s>>>(w.partial, rows, d_extr);
     }
     return check_launch();
 }
 
-int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream) {
+// do_next: run the next iteration's preprocess in the tail of the per-splat launch (only honoured when the iteration
+// qualifies: fit_next_pre_ok); parity: the slot pool / scale rows of THIS iteration (the next one gets the other set)
+static bool fit_next_pre_ok(const gfl_fit_state* st, const gfl_fit_hyper* hp, const FitWs& w, int T);
+
+static int fit_backward_step_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream, int do_next,
+                                  int parity) {
     int rc = fit_check(st, hp);
     if (rc) return rc;
     if (!st->adam_m || !st->adam_v || !st->pose_m || !st->pose_v || !st->depth_ab || !st->depth_ab_m ||
@@ -2464,13 +2565,38 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
         tail.sums = st->sums; tail.ac_cam = ac_cam; tail.ac_ab = ac; tail.step_camera = hp->step_camera;
         tail.d_step = st->step; tail.d_extr_out = st->d_extr; tail.ticket = w.pool_counter + 8;
     }
+    const int32_t* slot_pool = parity ? w.slot_pool2 : w.slot_pool;
+    const int32_t* scale_cnt = parity ? w.scale_cnt2 : w.scale_cnt;
+    if (do_next && frozen && fit_next_pre_ok(st, hp, w, T)) {
+        // the per-splat launch with 512-splat workgroups (= the binning's blocks) and the next preprocess in its tail
+        StageScope p(ST_PRE_BWD_ADAM, s);
+        const int rows512 = fit_nblk(st->N > 0 ? st->N : 1);
+        rcfg.scale_blocks = rows512;
+        const NextSched ns = next_sched(w, rows512, T);
+        const PreArgs next = pre_args(st, hp, w, gx, gy, 0, parity ^ 1);
+        fused_preprocess_bwd_adam_kernel<false, BIN_BLOCK, true><<<rows512 + next_sched_blocks(w, T), BIN_BLOCK, (size_t)T * sizeof(int32_t), s>>>(
+            st->params, st->adam_m, st->adam_v, st->intr, st->pose, st->rec, st->d_rec, w.pair_grad, slot_pool,
+            st->tile_range, w.slot_inv, gx, gy, st->N, st->W, st->H, st->flow_target, st->flow_w, st->still_target,
+            st->still_w, st->row_flags, rcfg, ac, st->step, w.partial, nullptr, nullptr, nullptr, scale_cnt, tail, ns, next);
+        return check_launch();
+    }
+    if (getenv("GFL_ADAM_512")) {      // experiment: the per-splat launch with 512-splat workgroups, no tail
+        StageScope p(ST_PRE_BWD_ADAM, s);
+        const int rows512 = fit_nblk(st->N > 0 ? st->N : 1);
+        const NextSched ns = next_sched(w, rows512, T);
+        fused_preprocess_bwd_adam_kernel<false, BIN_BLOCK, false><<<rows512 + next_sched_blocks(w, T), BIN_BLOCK, (size_t)T * sizeof(int32_t), s>>>(
+            st->params, st->adam_m, st->adam_v, st->intr, st->pose, st->rec, st->d_rec, w.pair_grad, slot_pool,
+            st->tile_range, w.slot_inv, gx, gy, st->N, st->W, st->H, st->flow_target, st->flow_w, st->still_target,
+            st->still_w, st->row_flags, rcfg, ac, st->step, w.partial, nullptr, nullptr, nullptr, scale_cnt, tail, ns, PreArgs{});
+        return check_launch();
+    }
     {
         StageScope p(ST_PRE_BWD_ADAM, s);
         const NextSched ns = next_sched(w, rows, T);
-        fused_preprocess_bwd_adam_kernel<false><<<rows + next_sched_blocks(w, T), REDUCE_BLOCK, next_sched_lds(w, T), s>>>(
-            st->params, st->adam_m, st->adam_v, st->intr, st->pose, st->rec, st->d_rec, w.pair_grad, w.slot_pool,
+        fused_preprocess_bwd_adam_kernel<false, REDUCE_BLOCK, false><<<rows + next_sched_blocks(w, T), REDUCE_BLOCK, next_sched_lds(w, T), s>>>(
+            st->params, st->adam_m, st->adam_v, st->intr, st->pose, st->rec, st->d_rec, w.pair_grad, slot_pool,
             st->tile_range, w.slot_inv, gx, gy, st->N, st->W, st->H, st->flow_target, st->flow_w, st->still_target,
-            st->still_w, st->row_flags, rcfg, ac, st->step, w.partial, nullptr, nullptr, nullptr, w.scale_cnt, tail, ns);
+            st->still_w, st->row_flags, rcfg, ac, st->step, w.partial, nullptr, nullptr, nullptr, scale_cnt, tail, ns, PreArgs{});
     }
     if (own_launch && !frozen) {
         StageScope p(ST_CAMERA, s);
@@ -2479,6 +2605,49 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
                                                     ac_cam, ac, hp->step_camera != 0, st->step, st->d_extr);
     }
     return check_launch();
+}
+
+int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream) {
+    return fit_backward_step_impl(st, hp, stream, 0, 0);
+}
+
+// The iteration qualifies for the next preprocess in its tail: a plain fit iteration whose camera cannot move (the pose the
+// tail projects with is the pose of the next iteration), splats that are stepped (not the camera-only stage), no
+// footprint mask, the XCD scheduler's 512-thread form available for the launch's two scheduling workgroups.
+static bool fit_next_pre_ok(const gfl_fit_state* st, const gfl_fit_hyper* hp, const FitWs& w, int T) {
+    const bool frozen = pose_frozen_fast() && hp->step_camera != 2 && (hp->step_camera == 0 || hp->lr_camera == 0.f) &&
+                        camera_own_launch();
+    const bool sched512 = !next_sched_enabled() || (w.sched.xcd && T <= SCHED_PLAN_TILES && w.sched.nq % 8 == 0 &&
+                                                    w.sched.nq / 8 <= 64 && w.sched.nq <= BIN_BLOCK);
+    return next_pre_enabled() && frozen && !hp->freeze_all_splats && !st->foot_flags && !ewa_on_mfma() && sched512 &&
+           st->N > 0 && (size_t)T * sizeof(int32_t) <= 42 * 1024;
+}
+
+int gfl_fit_iterations(const gfl_fit_state* st, const gfl_fit_hyper* hp, int count, int flags, gfl_stream_t stream) {
+    if (count < 1 || (flags & ~(GFL_ITER_PRE_DONE | GFL_ITER_PRE_NEXT | GFL_ITER_ODD))) return GFL_ERR_INVALID;
+    int rc = fit_check(st, hp);
+    if (rc) return rc;
+    const int T = ((st->W + GFL_TILE - 1) / GFL_TILE) * ((st->H + GFL_TILE - 1) / GFL_TILE);
+    const FitWs w = carve(st);
+    const bool ok = fit_next_pre_ok(st, hp, w, T);
+    if ((flags & GFL_ITER_PRE_DONE) && !ok) return GFL_ERR_INVALID;
+    int parity = (flags & GFL_ITER_ODD) ? 1 : 0;
+    for (int j = 0; j < count; ++j) {
+        const int pre_done = j == 0 ? ((flags & GFL_ITER_PRE_DONE) ? 1 : 0) : (ok ? 1 : 0);
+        const int do_next = ok && (j + 1 < count || (flags & GFL_ITER_PRE_NEXT));
+        rc = fit_forward_impl(st, hp, stream, 0, pre_done, parity);
+        if (rc) return rc;
+        rc = fit_backward_step_impl(st, hp, stream, do_next, parity);
+        if (rc) return rc;
+        if (ok) parity ^= 1;
+    }
+    return GFL_OK;
+}
+
+int gfl_fit_next_preprocess_supported(const gfl_fit_state* st, const gfl_fit_hyper* hp) {
+    if (fit_check(st, hp)) return 0;
+    const int T = ((st->W + GFL_TILE - 1) / GFL_TILE) * ((st->H + GFL_TILE - 1) / GFL_TILE);
+    return fit_next_pre_ok(st, hp, carve(st), T) ? 1 : 0;
 }
 
 int gfl_fit_prepare_targets(const gfl_fit_state* st, gfl_stream_t stream) {
@@ -2521,6 +2690,9 @@ int gfl_fit_iteration(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stre
 #ifdef GFL_TRACE
 int gfl_debug_read_fwd_trace(long long* out, int n_tiles) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gfl::g_fwd_trace), (size_t)n_tiles * 8 * sizeof(long long));
+}
+int gfl_debug_read_fwd_trace2(long long* out, int n_values) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gfl::g_fwd_trace2), (size_t)n_values * sizeof(long long));
 }
 int gfl_debug_read_phase_trace(long long* out, int n_values) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gfl::g_phase_trace), (size_t)n_values * sizeof(long long));

@@ -53,6 +53,10 @@ def _declare(lib):
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(FitState), ctypes.POINTER(FitHyper), _P]
+    lib.gfl_fit_iterations.restype = ctypes.c_int
+    lib.gfl_fit_iterations.argtypes = [ctypes.POINTER(FitState), ctypes.POINTER(FitHyper), ctypes.c_int, ctypes.c_int, _P]
+    lib.gfl_fit_next_preprocess_supported.restype = ctypes.c_int
+    lib.gfl_fit_next_preprocess_supported.argtypes = [ctypes.POINTER(FitState), ctypes.POINTER(FitHyper)]
     lib.gfl_fit_snapshot.restype = ctypes.c_int
     lib.gfl_fit_snapshot.argtypes = [ctypes.POINTER(FitState), ctypes.POINTER(FitHyper), _P, _P, _P, ctypes.c_size_t, _P]
     lib.gfl_render_bwd.restype = ctypes.c_int
@@ -290,7 +294,7 @@ class FitEngine:
         L.check(self.lib.gfl_fit_backward_step(ctypes.byref(self.state()), ctypes.byref(self.hp), L.stream()),
                 "fit backward/step")
 
-    def iteration(self, use_graph=False, count=1, snapshot=False):
+    def iteration(self, use_graph=False, count=1, snapshot=False, flags=0):
         """``count`` full iterations; ``snapshot=True`` (count 1): followed by gfl_fit_snapshot into the engine's own
         image buffer -- returns that (3, H, W, 3) uint8 tensor, which the NEXT snapshot overwrites -- so that the
         iteration and the eight launches of the snapshot replay as ONE graph (launched one by one they left ~6 us
@@ -308,7 +312,7 @@ class FitEngine:
                 self._snap_out = torch.empty(3, self.H, self.W, 3, dtype=torch.uint8, device=self.dev)
             snap_args = (L.ptr(lut("turbo", self.dev)), L.ptr(self._snap_out), L.ptr(self._snap_ws), self._snap_ws.numel())
         gkey = ("snap", count) if snapshot else count
-        if use_graph and not PROFILE["mask"] and self._launched:
+        if use_graph and not PROFILE["mask"] and self._launched and not flags:
             key = bytes(self.state()) + bytes(self.hp)
             if self._graph_key != key:
                 with _GRAPH_LOCK:
@@ -336,9 +340,10 @@ class FitEngine:
                         with torch.cuda.stream(side):
                             g.capture_begin(capture_error_mode="thread_local")
                             try:
-                                for _ in range(count):
-                                    L.check(self.lib.gfl_fit_iteration(ctypes.byref(st), ctypes.byref(hp), L.stream()),
-                                            "fit iteration (capture)")
+                                # (several iterations in one call: between two plain ones the next preprocess runs in
+                                #  the tail of the per-splat launch, include/gflow_hip.h)
+                                L.check(self.lib.gfl_fit_iterations(ctypes.byref(st), ctypes.byref(hp), count, 0, L.stream()),
+                                        "fit iterations (capture)")
                                 if snapshot:
                                     L.check(self.lib.gfl_fit_snapshot(ctypes.byref(st), ctypes.byref(hp), *snap_args,
                                                                       L.stream()), "snapshot (capture)")
@@ -351,9 +356,8 @@ class FitEngine:
                 self._graphs[gkey] = g
             g.replay()
             return self._snap_out if snapshot else None
-        for _ in range(count):
-            L.check(self.lib.gfl_fit_iteration(ctypes.byref(self.state()), ctypes.byref(self.hp), L.stream()),
-                    "fit iteration")
+        L.check(self.lib.gfl_fit_iterations(ctypes.byref(self.state()), ctypes.byref(self.hp), count, int(flags), L.stream()),
+                "fit iterations")
         self._launched = True          # every kernel is loaded now: capture is safe from here on
         if snapshot:
             L.check(self.lib.gfl_fit_snapshot(ctypes.byref(self.state()), ctypes.byref(self.hp), *snap_args, L.stream()),
@@ -430,9 +434,15 @@ class FitEngine:
     def check_overflow(self):
         """Blocking read of the pair-list overflow flag (sticky on the device); raises if pairs were dropped."""
         self._ovf_event = None
-        if int(self.overflow.item()):
+        code = int(self.overflow.item())
+        if code:
             self.overflow.zero_()
-            raise RuntimeError(f"FitEngine: more than K_cap={self.K_cap} splat-tile pairs; raise K_cap")
+            raise RuntimeError(self._overflow_message(code))
+
+    def _overflow_message(self, code):
+        if code == 2:
+            return "FitEngine: an iteration was told its preprocess had been run by the previous one's tail, and it had not"
+        return f"FitEngine: more than K_cap={self.K_cap} splat-tile pairs; raise K_cap"
 
     def watch_overflow(self):
         """The same check without stopping the host: the flag is copied to pinned memory behind the work queued so
@@ -452,7 +462,7 @@ class FitEngine:
             self._ovf_event = None
             if int(self._ovf_host[0]):
                 self.overflow.zero_()
-                raise RuntimeError(f"FitEngine: more than K_cap={self.K_cap} splat-tile pairs; raise K_cap")
+                raise RuntimeError(self._overflow_message(int(self._ovf_host[0])))
 
     def loss_terms(self):
         """(loss_rgb, loss_depth) of the last backward_step as device scalars (trainer.py:460-462,485)."""

@@ -263,7 +263,8 @@ typedef struct gfl_fit_state {
     float *render, *final_T;                    /* [4][H][W], [H][W] */
     int32_t* n_contrib;                         /* [H][W] */
     float *d_render, *err_px, *sums;            /* [4][H][W], [H][W], [8] as gfl_loss_fwd_bwd */
-    int32_t *tile_offsets, *ids, *tile_range, *overflow; /* [T+1], [K_cap], [T][2], [1] */
+    int32_t *tile_offsets, *ids, *tile_range, *overflow; /* [T+1], [K_cap], [T][2], [1] (sticky: 1 = more than K_cap pairs,
+                                                          * 2 = GFL_ITER_PRE_DONE without a preprocess) */
     void* workspace;
     size_t workspace_bytes;                     /* >= gfl_fit_workspace_bytes() */
 } gfl_fit_state;
@@ -293,6 +294,25 @@ int gfl_fit_forward(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream
 /* loss + backward + optimiser step on the state gfl_fit_forward left behind */
 int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream);
 int gfl_fit_iteration(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream);
+/* ``count`` iterations back to back (trainer.py:387-558 ``count`` times; what a caller captures into ONE graph).  Between
+ * two plain iterations whose camera cannot move (step_camera / lr_camera as above, not the camera-only stage, no
+ * footprint mask) the NEXT iteration's preprocess -- activations, projection, EWA, tile histogram of the row Adam has
+ * just stepped -- runs in the tail of the per-splat backward + Adam launch: the next iteration has no preprocess launch
+ * of its own (one launch and one read of the rows less; results bit-identical to ``count`` calls of gfl_fit_iteration
+ * up to the order of the backward's LDS adds, which differs from run to run anyway).  flags, for callers that chain
+ * calls themselves (0 is always right):
+ *   GFL_ITER_PRE_NEXT  the LAST iteration's tail prepares the next call's first forward as well; rec / uv / depth then
+ *                      describe the NEXT forward, not the last one -- the next call must pass GFL_ITER_PRE_DONE;
+ *   GFL_ITER_PRE_DONE  the first forward's preprocess has been run by the previous call's tail (checked on the device:
+ *                      otherwise *overflow becomes 2);
+ *   GFL_ITER_ODD       the first iteration uses the second of the two slot-pool sets (iterations alternate between them:
+ *                      pass it after an odd number of chained iterations).
+ * gfl_fit_next_preprocess_supported: 1 if iterations with this state / these hyper-parameters take the short cut. */
+#define GFL_ITER_PRE_DONE 1
+#define GFL_ITER_PRE_NEXT 2
+#define GFL_ITER_ODD 4
+int gfl_fit_iterations(const gfl_fit_state* st, const gfl_fit_hyper* hp, int count, int flags, gfl_stream_t stream);
+int gfl_fit_next_preprocess_supported(const gfl_fit_state* st, const gfl_fit_hyper* hp);
 /* ---- the fused rasteriser as a differentiable operator (no loss, no optimiser) ------------------------
  * render(gaussians, camera) -> {rgb, depth_map, uv, depth} = render_multiple(input_group, ["rgb", "uv", "depth",
  * "depth_map"]) of render.py:6-108 in ONE call (last row), and its backward.

@@ -663,3 +663,79 @@ def test_more_pairs_than_the_lists_hold_is_reported_not_silent(setup):
     torch.cuda.synchronize()
     with pytest.raises(RuntimeError, match="K_cap"):
         small.poll_overflow()
+
+
+def _copy_engine_state(src, dst):
+    n = src.N
+    for a in ("params", "adam_m", "adam_v"):
+        getattr(dst, a)[:n].copy_(getattr(src, a)[:n])
+    for a in ("pose", "pose_m", "pose_v", "depth_ab", "ab_m", "ab_v", "step"):
+        getattr(dst, a).copy_(getattr(src, a))
+
+
+@pytest.mark.parametrize("with_scale_term", [False, True])
+def test_next_preprocess_in_the_adam_tail_is_the_standalone_preprocess(setup, with_scale_term):
+    """gfl_fit_iterations: between two plain iterations the NEXT iteration's preprocess runs in the tail of the per-splat
+    backward + Adam launch.  Held against the stand-alone launch on the SAME stepped rows: records, pair count, sorted
+    ids and tile ranges bit for bit (GFL_ITER_PRE_NEXT leaves the next forward's records behind; a second engine that is
+    given the stepped rows runs the ordinary forward)."""
+    from gflow_amd import _lib as L
+    import ctypes
+    s, raw, img, dep = setup
+    hyper = dict(lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0, lr=4e-3, lr_camera=0.0, total_iters=100)
+    if with_scale_term:
+        hyper["lambda_scale"] = 0.5
+    a = _engine(raw, s, img, dep, pose=POSE, **hyper)
+    b = _engine(raw, s, img, dep, pose=POSE, **hyper)
+    if with_scale_term:
+        flags = (torch.arange(a.cap, device=DEV) % 3).to(torch.uint8)          # still / moving / unlabelled rows
+        for e in (a, b):
+            e.set_regularisers(row_flags=flags)
+    assert a.lib.gfl_fit_next_preprocess_supported(ctypes.byref(a.state()), ctypes.byref(a.hp)) == 1
+    PRE_DONE, PRE_NEXT, ODD = 1, 2, 4
+    a.iteration(count=1, flags=PRE_NEXT)             # iteration 0; its tail prepares iteration 1's forward
+    rec_next = a.rec[:a.N].clone()
+    _copy_engine_state(a, b)
+    b.forward()                                      # the ordinary forward on the same stepped rows
+    assert torch.equal(rec_next, b.rec[:b.N])
+    a.iteration(count=1, flags=PRE_DONE | ODD)       # iteration 1 without a preprocess launch of its own
+    a.check_overflow()
+    assert a.K == b.K > 0
+    assert torch.equal(a.tile_range, b.tile_range) and torch.equal(a.ids[:a.K], b.ids[:b.K])
+    assert torch.equal(a.render, b.render)
+    b.backward_step()
+    for name in ("params", "adam_m", "adam_v"):
+        x, y = getattr(a, name)[:a.N], getattr(b, name)[:b.N]
+        assert (x - y).abs().max().item() <= 1e-5 * max(1.0, y.abs().max().item()), name
+    assert int(a.step.item()) == int(b.step.item()) == 2
+    # a claim without a preprocess is caught on the device
+    a.iteration(count=1, flags=PRE_DONE)
+    with pytest.raises(RuntimeError, match="preprocess"):
+        a.check_overflow()
+
+
+def test_four_iterations_in_one_call_track_four_single_iterations(setup):
+    s, raw, img, dep = setup
+    hyper = dict(lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0, lr=4e-3, lr_camera=0.0, total_iters=100)
+    a = _engine(raw, s, img, dep, pose=POSE, **hyper)
+    b = _engine(raw, s, img, dep, pose=POSE, **hyper)
+    for use_graph in (False, True, True):
+        a.iteration(count=4, use_graph=use_graph)
+        for _ in range(4):
+            b.iteration()
+    a.check_overflow()
+    assert int(a.step.item()) == int(b.step.item()) == 12
+    assert a.K == b.K
+    rel = ((a.params[:a.N] - b.params[:b.N]).norm() / b.params[:b.N].norm()).item()
+    assert rel < 1e-5, rel
+    assert (a.render - b.render).abs().max().item() < 1e-3
+    assert torch.allclose(a.rec[:a.N], b.rec[:b.N], rtol=1e-3, atol=1e-3)       # rec = the LAST forward's in both
+    assert torch.allclose(a.depth_ab, b.depth_ab, rtol=1e-5, atol=1e-7) and torch.allclose(a.sums, b.sums, rtol=1e-4)
+    # the camera-only stage and a moving camera do not qualify: same entry, ordinary launches
+    import ctypes
+    a.hp.lr_camera = 1e-3
+    assert a.lib.gfl_fit_next_preprocess_supported(ctypes.byref(a.state()), ctypes.byref(a.hp)) == 0
+    b.hp.lr_camera = 1e-3
+    a.iteration(count=2)
+    b.iteration(); b.iteration()
+    assert torch.allclose(a.pose, b.pose, rtol=1e-4, atol=1e-6)

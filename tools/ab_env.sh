@@ -1,11 +1,14 @@
 #!/bin/bash
-# A/B of an environment switch of the library on ONE box:  gpurun -- 'bash tools/ab_env.sh GFL_CAMERA_KERNEL=1 [rounds]'
-# A = default, B = with the switch.  Prints ms_per_step and the stage times of both, alternating.
-SW=$1
-for r in $(seq 1 ${2:-3}); do
-  for v in A B; do
-    if [ $v = B ]; then export $SW; else unset ${SW%%=*}; fi
-    echo -n "$v: clip "; python tools/profile_clip.py 8 10 | grep "^total" | cut -d= -f2
-    echo -n "$v: step "; python bench.py --steps 200 --warmup 50 --no-clip --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); s=d['stage_ms']; print(round(d['ms_per_step'],4), {k: round(v*1e3,1) for k,v in s.items()})"
+# A/B of one environment switch on ONE box, alternating: bench.py's step (pinned window) with VAR=A and VAR=B, R times each.
+#   gpurun -- bash tools/ab_env.sh GFL_NEXT_PRE 1 0 [repeats] [extra bench flags]
+VAR=$1; A=$2; B=$3; R=${4:-3}; shift 4
+for r in $(seq 1 $R); do
+  for v in $A $B; do
+    env $VAR=$v python bench.py --no-clip --no-cpu-baseline --steps 200 --warmup 20 "$@" 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline())
+st=d['stage_ms']
+print('$VAR=$v', 'ms_per_step %.4f' % d['ms_per_step'], 'K %.0f' % d['config']['splat_tile_pairs_K'], ' '.join('%s %.1f' % (k, 1e3*x) for k,x in st.items()))
+"
   done
 done

@@ -158,3 +158,21 @@ if FWD:
     heavy = total > np.percentile(total, 95)
     print("terminated pixels per tile (of 256): all tiles mean %.1f ; 5%% longest lists mean %.1f max %d" %
           (done_px.mean(), done_px[heavy].mean(), done_px.max()))
+
+if FWD and hasattr(lib, "gfl_debug_read_fwd_trace2"):
+    # the sixteen quarter waves of the long first tiles: where does a wave's time go?
+    n2 = 4096 * 16 * 4
+    buf2 = (ctypes.c_longlong * n2)()
+    f2 = lib.gfl_debug_read_fwd_trace2
+    f2.restype = ctypes.c_int
+    f2.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    assert f2(buf2, n2) == 0
+    b = np.frombuffer(buf2, dtype=np.int64).reshape(4096, 16, 4)
+    live = np.nonzero(b[:, :, 1].sum(1) > 0)[0]
+    print("long first tiles walked as blocks:", len(live))
+    tr_rng = tr.engine.tile_range.cpu().numpy()
+    for t in sorted(live, key=lambda t: -(b[t, :, 0] + b[t, :, 1]).max())[:8]:
+        w = int(np.argmax(b[t, :, 0] + b[t, :, 1]))
+        print("  tile %4d list %4d | slowest wave %2d: staging %.1f us, walk %.1f us, steps %d, units %d | mean over 16 waves: staging %.1f walk %.1f steps %.0f"
+              % (t, tr_rng[t, 1] - tr_rng[t, 0], w, b[t, w, 0] / 100.0, b[t, w, 1] / 100.0, b[t, w, 2], b[t, w, 3],
+                 b[t, :, 0].mean() / 100.0, b[t, :, 1].mean() / 100.0, b[t, :, 2].mean()))
