@@ -26,6 +26,7 @@ SIGNATURES = {
     "gfl_version": (c_int, []),
     "gfl_constants": (c_int, [_P]),
     "gfl_ewa_on_mfma": (c_int, []),
+    "gfl_bwd_rows_on": (c_int, []),
     "gfl_status_string": (ctypes.c_char_p, [c_int]),
     "gfl_last_hip_error": (c_int, []),
     "gfl_reduce_workspace_bytes": (c_size_t, [c_int]),

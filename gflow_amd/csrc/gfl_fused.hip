@@ -1036,9 +1036,9 @@ struct LossTail {
     float* d_extr_out;                      // [12]: zeros (not computed in such an iteration)
 };
 
+template <int B = 256>
 __device__ void loss_tail(const LossTail& t) {
     constexpr int NV = 5;                   // mse, ssim, depth, d/da, d/db
-    constexpr int B = 256;
     __shared__ float red[B / 64][NV];
     __shared__ float ge[NV];
     float ab[2] = {0.f, 0.f}, abm[2] = {0.f, 0.f}, abv[2] = {0.f, 0.f};
@@ -1299,6 +1299,298 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
         tr[4 + wave] = ((long long)(trace_lanes | ((hw >> 4) & 3) << 28) << 32) | (unsigned)units;   // bits 60-61: this wave's SIMD
     }
 #endif
+  }
+}
+
+// ------------------------------------------------------------------ backward blend, "rows" formulation (round 4)
+// The kernel above gives a wave the 64 pixels of an 8x8 block and ONE splat per step: every step ends in a reduction of
+// ten sums over the 64 lanes (27 of its ~65 VALU instructions), 41 % of the lanes see the splat at all, and the
+// transmittance recurrence is one dependent chain per pixel.  Here a wave owns a 4x4 QUARTER of the tile (sixteen waves,
+// one 1024-lane workgroup per tile item) and a step takes SIXTEEN splats of the quarter's hit list at once:
+//     lane = (s, r): s = lane & 15 = the splat of the step (list order along the lanes of a 16-lane row),
+//                    r = lane >> 4 = the pixel column of the quarter; four passes g = 0..3 over the quarter's pixel rows.
+// * The recurrences along the list become ROW SCANS: T in front of splat k = T_in * prod_{j<=k} 1 / (1 - a_j)  (four DPP
+//   row_shr multiplies), S behind splat k = S_in + sum_{j<k} h_j w_j (four DPP row_shr adds); the carries for the next
+//   step are lane 15's values (ds_swizzle broadcast inside the row).
+// * The sums over the PIXELS of a splat need no cross-lane work inside a pass: a lane adds its four pixels (one per pass)
+//   in registers; once per STEP the four rows are folded with two permlane swap stages (the first two stages of the
+//   reduce-scatter above: ten values -> three registers) and every lane adds its components into the splat's LDS row.
+// ~290 VALU instructions per step of sixteen (splat, quarter) units = ~18 per unit, against ~65 per (splat, 8x8 block)
+// unit = ~30 per quarter-sized share of it; 4x4 units that are evaluated at all have 63 % of their lanes inside the splat
+// (tools/lane_efficiency.py: 1.08 M such units against 0.42 M 8x8 units on the bench scene).
+// Products and sums along the list are formed in tree order by the scans, not one after the other: gradients differ from
+// the kernel above in the last bits (they already differ from run to run there: unordered LDS adds).  The skip / keep
+// decision of every (pixel, splat) pair is the forward's: the same splat_alpha2, the same n_contrib.
+#ifndef GFL_ROWS_BATCH
+#define GFL_ROWS_BATCH 128
+#endif
+constexpr int RB_BATCH = GFL_ROWS_BATCH;   // staged splats per batch (LDS: 96 B per slot + 8 KB of pixel state -> 8 workgroups per CU at 128)
+
+#define GFL_ROW_SHR(old, val, n) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)), __builtin_bit_cast(int, (val)), 0x110 + (n), 0xF, 0xF, false))
+
+// inclusive scans along the sixteen lanes of a row (lanes shifted in from outside the row keep the identity)
+__device__ __forceinline__ float row_scan_mul(float x) {
+    x *= GFL_ROW_SHR(1.0f, x, 1);
+    x *= GFL_ROW_SHR(1.0f, x, 2);
+    x *= GFL_ROW_SHR(1.0f, x, 4);
+    x *= GFL_ROW_SHR(1.0f, x, 8);
+    return x;
+}
+__device__ __forceinline__ float row_scan_add(float x) {
+    x += GFL_ROW_SHR(0.0f, x, 1);
+    x += GFL_ROW_SHR(0.0f, x, 2);
+    x += GFL_ROW_SHR(0.0f, x, 4);
+    x += GFL_ROW_SHR(0.0f, x, 8);
+    return x;
+}
+
+// the 4x4 quarters of two 8x8 blocks (b0, b0 + 1) of a tile a staged splat reaches with alpha >= 1/255:
+// bit 4 * (b - b0) + c, c = the quarter inside the block (x fastest)
+__device__ __forceinline__ unsigned quarter_mask_pair(const float4& p0, const float4& p1, float cutoff, int tx0, int ty0, int b0) {
+    const BlockTest t = block_test(p0, p1, cutoff);
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int b = b0 + k;
+        const float bx = (float)(tx0 + (b & 1) * 8), by = (float)(ty0 + (b >> 1) * 8);
+        if (!box_hit(t, bx, bx + 7.f, by, by + 7.f)) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float x_lo = bx + (float)((c & 1) * 4), y_lo = by + (float)((c >> 1) * 4);
+            if (box_hit(t, x_lo, x_lo + 3.f, y_lo, y_lo + 3.f)) m |= 1u << (4 * k + c);
+        }
+    }
+    return m;
+}
+
+struct PixState {            // per pixel of the workgroup's tile, in LDS: 32 bytes
+    float T, S;
+    int last, pad;
+    float g0, g1, g2, g3;
+};
+
+template <int SUMS>
+__global__ void __launch_bounds__(256, 5) fused_blend_bwd_rows_kernel(
+    const float* __restrict__ rec, const int32_t* __restrict__ ids, const int32_t* __restrict__ tile_range, float bg, int W,
+    int H, int gx, const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib,
+    const float* __restrict__ d_out, float* __restrict__ pair_grad, TileQueue queue, int32_t* __restrict__ tile_work,
+    const float* __restrict__ ckpt, const float* __restrict__ render, LossTail ltail) {
+    if (ltail.enabled && blockIdx.x == gridDim.x - queue.nq) loss_tail(ltail);
+    constexpr int FB_ = RB_BATCH;
+    static_assert(2 * FB_ == 256, "two staging lanes per slot");
+    __shared__ RecLDS recs[FB_ + 1];                 // recs[FB_]: the null record (opacity 0)
+    __shared__ float acc[FB_ + 1][REC];              // acc[FB_]: where the null record's (zero) sums go
+    __shared__ unsigned char s_mask[2][FB_];         // quarters of blocks {0, 1} / {2, 3} a slot's splat reaches
+    __shared__ unsigned char s_hits[4][FB_];         // a wave's hit list of the quarter it is walking
+    __shared__ __attribute__((aligned(16))) PixState s_px[4][64];
+    __shared__ int32_t s_max_last;
+    __shared__ int32_t s_ticket;
+    __shared__ int32_t s_simd[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ls = lane & 15, lr = lane >> 4;        // the splat of a step, the pixel column of the quarter
+    if (tid == 0) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        recs[FB_].p0 = z; recs[FB_].p1 = z; recs[FB_].p2 = z;
+    }
+    // which components of a splat's row this lane adds after the two swap stages (gfl_common.hpp): by row of the wave
+    const int hi = lane >> 5, odd = (lane >> 4) & 1;
+    unsigned hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    const int simd = (hw_id >> 4) & 3;
+    if (lane == 0) s_simd[wave] = simd;
+    __syncthreads();
+    const bool simd_ok = ((1 << s_simd[0]) | (1 << s_simd[1]) | (1 << s_simd[2]) | (1 << s_simd[3])) == 15;
+  for (bool first = true;; first = false) {
+    const TileItem item = next_item(queue, &s_ticket, first, true);
+    const int tile = item.tile;
+    if (tile < 0) break;
+    const unsigned plan = item.plan;
+    const bool plan_ok = simd_ok && ((1 << (plan & 3)) | (1 << ((plan >> 2) & 3)) | (1 << ((plan >> 4) & 3)) | (1 << ((plan >> 6) & 3))) == 15;
+    const int blk = plan_ok ? (int)((plan >> (2 * simd)) & 3u) : wave;           // the 8x8 block of the tile this wave walks
+    const int tx = tile % gx, ty = tile / gx;
+    const int bx0 = tx * GFL_TILE + (blk & 1) * 8, by0 = ty * GFL_TILE + (blk >> 1) * 8;
+    const int start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
+    const int total = end - start;
+    const int parts = item.part >= 0 ? heavy_parts(total) : 1;
+    if (item.part >= parts) continue;                // this tile has fewer segments
+    const int seg = heavy_seg(total, parts);
+    const bool last_part = item.part < 0 || item.part == parts - 1;      // the farthest segment (or the whole tile)
+    int units = 0;
+
+    // ---- per-pixel state into LDS: lane = pixel of the 8x8 block ((y << 3) | x), stored by (quarter, row, column)
+    int q_last;                                      // deepest contributor of this lane's quarter (lanes 16 c .. 16 c + 15)
+    {
+        const int lx = lane & 7, ly = lane >> 3;
+        const int px = bx0 + lx, py = by0 + ly;
+        PixState ps;
+        ps.T = 1.f; ps.S = 0.f; ps.last = 0; ps.pad = 0; ps.g0 = 0.f; ps.g1 = 0.f; ps.g2 = 0.f; ps.g3 = 0.f;
+        if (px < W && py < H) {
+            const size_t pix = (size_t)py * W + px, plane = (size_t)H * W;
+            ps.last = n_contrib[pix];
+            ps.g0 = d_out[pix]; ps.g1 = d_out[plane + pix]; ps.g2 = d_out[2 * plane + pix]; ps.g3 = d_out[3 * plane + pix];
+            if (last_part) {
+                ps.T = final_T[pix];
+                ps.S = ps.T * bg * (ps.g0 + ps.g1 + ps.g2 + ps.g3);
+            } else {
+                const float* ck = ckpt + ((size_t)item.queue * (HEAVY_PARTS - 1) + item.part) * 5 * 256 + blk * 64 + lane;
+                ps.T = ck[0];
+                ps.S = ps.g0 * (render[pix] - ck[256]) + ps.g1 * (render[plane + pix] - ck[512]) +
+                       ps.g2 * (render[2 * plane + pix] - ck[768]) + ps.g3 * (render[3 * plane + pix] - ck[1024]);
+            }
+        }
+        const int c = ((ly >> 2) << 1) | (lx >> 2);
+        const int slot = c * 16 + (ly & 3) * 4 + (lx & 3);
+        float4* dst = reinterpret_cast<float4*>(&s_px[wave][slot]);
+        dst[0] = make_float4(ps.T, ps.S, __int_as_float(ps.last), 0.f);
+        dst[1] = make_float4(ps.g0, ps.g1, ps.g2, ps.g3);
+        // the block's deepest contributor (for the tile's depth_n) and each quarter's (for its hit list)
+        int wl = ps.last;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) wl = max(wl, __shfl_xor(wl, off));
+        if (tid == 0) s_max_last = 0;
+        __syncthreads();
+        if (lane == 0) atomicMax(&s_max_last, wl);
+        __syncthreads();
+        // (after the barrier: the pixel state is visible to the whole wave)
+        int ql = 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ql = max(ql, s_px[wave][lr * 16 + g * 4 + (ls & 3)].last);
+        // lanes of row lr now hold the maximum over the quarter lr's column (ls & 3); fold the four columns
+        ql = max(ql, __shfl_xor(ql, 1));
+        ql = max(ql, __shfl_xor(ql, 2));
+        q_last = ql;                                 // row lr: quarter lr
+    }
+    const int depth_n = min(total, (int)s_max_last);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // this item walks list positions hi_pos-1 down to lo
+    const int lo = item.part > 0 ? item.part * seg : 0;
+    const int hi_pos = last_part ? depth_n : min((item.part + 1) * seg, depth_n);
+    // pairs behind the deepest contributor of the tile get a zero row
+    if (last_part)
+        for (int p = depth_n + tid; p < total; p += 256) {
+            float4* o = reinterpret_cast<float4*>(pair_grad + (size_t)(start + p) * PG);
+            o[0] = zero4; o[1] = zero4; o[2] = zero4;
+        }
+
+    for (int r0 = 0; r0 < hi_pos - lo; r0 += FB_) {
+        // two staging lanes per slot: both fetch the record, each tests the quarters of two of the tile's four blocks
+        const int sslot = tid & (FB_ - 1), shalf = tid >> 7;
+        const int pos_t = hi_pos - 1 - r0 - sslot;                        // slot <-> list position
+        __syncthreads();
+        if (pos_t >= lo) {
+            const int gid = ids[start + pos_t];
+            const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)gid * REC);
+            const float4 p0 = r4[0], p1 = r4[1], p2 = r4[2];
+            if (shalf == 0) { recs[sslot].p0 = p0; recs[sslot].p1 = p1; recs[sslot].p2 = p2; }
+            s_mask[shalf][sslot] = (unsigned char)quarter_mask_pair(p0, p1, p2.z, tx * GFL_TILE, ty * GFL_TILE, 2 * shalf);
+        }
+        if (tid <= FB_) {
+            float4* az = reinterpret_cast<float4*>(&acc[tid][0]);
+            az[0] = zero4; az[1] = zero4; az[2] = zero4;
+        }
+        __syncthreads();
+        const int cnt = min(FB_, hi_pos - lo - r0);
+        for (int c = 0; c < 4; ++c) {                // the four quarters of this wave's block
+            const int c_last = __shfl(q_last, 16 * c);
+            const int mbit = (blk & 1) * 4 + c;
+            // ---- the quarter's hit list of the batch, in slot order = back to front
+            int n_hit = 0;
+            for (int c0 = 0; c0 < cnt; c0 += 64) {
+                const int slot = c0 + lane;
+                const bool hit = slot < cnt && (hi_pos - 1 - r0 - slot) < c_last && ((s_mask[blk >> 1][slot] >> mbit) & 1);
+                const unsigned long long bal = __ballot(hit);
+                if (hit) s_hits[wave][n_hit + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0))] = (unsigned char)slot;
+                n_hit += (int)__popcll(bal);
+            }
+            if (n_hit == 0) continue;
+            units += n_hit;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the list is read back by other lanes of this wave)
+            const float fx = (float)(bx0 + (c & 1) * 4 + lr);
+            const int fy0 = by0 + (c >> 1) * 4;
+            for (int st = 0; st < n_hit; st += 16) {
+                const bool have = st + ls < n_hit;
+                const int j = have ? (int)s_hits[wave][st + ls] : FB_;
+                const int pos = have ? hi_pos - 1 - r0 - j : 0x7fffffff;
+                const float4 p0 = recs[j].p0, p1 = recs[j].p1, p2 = recs[j].p2;
+                const float dx = p0.x - fx;
+                float v[10];
+#pragma unroll
+                for (int k = 0; k < 10; ++k) v[k] = 0.f;
+#pragma unroll 1
+                for (int g = 0; g < 4; ++g) {
+                    PixState* sp = &s_px[wave][c * 16 + g * 4 + lr];
+                    const float4 st0 = *reinterpret_cast<const float4*>(sp);
+                    const float4 gq = *(reinterpret_cast<const float4*>(sp) + 1);
+                    const float fy = (float)(fy0 + g);
+                    float alpha, G;
+                    const bool valid = splat_alpha2(p0, p1, fx, fy, alpha, G) && (pos < __float_as_int(st0.z));
+                    const float a_eff = valid ? alpha : 0.f;
+                    const float rom = __builtin_amdgcn_rcpf(1.f - a_eff);
+                    const float Tk = st0.x * row_scan_mul(rom);                     // T in front of this splat
+                    const float h = fmaf(gq.x, p1.z, fmaf(gq.y, p1.w, fmaf(gq.z, p2.x, gq.w * p2.y)));
+                    const float w = a_eff * Tk;
+                    const float hw = h * w;
+                    const float incl = row_scan_add(hw);
+                    const float Sk = st0.y + (incl - hw);                            // S behind this splat
+                    const float dalpha = valid ? fmaf(Tk, h, -(Sk * rom)) : 0.f;
+                    if (ls == 15) *reinterpret_cast<float2*>(sp) = make_float2(Tk, Sk + hw);      // the carries of the next step
+                    const float dy = p0.y - fy;
+                    const float t5 = G * dalpha;
+                    const float dpow = p1.y * t5;
+                    const float mx = -dx * dpow, my = -dy * dpow;
+                    v[0] += mx;
+                    v[1] += my;
+                    v[2] = fmaf(dx, mx, v[2]);
+                    v[3] = fmaf(dx, my, v[3]);
+                    v[4] = fmaf(dy, my, v[4]);
+                    if (SUMS >= 7) v[5] += t5;
+                    if (SUMS == 10) { v[6] = fmaf(w, gq.x, v[6]); v[7] = fmaf(w, gq.y, v[7]); v[8] = fmaf(w, gq.z, v[8]); }
+                    v[9] = fmaf(w, gq.w, v[9]);
+                }
+                // ---- fold the four rows (the four pixel columns) and add into the splat's LDS row
+                float* arow = &acc[j][0];
+                if (SUMS == 10) {
+                    float a[5] = {v[0], v[2], v[4], v[6], v[8]}, b[5] = {v[1], v[3], v[5], v[7], v[9]};
+                    permlane32_swap_x5(a, b);
+                    float w5[5];
+#pragma unroll
+                    for (int m = 0; m < 5; ++m) w5[m] = a[m] + b[m];               // lanes 0-31: component 2m, 32-63: 2m + 1
+                    float cc[3] = {w5[0], w5[2], w5[4]}, dd[3] = {w5[1], w5[3], 0.f};
+                    permlane16_swap_x3(cc, dd);
+                    atomicAdd(&arow[2 * odd + hi], cc[0] + dd[0]);
+                    atomicAdd(&arow[4 + 2 * odd + hi], cc[1] + dd[1]);
+                    if (!odd) atomicAdd(&arow[8 + hi], cc[2] + dd[2]);
+                } else {
+                    // SUMS 7: v0..v5, v9; SUMS 6: v0..v4, v9 (the colour sums are neither formed nor folded)
+                    float a[3] = {v[0], v[2], v[4]}, b[3] = {v[1], v[3], SUMS == 7 ? v[5] : v[9]};
+                    float e = v[9], f = 0.f;
+                    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %3\n\tv_permlane32_swap_b32 %1, %4\n\tv_permlane32_swap_b32 %2, %5"
+                        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));
+                    const float w3[3] = {a[0] + b[0], a[1] + b[1], a[2] + b[2]};  // lower half: v0 v2 v4, upper: v1 v3 v5|v9
+                    if (SUMS == 7) { permlane32_swap(e, f); }
+                    const float w9 = e + f;                                       // SUMS 7, lower half: v9 over lanes i, i + 32
+                    float cc[2] = {w3[0], w3[2]}, dd[2] = {w3[1], SUMS == 7 ? w9 : 0.f};
+                    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3"
+                        : "+v"(cc[0]), "+v"(cc[1]), "+v"(dd[0]), "+v"(dd[1]));
+                    // cc0 + dd0 by row (hi, odd): component 2 odd + hi of {v0 v1 v2 v3};
+                    // cc1 + dd1: even rows: component 4 (hi 0) / 5 or 9 (hi 1); odd rows: v9 (SUMS 7, hi 0 only)
+                    atomicAdd(&arow[2 * odd + hi], cc[0] + dd[0]);
+                    const float x1 = cc[1] + dd[1];
+                    if (!odd) atomicAdd(&arow[hi == 0 ? 4 : (SUMS == 7 ? 5 : 9)], x1);
+                    else if (SUMS == 7 && hi == 0) atomicAdd(&arow[9], x1);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < FB_ && pos_t >= lo) {
+            const float4* a4 = reinterpret_cast<const float4*>(&acc[tid][0]);
+            float4* o = reinterpret_cast<float4*>(pair_grad + (size_t)(start + pos_t) * PG);
+            o[0] = a4[0]; o[1] = a4[1]; o[2] = a4[2];
+        }
+    }
+    // work feedback for the next iteration's schedule, per 8x8 block (gfl_sched.hpp): (splat, quarter) units
+    if (lane == 0) atomicAdd(&tile_work[4 * tile + blk], units + 1);
   }
 }
 
@@ -2089,6 +2381,20 @@ static int blend_grid(int T, int max_per_cu = BLEND_WG_PER_CU) {
     return nq * per;
 }
 
+// GFL_BWD_ROWS=1: the "rows" formulation of the backward blend (fused_blend_bwd_rows_kernel: a step = sixteen splats x
+// four pixels, recurrences as row scans, no cross-lane reduction per splat) instead of the kernel of rounds 1-3.  Parity-
+// green, measured in round 4 on the bench window (K = 264 k): 127.5 us against 71 us -- 30.8 M VALU instructions per launch
+// against 32.2 M (its steps are 70 % full and cost ~290 instructions each) at 39 % VALU busy against 76 %.  Off by default.
+static bool bwd_rows() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GFL_BWD_ROWS");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+int gfl_bwd_rows_on(void) { return bwd_rows() ? 1 : 0; }
+
 size_t gfl_fit_workspace_bytes(int cap, int K_cap, int W, int H) {
     if (cap < 0 || K_cap < 0 || W <= 0 || H <= 0) return 0;
     const size_t T = (size_t)((W + GFL_TILE - 1) / GFL_TILE) * ((H + GFL_TILE - 1) / GFL_TILE);
@@ -2228,12 +2534,17 @@ static int fit_check(const gfl_fit_state* st, const gfl_fit_hyper* hp) {
 // kernels of gfl_bin.hip / gfl_loss.hip reused through their C entry points
 // (gfl_loss_fwd_bwd, gfl_tile_sort_only: declared in gflow_hip.h)
 
-// GFL_NEXT_PRE=0: every iteration has its own preprocess launch (rounds 1-3)
+// GFL_NEXT_PRE=1: between two plain iterations of one gfl_fit_iterations call the next preprocess runs in the tail of the
+// per-splat launch (round 4).  Records and lists are bit-identical to the stand-alone launch; measured NEUTRAL on the bench
+// window (the per-splat launch needs the binning's 512-splat workgroups for it: 22.0 -> 25.2 us, + 7.4 us of tail, against
+// the 10.8 us launch it replaces), and the two instantiations of the per-splat kernel round their chain rule differently
+// in the last bit, which Adam's first steps amplify: fits that group their iterations differently no longer agree to the
+// order of the LDS adds.  Off by default.
 static bool next_pre_enabled() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("GFL_NEXT_PRE");
-        v = (e && e[0] == '0') ? 0 : 1;
+        v = (e && e[0] == '1') ? 1 : 0;
     }
     return v == 1;
 }
@@ -2539,11 +2850,16 @@ static int fit_backward_step_impl(const gfl_fit_state* st, const gfl_fit_hyper* 
     {
         StageScope p(ST_BLEND_BWD, s);
         const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters + w.sched.nq, w.sched.nq, w.sched.cap_q};
-        auto kern = !bwd_geom_only() ? fused_blend_bwd_kernel<10>
-                    : (hp->freeze_all_splats ? fused_blend_bwd_kernel<6>
-                                             : (hp->freeze_rgb ? fused_blend_bwd_kernel<7> : fused_blend_bwd_kernel<10>));
-        kern<<<blend_grid(T), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx, st->final_T, st->n_contrib,
-                                           st->d_render, w.pair_grad, q, w.sched.work, w.ckpt, st->render, lt);
+        const int sums = !bwd_geom_only() ? 10 : (hp->freeze_all_splats ? 6 : (hp->freeze_rgb ? 7 : 10));
+        if (bwd_rows()) {
+            auto kern = sums == 6 ? fused_blend_bwd_rows_kernel<6> : (sums == 7 ? fused_blend_bwd_rows_kernel<7> : fused_blend_bwd_rows_kernel<10>);
+            kern<<<blend_grid(T), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx, st->final_T,
+                                                     st->n_contrib, st->d_render, w.pair_grad, q, w.sched.work, w.ckpt, st->render, lt);
+        } else {
+            auto kern = sums == 6 ? fused_blend_bwd_kernel<6> : (sums == 7 ? fused_blend_bwd_kernel<7> : fused_blend_bwd_kernel<10>);
+            kern<<<blend_grid(T), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx, st->final_T, st->n_contrib,
+                                               st->d_render, w.pair_grad, q, w.sched.work, w.ckpt, st->render, lt);
+        }
     }
     const int rows = reduce_rows(st->N > 0 ? st->N : 1);
     RegCfg rcfg;
@@ -2578,16 +2894,6 @@ static int fit_backward_step_impl(const gfl_fit_state* st, const gfl_fit_hyper* 
             st->params, st->adam_m, st->adam_v, st->intr, st->pose, st->rec, st->d_rec, w.pair_grad, slot_pool,
             st->tile_range, w.slot_inv, gx, gy, st->N, st->W, st->H, st->flow_target, st->flow_w, st->still_target,
             st->still_w, st->row_flags, rcfg, ac, st->step, w.partial, nullptr, nullptr, nullptr, scale_cnt, tail, ns, next);
-        return check_launch();
-    }
-    if (getenv("GFL_ADAM_512")) {      // experiment: the per-splat launch with 512-splat workgroups, no tail
-        StageScope p(ST_PRE_BWD_ADAM, s);
-        const int rows512 = fit_nblk(st->N > 0 ? st->N : 1);
-        const NextSched ns = next_sched(w, rows512, T);
-        fused_preprocess_bwd_adam_kernel<false, BIN_BLOCK, false><<<rows512 + next_sched_blocks(w, T), BIN_BLOCK, (size_t)T * sizeof(int32_t), s>>>(
-            st->params, st->adam_m, st->adam_v, st->intr, st->pose, st->rec, st->d_rec, w.pair_grad, slot_pool,
-            st->tile_range, w.slot_inv, gx, gy, st->N, st->W, st->H, st->flow_target, st->flow_w, st->still_target,
-            st->still_w, st->row_flags, rcfg, ac, st->step, w.partial, nullptr, nullptr, nullptr, scale_cnt, tail, ns, PreArgs{});
         return check_launch();
     }
     {

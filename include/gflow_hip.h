@@ -86,6 +86,9 @@ int gfl_constants(float* out10);
 /* 1 when this process runs the J Sigma J^T contraction of gfl_fit_forward / gfl_render_fwd on the matrix cores
  * (GFL_EWA_MFMA=1 in the environment when the library first looked), 0 for the VALU form */
 int gfl_ewa_on_mfma(void);
+/* 1 when this process runs the backward blend of the fit iteration in its "rows" formulation (GFL_BWD_ROWS=1: a measured
+ * alternative, off by default) */
+int gfl_bwd_rows_on(void);
 const char* gfl_status_string(int status);
 int gfl_last_hip_error(void);
 /* bytes of scratch any *_bwd that reduces camera gradients needs for N splats */

@@ -215,7 +215,9 @@ def test_batched_graph_launches_equal_one_iteration_at_a_time():
     torch.cuda.synchronize()
     assert sa.iteration == sb.iteration == 37
     assert len(sa.frames) == len(sb.frames) == 8                             # iterations 0, 5, ..., 35
-    assert ta.current_pts_num() == tb.current_pts_num() > 1500               # two densifications, the same draws
+    # two densifications; their counts follow the number of pixels above the error threshold, which the last bits of the
+    # two fits can move by one or two
+    assert abs(ta.current_pts_num() - tb.current_pts_num()) <= 3 and tb.current_pts_num() > 1500
     assert ta.iterations_done == tb.iterations_done and ta.rasterisations_done == tb.rasterisations_done
     # the initial splats took the same 37 Adam steps (the rows appended by the densifications are drawn from error maps
     # that differ in the last bits -- the backward's LDS atomics are unordered -- and need not be the same pixels)

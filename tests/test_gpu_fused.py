@@ -5,6 +5,8 @@ operator-by-operator path (``-m gpu``).
 Gradients of the fused path are read back from Adam's first moment after ONE step from
 a zero state: m = (1 - beta1) * g exactly, so g = m / 0.1.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -673,6 +675,27 @@ def _copy_engine_state(src, dst):
         getattr(dst, a).copy_(getattr(src, a))
 
 
+def _next_pre_on():
+    import ctypes
+    from gflow_amd import _lib as L
+    return os.environ.get("GFL_NEXT_PRE") == "1"
+
+
+def test_next_preprocess_variant_in_a_process_of_its_own():
+    """GFL_NEXT_PRE=1 (read once per process): the two tests below, which skip themselves without the switch."""
+    import subprocess
+    import sys
+    if _next_pre_on():
+        pytest.skip("already inside that process")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+           "tests/test_gpu_fused.py::test_next_preprocess_in_the_adam_tail_is_the_standalone_preprocess",
+           "tests/test_gpu_fused.py::test_four_iterations_in_one_call_track_four_single_iterations"]
+    r = subprocess.run(cmd, env=dict(os.environ, GFL_NEXT_PRE="1"), cwd=root, capture_output=True, text=True, timeout=900)
+    tail = (r.stdout + r.stderr)[-4000:]
+    assert r.returncode == 0 and "3 passed" in r.stdout, tail
+
+
 @pytest.mark.parametrize("with_scale_term", [False, True])
 def test_next_preprocess_in_the_adam_tail_is_the_standalone_preprocess(setup, with_scale_term):
     """gfl_fit_iterations: between two plain iterations the NEXT iteration's preprocess runs in the tail of the per-splat
@@ -681,6 +704,8 @@ def test_next_preprocess_in_the_adam_tail_is_the_standalone_preprocess(setup, wi
     given the stepped rows runs the ordinary forward)."""
     from gflow_amd import _lib as L
     import ctypes
+    if not _next_pre_on():
+        pytest.skip("needs GFL_NEXT_PRE=1 (test_next_preprocess_variant_in_a_process_of_its_own starts it)")
     s, raw, img, dep = setup
     hyper = dict(lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0, lr=4e-3, lr_camera=0.0, total_iters=100)
     if with_scale_term:
@@ -715,6 +740,8 @@ def test_next_preprocess_in_the_adam_tail_is_the_standalone_preprocess(setup, wi
 
 
 def test_four_iterations_in_one_call_track_four_single_iterations(setup):
+    if not _next_pre_on():
+        pytest.skip("needs GFL_NEXT_PRE=1 (test_next_preprocess_variant_in_a_process_of_its_own starts it)")
     s, raw, img, dep = setup
     hyper = dict(lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0, lr=4e-3, lr_camera=0.0, total_iters=100)
     a = _engine(raw, s, img, dep, pose=POSE, **hyper)
@@ -733,6 +760,7 @@ def test_four_iterations_in_one_call_track_four_single_iterations(setup):
     assert torch.allclose(a.depth_ab, b.depth_ab, rtol=1e-5, atol=1e-7) and torch.allclose(a.sums, b.sums, rtol=1e-4)
     # the camera-only stage and a moving camera do not qualify: same entry, ordinary launches
     import ctypes
+    assert a.lib.gfl_fit_next_preprocess_supported(ctypes.byref(a.state()), ctypes.byref(a.hp)) == 1
     a.hp.lr_camera = 1e-3
     assert a.lib.gfl_fit_next_preprocess_supported(ctypes.byref(a.state()), ctypes.byref(a.hp)) == 0
     b.hp.lr_camera = 1e-3
