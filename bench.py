@@ -409,6 +409,7 @@ def main():
             stepper()
             k_dev[i:i + 1].copy_(eng.tile_offsets[eng.T:eng.T + 1])
     kern = {k: kern_all[k] for k in ("blend_fwd", "loss", "blend_bwd") if k in kern_all}
+    eng.check_overflow()                   # (the stepper is driven directly here: no train() looks at the pair lists' flag)
     ks = k_dev[:min(args.steps, STEP_WINDOW)].cpu().tolist()
     K = sum(ks) / len(ks)                  # mean over the window's iterations: what the kernels' average durations belong to
     psnr_step = float(tr.psnr_of(stepper.last_render))

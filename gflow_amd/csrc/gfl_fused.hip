@@ -1034,6 +1034,7 @@ struct LossTail {
     int step_affine;                        // hp->step_camera (after a densification nothing is stepped)
     int32_t* d_step;
     float* d_extr_out;                      // [12]: zeros (not computed in such an iteration)
+    int32_t* overflow;                      // [2]: the forward dropped pairs -> nothing is stepped, [1] counts the iteration
 };
 
 template <int B = 256>
@@ -1083,6 +1084,13 @@ __device__ void loss_tail(const LossTail& t) {
     if (threadIdx.x >= 16 && threadIdx.x < 28) t.d_extr_out[threadIdx.x - 16] = 0.f;
     __syncthreads();
     if (threadIdx.x == 0) {
+        if (t.overflow && t.overflow[0] != 0) {
+            // The forward of this iteration dropped (splat, tile) pairs: its gradients are not the scene's.  Nothing is
+            // stepped -- the per-splat launch skips its rows the same way --, the step counter stays, and the iteration is
+            // counted so that the host can run it again once it has grown the lists (FitEngine.settle_overflow).
+            t.overflow[1] += 1;
+            return;
+        }
         if (t.step_affine) {
             float ss, isb;
             adam_scalars(t.ac_ab, e_step, t.ac_ab.lr, ss, isb);
@@ -1682,6 +1690,7 @@ struct CamTail {
     int32_t* d_step;
     float* d_extr_out;                      // [12]
     int32_t* ticket;                        // zero between launches
+    int32_t* overflow;                      // [2], as LossTail
 };
 
 __device__ __forceinline__ float ld_agent(const float* p) {
@@ -1758,6 +1767,10 @@ __device__ __forceinline__ void camera_tail(const CamTail& t, const float* parti
     __syncthreads();
     if (threadIdx.x == 0) {
         const int e = e_step;
+        if (t.overflow && t.overflow[0] != 0) {
+            t.overflow[1] += 1;
+            return;
+        }
         if (t.step_camera) {
             // d_extr (rows R|t) -> d_pose; q = raw/|raw| in XYZW order
             const float rx = pz[0], ry = pz[1], rz = pz[2], rw = pz[3];
@@ -1821,7 +1834,7 @@ __global__ void __launch_bounds__(BLOCK) fused_preprocess_bwd_adam_kernel(
     const float* __restrict__ still_w, const uint8_t* __restrict__ row_flags, RegCfg rc, AdamCfg ac,
     const int32_t* d_step, float* partial, const float* __restrict__ d_uv_in,
     const float* __restrict__ d_depth_in, float* __restrict__ d_params, const int32_t* __restrict__ scale_cnt, CamTail tail,
-    NextSched ns, PreArgs next) {
+    NextSched ns, PreArgs next, const int32_t* next_overflow) {
     extern __shared__ int32_t sched_scratch[];           // T ints: the scheduler's scratch, or (NEXT) the tile histogram
     if ((int)blockIdx.x >= ns.rows) {
         // the two workgroups behind the per-splat ones build the NEXT iteration's tile queues (see fused_scatter_kernel)
@@ -1838,7 +1851,8 @@ __global__ void __launch_bounds__(BLOCK) fused_preprocess_bwd_adam_kernel(
         for (int t = threadIdx.x; t < next.gx * next.gy; t += BLOCK) sched_scratch[t] = 0;
     }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int e_step = OP ? 0 : *d_step - (rc.no_pose_grad ? 1 : 0);   // (the camera launch advances it -- or already has: LossTail)
+    const bool dropped = !OP && next_overflow != nullptr && next_overflow[0] != 0;      // the forward dropped pairs: no row is stepped
+    const int e_step = OP ? 0 : *d_step - ((rc.no_pose_grad && !dropped) ? 1 : 0);   // (the camera launch advances it -- or already has: LossTail)
     float scale_w = 0.f;                              // lambda_scale / rows of the scale term
     if (!OP && rc.lambda_scale != 0.f) {
         __shared__ int32_t s_rows;
@@ -2103,7 +2117,7 @@ __global__ void __launch_bounds__(BLOCK) fused_preprocess_bwd_adam_kernel(
         }
         // Adam over the 64-byte row
         GFL_PHASE(3, 5);
-        if (!rc.freeze_all) {
+        if (!rc.freeze_all && !dropped) {
         float step_size, isb2;
         adam_scalars(ac, e_step, ac.lr, step_size, isb2);
         float4* prow = reinterpret_cast<float4*>(params + (size_t)i * ROW);
@@ -2156,7 +2170,7 @@ __global__ void __launch_bounds__(1024) fused_camera_adam_kernel(
     const float* __restrict__ p_grad, int n_grad, float* __restrict__ pose, float* __restrict__ pose_m,
     float* __restrict__ pose_v, float* __restrict__ depth_ab, float* __restrict__ ab_m, float* __restrict__ ab_v,
     float* __restrict__ sums, AdamCfg ac_cam, AdamCfg ac_ab, int step_camera, int32_t* __restrict__ d_step,
-    float* __restrict__ d_extr_out) {
+    float* __restrict__ d_extr_out, int32_t* __restrict__ overflow) {
     constexpr int NV = 17;   // 12 extr + {mse, ssim, depth, d/da, d/db}
     float acc[NV];
 #pragma unroll
@@ -2214,6 +2228,10 @@ __global__ void __launch_bounds__(1024) fused_camera_adam_kernel(
     __syncthreads();
     if (threadIdx.x == 0) {
         const int e = e_step;
+        if (overflow && overflow[0] != 0) {      // the forward dropped pairs: nothing is stepped, the iteration is counted (LossTail)
+            overflow[1] += 1;
+            return;
+        }
         if (step_camera) {
             // d_extr (rows R|t) -> d_pose; q = raw/|raw| in XYZW order
             const float rx = pz[0], ry = pz[1], rz = pz[2], rw = pz[3];
@@ -2800,7 +2818,7 @@ int gfl_render_bwd(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float
         fused_preprocess_bwd_adam_kernel<true, REDUCE_BLOCK, false><<<rows + next_sched_blocks(w, T), REDUCE_BLOCK, next_sched_lds(w, T), s>>>(
             st->params, nullptr, nullptr, st->intr, st->extr, st->rec, st->d_rec, w.pair_grad, w.slot_pool, st->tile_range,
             w.slot_inv, gx, gy, st->N, st->W, st->H, nullptr, nullptr, nullptr, nullptr, nullptr, rcfg, ac, nullptr,
-            w.partial, d_uv, d_depth, d_params, nullptr, CamTail{}, ns, PreArgs{});
+            w.partial, d_uv, d_depth, d_params, nullptr, CamTail{}, ns, PreArgs{}, nullptr);
         fold_partials_kernel<12><<<1, 256, 0, s>>>(w.partial, rows, d_extr);
     }
     return check_launch();
@@ -2845,7 +2863,7 @@ static int fit_backward_step_impl(const gfl_fit_state* st, const gfl_fit_hyper* 
         lt.p_ssim = p_ssim; lt.n_ssim = n_ssim; lt.p_grad = p_grad; lt.n_grad = n_grad;
         lt.depth_ab = st->depth_ab; lt.ab_m = st->depth_ab_m; lt.ab_v = st->depth_ab_v;
         lt.sums = st->sums; lt.ac_ab = ac; lt.step_affine = hp->step_camera != 0;
-        lt.d_step = st->step; lt.d_extr_out = st->d_extr;
+        lt.d_step = st->step; lt.d_extr_out = st->d_extr; lt.overflow = st->overflow;
     }
     {
         StageScope p(ST_BLEND_BWD, s);
@@ -2879,7 +2897,7 @@ static int fit_backward_step_impl(const gfl_fit_state* st, const gfl_fit_hyper* 
         tail.pose = st->pose; tail.pose_m = st->pose_m; tail.pose_v = st->pose_v;
         tail.depth_ab = st->depth_ab; tail.ab_m = st->depth_ab_m; tail.ab_v = st->depth_ab_v;
         tail.sums = st->sums; tail.ac_cam = ac_cam; tail.ac_ab = ac; tail.step_camera = hp->step_camera;
-        tail.d_step = st->step; tail.d_extr_out = st->d_extr; tail.ticket = w.pool_counter + 8;
+        tail.d_step = st->step; tail.d_extr_out = st->d_extr; tail.ticket = w.pool_counter + 8; tail.overflow = st->overflow;
     }
     const int32_t* slot_pool = parity ? w.slot_pool2 : w.slot_pool;
     const int32_t* scale_cnt = parity ? w.scale_cnt2 : w.scale_cnt;
@@ -2893,7 +2911,7 @@ static int fit_backward_step_impl(const gfl_fit_state* st, const gfl_fit_hyper* 
         fused_preprocess_bwd_adam_kernel<false, BIN_BLOCK, true><<<rows512 + next_sched_blocks(w, T), BIN_BLOCK, (size_t)T * sizeof(int32_t), s>>>(
             st->params, st->adam_m, st->adam_v, st->intr, st->pose, st->rec, st->d_rec, w.pair_grad, slot_pool,
             st->tile_range, w.slot_inv, gx, gy, st->N, st->W, st->H, st->flow_target, st->flow_w, st->still_target,
-            st->still_w, st->row_flags, rcfg, ac, st->step, w.partial, nullptr, nullptr, nullptr, scale_cnt, tail, ns, next);
+            st->still_w, st->row_flags, rcfg, ac, st->step, w.partial, nullptr, nullptr, nullptr, scale_cnt, tail, ns, next, st->overflow);
         return check_launch();
     }
     {
@@ -2902,13 +2920,13 @@ static int fit_backward_step_impl(const gfl_fit_state* st, const gfl_fit_hyper* 
         fused_preprocess_bwd_adam_kernel<false, REDUCE_BLOCK, false><<<rows + next_sched_blocks(w, T), REDUCE_BLOCK, next_sched_lds(w, T), s>>>(
             st->params, st->adam_m, st->adam_v, st->intr, st->pose, st->rec, st->d_rec, w.pair_grad, slot_pool,
             st->tile_range, w.slot_inv, gx, gy, st->N, st->W, st->H, st->flow_target, st->flow_w, st->still_target,
-            st->still_w, st->row_flags, rcfg, ac, st->step, w.partial, nullptr, nullptr, nullptr, scale_cnt, tail, ns, PreArgs{});
+            st->still_w, st->row_flags, rcfg, ac, st->step, w.partial, nullptr, nullptr, nullptr, scale_cnt, tail, ns, PreArgs{}, st->overflow);
     }
     if (own_launch && !frozen) {
         StageScope p(ST_CAMERA, s);
         fused_camera_adam_kernel<<<1, 1024, 0, s>>>(w.partial, rows, p_ssim, n_ssim, p_grad, n_grad, st->pose, st->pose_m,
                                                     st->pose_v, st->depth_ab, st->depth_ab_m, st->depth_ab_v, st->sums,
-                                                    ac_cam, ac, hp->step_camera != 0, st->step, st->d_extr);
+                                                    ac_cam, ac, hp->step_camera != 0, st->step, st->d_extr, st->overflow);
     }
     return check_launch();
 }

@@ -119,7 +119,7 @@ class FitEngine:
         self.sums = torch.zeros(8, **f32)
         self.tile_offsets = torch.zeros(self.T + 1, **i32)
         self.tile_range = torch.zeros(self.T, 2, **i32)
-        self.overflow = torch.zeros(1, **i32)
+        self.overflow = torch.zeros(2, **i32)         # [0]: sticky flag, [1]: iterations that stepped nothing because of it
         self.gt_rgb = self.gt_depth = self.keep = None
         self.move_mask = self.foot_flags = None
         self.flow_target = self.flow_w = self.still_target = self.still_w = self.row_flags = None
@@ -150,9 +150,16 @@ class FitEngine:
         self.d_rec = torch.zeros(cap, REC, **f32)
         if old is not None and n:
             self.params[:n] = old[:n]
-        self.K_cap = int(self.K_cap_req) if self.K_cap_req else max(4_000_000, 8 * cap)     # (64 B per pair: 0.25-0.5 GB of 288)
+        k_min = getattr(self, "K_cap", 0) if getattr(self, "_K_grown", False) else 0      # (never below what an overflow asked for)
+        self._alloc_pairs(max(int(self.K_cap_req) if self.K_cap_req else max(4_000_000, 8 * cap), k_min))
+
+    def _alloc_pairs(self, K_cap):
+        """The buffers whose size follows K_cap (the sorted ids, and the workspace: keys, per-pair gradient rows, slot
+        pools, the tile scheduler's state, checkpoints, cached target statistics -- everything in it is rebuilt by the
+        next forward / set_targets)."""
+        self.K_cap = int(K_cap)                                                         # (64 B per pair: 0.25-0.5 GB of 288)
         self.ids = torch.zeros(self.K_cap, dtype=torch.int32, device=self.dev)
-        nbytes = self.lib.gfl_fit_workspace_bytes(cap, self.K_cap, self.W, self.H)
+        nbytes = self.lib.gfl_fit_workspace_bytes(self.cap, self.K_cap, self.W, self.H)
         self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.dev)   # the pool counter must start at 0
         self._state = None
 
@@ -434,10 +441,32 @@ class FitEngine:
     def check_overflow(self):
         """Blocking read of the pair-list overflow flag (sticky on the device); raises if pairs were dropped."""
         self._ovf_event = None
-        code = int(self.overflow.item())
+        code = int(self.overflow[0].item())
         if code:
             self.overflow.zero_()
             raise RuntimeError(self._overflow_message(code))
+
+    def settle_overflow(self):
+        """Blocking.  If a forward dropped (splat, tile) pairs since the last call: the lists are doubled, both words are
+        cleared, and the number of iterations that stepped NOTHING meanwhile is returned (the library skips every update
+        while the flag is set, include/gflow_hip.h) -- the caller runs that many iterations again and the fit is where a
+        fit that never overflowed would be.  0: nothing happened.  (K_cap is max(4 M, 8 x capacity), ~15 x what fits
+        produce: this is the rare path, but a silent or fatal one it must not be.)"""
+        self._ovf_event = None
+        code, skipped = (int(v) for v in self.overflow.tolist())                       # the host read
+        if code == 0:
+            return 0
+        if code != 1:
+            self.overflow.zero_()
+            raise RuntimeError(self._overflow_message(code))
+        self._K_grown = True
+        self._alloc_pairs(2 * self.K_cap)
+        self.overflow.zero_()
+        with _GRAPH_LOCK:
+            self._graphs.clear()
+        self._graph_key = None
+        self.pairs_grown = getattr(self, "pairs_grown", 0) + 1
+        return max(skipped, 0)
 
     def _overflow_message(self, code):
         if code == 2:
@@ -452,7 +481,7 @@ class FitEngine:
         self.poll_overflow()
         if getattr(self, "_ovf_host", None) is None:
             self._ovf_host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
-        self._ovf_host.copy_(self.overflow, non_blocking=True)
+        self._ovf_host.copy_(self.overflow[0:1], non_blocking=True)
         self._ovf_event = torch.cuda.Event()
         self._ovf_event.record()
 

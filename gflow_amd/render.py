@@ -39,12 +39,7 @@ def _checkout(W, H, n, dev):
         _POOL[key].append(eng)
     # the pair-list overflow flag of this engine's PREVIOUS call, copied to pinned memory behind that call: read it
     # here without waiting for the device (an overflow drops splat-tile pairs silently otherwise)
-    if eng.ovf_event is not None and eng.ovf_event.query():
-        eng.ovf_event = None
-        if int(eng.ovf_host[0]):
-            eng.overflow.zero_()
-            raise RuntimeError(f"gflow_amd.render: an earlier render produced more than K_cap={eng.K_cap} splat-tile "
-                               f"pairs and dropped some; raise K_cap (FitEngine(..., K_cap=...))")
+    _poll_overflow(eng)
     eng.ensure_capacity(n)
     if getattr(eng, "pad2", None) is None or eng.pad2.shape[0] < eng.cap:
         eng.pad2 = torch.zeros(eng.cap, 2, dtype=torch.float32, device=eng.dev)
@@ -59,8 +54,28 @@ def _release(eng, token):
         eng.busy = False
 
 
+def _poll_overflow(eng):
+    """raises if the copy of the flag that followed the engine's last forward has landed and shows dropped pairs"""
+    if eng.ovf_event is not None and eng.ovf_event.query():
+        eng.ovf_event = None
+        if int(eng.ovf_host[0]):
+            eng.overflow.zero_()
+            raise RuntimeError(f"gflow_amd.render: a render produced more than K_cap={eng.K_cap} splat-tile "
+                               f"pairs and dropped some; raise K_cap (FitEngine(..., K_cap=...))")
+
+
+def check_overflow():
+    """Blocking: raises if ANY render of the fused operator so far dropped splat-tile pairs (the operator itself looks at
+    the flag without stopping the host: at the backward of the same render, and at the next render on the same engine).
+    Call it after the last render of a program whose result matters."""
+    for engines in _POOL.values():
+        for eng in engines:
+            eng.ovf_event = None
+            eng.check_overflow()
+
+
 def _watch_overflow(eng):
-    eng.ovf_host.copy_(eng.overflow, non_blocking=True)
+    eng.ovf_host.copy_(eng.overflow[0:1], non_blocking=True)
     eng.ovf_event = torch.cuda.Event()
     eng.ovf_event.record()
 
@@ -111,6 +126,7 @@ class _FusedRender(torch.autograd.Function):
             # pool with the first backward)
             raise RuntimeError("gflow_amd.render: backward through the fused render operator a second time "
                                "(retain_graph) is not supported; call render() again")
+        _poll_overflow(eng)          # (the forward of this very render: by now its flag has usually reached the host)
         dev = eng.dev
         H, W = eng.H, eng.W
         z = lambda c: torch.zeros(c, H, W, dtype=torch.float32, device=dev)

@@ -600,6 +600,20 @@ class SimpleGaussian:
             eng.set_footprint_mask(move_mask if move_mask is not None else torch.zeros(H, W, dtype=torch.bool),
                                    ~self.still_mask_tentative)
 
+        def settle():
+            """The pair lists overflowed since the last look?  Then the library has stepped nothing since (the iterations
+            ran, their updates were skipped): grow the lists and run those iterations again -- plain ones: what a snapshot
+            taken meanwhile shows is not repeated.  Blocking; called where the host stops anyway (before a densification
+            reads the error map) and at the end of the call."""
+            while True:
+                k = eng.settle_overflow()
+                if not k:
+                    return
+                for _ in range(k):
+                    eng.iteration(use_graph=False)
+
+        st.settle = settle
+
         def one_iteration():
             iteration = st.iteration
             n_rendered = eng.N                       # rows this iteration projects (densification appends afterwards)
@@ -666,6 +680,9 @@ class SimpleGaussian:
 
             # ---- densification (trainer.py:560-571)
             densified = False
+            if (not camera_only and densify_interval and (iteration + 1) % densify_interval == 0
+                    and (iteration + 1) // densify_interval <= densify_times):
+                settle()                             # (the error map below must be the scene's; this event reads back anyway)
             if not camera_only and iteration == 0 and later_frame and mask is not None:
                 # (an empty mask appends nothing: densify_by_pixels's own single host read decides, there is no
                 #  separate ``mask.sum() > 0`` read as in trainer.py:563)
@@ -760,7 +777,9 @@ class SimpleGaussian:
             st.run(iterations)
         self.train_log = st.log
         if self.fused and self.engine is not None:
-            self.engine.watch_overflow()          # dropped pairs must not go unnoticed -- without stopping the host here
+            # Dropped (splat, tile) pairs must neither go unnoticed nor end the fit: the lists are grown and the iterations
+            # that stepped nothing are run again (FitEngine.settle_overflow).  One read of two words per train() call.
+            st.settle()
             if getattr(st, "snap_stream", None) is not None:
                 with torch.cuda.stream(st.snap_stream):
                     self._snap_aux.watch_overflow()

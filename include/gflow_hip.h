@@ -266,8 +266,13 @@ typedef struct gfl_fit_state {
     float *render, *final_T;                    /* [4][H][W], [H][W] */
     int32_t* n_contrib;                         /* [H][W] */
     float *d_render, *err_px, *sums;            /* [4][H][W], [H][W], [8] as gfl_loss_fwd_bwd */
-    int32_t *tile_offsets, *ids, *tile_range, *overflow; /* [T+1], [K_cap], [T][2], [1] (sticky: 1 = more than K_cap pairs,
-                                                          * 2 = GFL_ITER_PRE_DONE without a preprocess) */
+    int32_t *tile_offsets, *ids, *tile_range, *overflow; /* [T+1], [K_cap], [T][2], [2].  overflow[0] is sticky: 1 = a
+                                                          * forward produced more than K_cap pairs (or slot-pool entries) and
+                                                          * dropped some, 2 = GFL_ITER_PRE_DONE without a preprocess.  While it
+                                                          * is set, gfl_fit_backward_step steps NOTHING (rows, moments, pose,
+                                                          * depth affine and step counter stay) and adds 1 to overflow[1]: the
+                                                          * caller grows the lists, clears both words and runs overflow[1]
+                                                          * iterations again (gflow_amd/fused.py: settle_overflow) */
     void* workspace;
     size_t workspace_bytes;                     /* >= gfl_fit_workspace_bytes() */
 } gfl_fit_state;

