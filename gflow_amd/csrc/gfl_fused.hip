@@ -495,8 +495,9 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* _
         if (*sched_valid) return;
         __shared__ SchedLds sched_lds;
         const Sched sc = blockIdx.x == gridDim.x - 1 ? sched_bwd : sched_fwd;
-        if (sched_xcd_usable(sc, T, SCHED_BLOCK)) schedule_tiles_xcd<SCHED_BLOCK>(tile_counts, T, sc, cursor, wsum, sched_lds);
-        else schedule_tiles(tile_counts, T, sc, cursor, wsum, sched_lds);
+        uint32_t* frac4 = T <= SCHED_PLAN_TILES ? reinterpret_cast<uint32_t*>(cursor + T) : nullptr;      // (sched_dyn_lds)
+        if (sched_xcd_usable(sc, T, SCHED_BLOCK)) schedule_tiles_xcd<SCHED_BLOCK>(tile_counts, T, sc, cursor, wsum, sched_lds, frac4);
+        else schedule_tiles(tile_counts, T, sc, cursor, wsum, sched_lds, frac4);
         return;
     }
     const int32_t* base_row = hist_g + (size_t)blockIdx.x * T;
@@ -1841,7 +1842,8 @@ __global__ void __launch_bounds__(BLOCK) fused_preprocess_bwd_adam_kernel(
         __shared__ SchedLds sched_lds;
         __shared__ int32_t sched_wsum[BLOCK / 64];
         const Sched sc = (int)blockIdx.x == ns.rows ? ns.bwd : ns.fwd;
-        schedule_tiles_xcd<BLOCK>(ns.tile_counts, ns.T, sc, sched_scratch, sched_wsum, sched_lds);
+        schedule_tiles_xcd<BLOCK>(ns.tile_counts, ns.T, sc, sched_scratch, sched_wsum, sched_lds,
+                                  reinterpret_cast<uint32_t*>(sched_scratch + ns.T));      // (T <= SCHED_PLAN_TILES: next_sched_ok)
         if (threadIdx.x == 0) *ns.valid = 1;
         return;
     }
@@ -2527,7 +2529,12 @@ static bool next_sched_ok(const FitWs& w, int T) {
            next_sched_enabled();
 }
 static int next_sched_blocks(const FitWs& w, int T) { return next_sched_ok(w, T) ? 2 : 0; }
-static size_t next_sched_lds(const FitWs& w, int T) { return next_sched_ok(w, T) ? (size_t)T * sizeof(int32_t) : 0; }
+// dynamic LDS of a launch that carries scheduling workgroups: T ints of scratch (the launch's own histogram / cursors) and,
+// for tile grids of up to SCHED_PLAN_TILES tiles, the block plans' SCHED_PLAN_TILES words behind them
+static size_t sched_dyn_lds(int T) {
+    return (size_t)T * sizeof(int32_t) + (T <= SCHED_PLAN_TILES ? (size_t)SCHED_PLAN_TILES * sizeof(uint32_t) : 0);
+}
+static size_t next_sched_lds(const FitWs& w, int T) { return next_sched_ok(w, T) ? sched_dyn_lds(T) : 0; }
 static NextSched next_sched(const FitWs& w, int rows, int T) {
     NextSched ns;
     ns.rows = rows;
@@ -2594,7 +2601,9 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
     const FitWs w = carve(st);
     const int nblk = fit_nblk(st->N > 0 ? st->N : 1);
     const size_t lds = (size_t)T * sizeof(int32_t);
-    if (lds > 42 * 1024) return GFL_ERR_INVALID;   // tile grid too large for the LDS histogram (+ 21 KB of scheduler state: 64 KB)
+    // tile grid too large for the LDS histogram: 64 KB less the scheduling workgroups' ~6 KB of static state (their block
+    // plans' 16 KB exist only for grids of up to 4096 tiles).  14 592 tiles: 2560 x 1440 has 14 400.
+    if (lds > 57 * 1024) return GFL_ERR_INVALID;
     int32_t* slot_pool = parity ? w.slot_pool2 : w.slot_pool;
     if (!pre_done) {
         StageScope p(ST_PREPROCESS, s);
@@ -2612,7 +2621,7 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
     const bool ordered = sort_heavy_first() && T <= 8 * BIN_BLOCK;
     {
         StageScope p(ST_SCATTER, s);
-        fused_scatter_kernel<<<nblk + 2 + (ordered ? 1 : 0), BIN_BLOCK, lds, s>>>(st->rec, st->N, gx, gy, w.hist, w.tile_counts,
+        fused_scatter_kernel<<<nblk + 2 + (ordered ? 1 : 0), BIN_BLOCK, sched_dyn_lds(T), s>>>(st->rec, st->N, gx, gy, w.hist, w.tile_counts,
                                                               st->tile_offsets, st->K_cap, w.keys, st->overflow, w.sched, w.sched_fwd,
                                                               w.sched_valid, ordered ? w.sort_order : nullptr);
     }
@@ -2908,7 +2917,7 @@ static int fit_backward_step_impl(const gfl_fit_state* st, const gfl_fit_hyper* 
         rcfg.scale_blocks = rows512;
         const NextSched ns = next_sched(w, rows512, T);
         const PreArgs next = pre_args(st, hp, w, gx, gy, 0, parity ^ 1);
-        fused_preprocess_bwd_adam_kernel<false, BIN_BLOCK, true><<<rows512 + next_sched_blocks(w, T), BIN_BLOCK, (size_t)T * sizeof(int32_t), s>>>(
+        fused_preprocess_bwd_adam_kernel<false, BIN_BLOCK, true><<<rows512 + next_sched_blocks(w, T), BIN_BLOCK, sched_dyn_lds(T), s>>>(
             st->params, st->adam_m, st->adam_v, st->intr, st->pose, st->rec, st->d_rec, w.pair_grad, slot_pool,
             st->tile_range, w.slot_inv, gx, gy, st->N, st->W, st->H, st->flow_target, st->flow_w, st->still_target,
             st->still_w, st->row_flags, rcfg, ac, st->step, w.partial, nullptr, nullptr, nullptr, scale_cnt, tail, ns, next, st->overflow);
@@ -2944,7 +2953,7 @@ static bool fit_next_pre_ok(const gfl_fit_state* st, const gfl_fit_hyper* hp, co
     const bool sched512 = !next_sched_enabled() || (w.sched.xcd && T <= SCHED_PLAN_TILES && w.sched.nq % 8 == 0 &&
                                                     w.sched.nq / 8 <= 64 && w.sched.nq <= BIN_BLOCK);
     return next_pre_enabled() && frozen && !hp->freeze_all_splats && !st->foot_flags && !ewa_on_mfma() && sched512 &&
-           st->N > 0 && (size_t)T * sizeof(int32_t) <= 42 * 1024;
+           st->N > 0 && (size_t)T * sizeof(int32_t) <= 57 * 1024;
 }
 
 int gfl_fit_iterations(const gfl_fit_state* st, const gfl_fit_hyper* hp, int count, int flags, gfl_stream_t stream) {

@@ -135,7 +135,6 @@ __device__ __forceinline__ int sched_scan_bins(int32_t* bins, int32_t* wsum) {
 // static LDS of the scheduling workgroup, declared ONCE in the kernel that calls either scheduler
 struct SchedLds {
     int32_t bins[SCHED_BINS];
-    uint32_t frac4[SCHED_PLAN_TILES];     // share of each block in its tile's weight, 4 x 8 bits
     int32_t s_max, s_lo;
     int32_t g_base[9];
     int32_t rank[SCHED_BLOCK];
@@ -143,12 +142,14 @@ struct SchedLds {
 
 // lds: scratch of T ints (used as two 16-bit arrays); wsum: LDS scratch of SCHED_BLOCK / 64 ints.  SCHED_BLOCK threads.
 // Whole workgroup.
+// frac4: SCHED_PLAN_TILES words of LDS for the block plans (share of each block in its tile's weight, 4 x 8 bits), or null:
+// every item then keeps the identity plan.  (The caller carves it out of its dynamic LDS only for tile grids of up to
+// SCHED_PLAN_TILES tiles: a 1440p frame needs 56 KB of histogram there, and 16 KB more would not fit.)
 __device__ void schedule_tiles(const int32_t* __restrict__ tile_counts, int T, const Sched sc, int32_t* lds,
-                               int32_t* wsum, SchedLds& sl) {
+                               int32_t* wsum, SchedLds& sl, uint32_t* frac4) {
     int32_t (&bins)[SCHED_BINS] = sl.bins;
     int32_t& s_max = sl.s_max;
     int32_t& s_lo = sl.s_lo;
-    uint32_t (&frac4)[SCHED_PLAN_TILES] = sl.frac4;
     unsigned short* w16 = reinterpret_cast<unsigned short*>(lds);      // weight of tile t
     unsigned short* ord16 = w16 + T;                                     // tiles by descending weight
     const int tid = threadIdx.x;
@@ -176,7 +177,7 @@ __device__ void schedule_tiles(const int32_t* __restrict__ tile_counts, int T, c
         x = min(x, SCHED_MAX_WEIGHT);
         *w4 = make_int4(0, 0, 0, 0);     // the blend kernel adds this iteration's units
         w16[t] = (unsigned short)x;
-        if (t < SCHED_PLAN_TILES) frac4[t] = fr;
+        if (frac4 && t < SCHED_PLAN_TILES) frac4[t] = fr;
         local += x;
         lmax = max(lmax, x);
     }
@@ -258,7 +259,7 @@ __device__ void schedule_tiles(const int32_t* __restrict__ tile_counts, int T, c
             const int wt = w16[tile];
             const int prio = next > 0 ? 0 : (wt * 5 >= target * 2 ? 3 : (wt * 4 >= target ? 2 : 1));
             unsigned plan = ITEM_PLAN_IDENTITY;
-            if (tile < SCHED_PLAN_TILES) {
+            if (frac4 && tile < SCHED_PLAN_TILES) {
                 const uint32_t fr = frac4[tile];
                 const int bw[4] = {(int)(fr & 255u) * wt, (int)((fr >> 8) & 255u) * wt, (int)((fr >> 16) & 255u) * wt,
                                    (int)(fr >> 24) * wt};
@@ -330,10 +331,9 @@ __device__ __forceinline__ unsigned sched_sort32(unsigned key, int lane) {
 // block plans are made per queue in order.  Needs nq % 8 == 0 and nq / 8 <= 64; otherwise the caller uses schedule_tiles.
 template <int BLOCK>
 __device__ void schedule_tiles_xcd(const int32_t* __restrict__ tile_counts, int T, const Sched sc, int32_t* lds, int32_t* wsum,
-                                   SchedLds& sl) {
+                                   SchedLds& sl, uint32_t* frac4) {
     int32_t (&bins)[SCHED_BINS] = sl.bins;
     int32_t& s_max = sl.s_max;
-    uint32_t (&frac4)[SCHED_PLAN_TILES] = sl.frac4;
     int32_t (&g_base)[9] = sl.g_base;
     unsigned short* w16 = reinterpret_cast<unsigned short*>(lds);      // weight of tile t
     unsigned short* ord16 = w16 + T;                                     // tiles by (band, descending weight)
@@ -364,7 +364,7 @@ __device__ void schedule_tiles_xcd(const int32_t* __restrict__ tile_counts, int 
         x = min(x, SCHED_MAX_WEIGHT);
         *w4 = make_int4(0, 0, 0, 0);
         w16[t] = (unsigned short)x;
-        if (t < SCHED_PLAN_TILES) frac4[t] = fr;
+        if (frac4 && t < SCHED_PLAN_TILES) frac4[t] = fr;
         local += x;
         lmax = max(lmax, x);
     }
@@ -454,7 +454,7 @@ __device__ void schedule_tiles_xcd(const int32_t* __restrict__ tile_counts, int 
                 const int wt = w16[tile];
                 const int prio = k > 0 ? 0 : (wt * 5 >= target * 2 ? 3 : (wt * 4 >= target ? 2 : 1));
                 unsigned plan = ITEM_PLAN_IDENTITY;
-                if (tile < SCHED_PLAN_TILES) {
+                if (frac4 && tile < SCHED_PLAN_TILES) {
                     const uint32_t fr = frac4[tile];
                     const int bw[4] = {(int)(fr & 255u) * wt, (int)((fr >> 8) & 255u) * wt, (int)((fr >> 16) & 255u) * wt,
                                        (int)(fr >> 24) * wt};

@@ -91,8 +91,10 @@ class _PinnedPool:
 
     def __init__(self):
         import threading
-        self.blocks = []                                # [uint8 pinned tensor, arrays still alive]
-        self.lock = threading.Lock()                    # several fits may run in one process (fit_clips_concurrent)
+        self.blocks = []                                # [uint8 pinned tensor, arrays still alive, event of the last copy INTO it]
+        # re-entrant: the finalizers below take it too, and a garbage collection that runs them can start inside take()
+        # (which allocates while it holds the lock) on the same thread
+        self.lock = threading.RLock()                   # several fits may run in one process (fit_clips_concurrent)
 
     def total_bytes(self):
         return sum(b[0].numel() for b in self.blocks)
@@ -103,11 +105,24 @@ class _PinnedPool:
             for b in self.blocks:
                 if b[1] == 0 and b[0].numel() >= nbytes:
                     b[1] = 1
-                    return b
-            step = 32 << 20
-            b = [torch.empty((nbytes + step - 1) // step * step, dtype=torch.uint8, pin_memory=True), 1]
-            self.blocks.append(b)
-            return b
+                    break
+            else:
+                step = 32 << 20
+                b = [torch.empty((nbytes + step - 1) // step * step, dtype=torch.uint8, pin_memory=True), 1, None]
+                self.blocks.append(b)
+                return b
+        # a caller that did not wait for its images (lazy_images) may have dropped them while the device-to-host copy
+        # into this block was still queued: the next user must not be given the block before that copy has landed
+        if b[2] is not None:
+            b[2].synchronize()
+            b[2] = None
+        return b
+
+    def copied(self, block, stream):
+        """a device-to-host copy into ``block`` has just been queued on ``stream``"""
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        block[2] = ev
 
     def release(self, block):
         """drop the reference ``take`` left (after ``hold`` / ``hand_out`` have added theirs)"""
@@ -134,7 +149,10 @@ class _PinnedPool:
                 block[1] -= 1
         if self.total_bytes() > self.MAX_BYTES:
             # a caller that keeps every frame's snapshot lists (the reference's fit_video does, to write its videos)
-            # would otherwise hold one 110-180 MB page-locked block per train() call: tens of GB over a 60-frame clip
+            # would otherwise hold one 110-180 MB page-locked block per train() call: tens of GB over a 60-frame clip.
+            # Pageable copies then -- taken only once the device has filled the block (lazy_images callers included)
+            if block[2] is not None:
+                block[2].synchronize()
             return [t.numpy().copy() for t in tensors]
         out = []
         for t in tensors:
@@ -366,6 +384,27 @@ class SimpleGaussian:
             extras = (depth_color, center)
         self.rasterisations_done += 1
         return uv, depth, render4, extras
+
+    def init_mask_prompt_pts(self, mask_prompt, ckpt_name=None):
+        """trainer.py:290-330 (fit_video.py:155-157 calls it once, after the first frame's fit, with the first frame's
+        segmentation mask): ``self.mask_prompt_pts`` (N,) bool -- the splats that project inside the image AND onto a set
+        pixel of ``mask_prompt`` (H, W).  From then on every joint ``train()`` leaves ``self.propagate_seg``, the hull of
+        those splats' current projections (trainer.py:611-619).  With a log directory the prompt is written out as
+        images_seg/propagate_mask_<ckpt_name>.png like the reference does."""
+        with torch.no_grad():
+            uv = render_mod.render_multiple(self._input_group(detach=True), ["uv", "center"])["uv"].detach()
+        self.rasterisations_done += 1
+        mask_prompt = torch.as_tensor(mask_prompt).to(self.device)
+        within = _within(uv, self.W, self.H)
+        yx = uv.long()
+        under = mask_prompt[yx[:, 1].clamp(0, self.H - 1), yx[:, 0].clamp(0, self.W - 1)].bool()
+        self.mask_prompt_pts = within & under
+        if self.dir is not None and ckpt_name is not None:
+            from PIL import Image
+            os.makedirs(os.path.join(self.dir, "images_seg"), exist_ok=True)
+            Image.fromarray((mask_prompt.detach().cpu().numpy() * 255).astype(np.uint8)).save(
+                os.path.join(self.dir, "images_seg", f"propagate_mask_{ckpt_name}.png"))
+        return self.mask_prompt_pts
 
     # ------------------------------------------------------------------- train
     def make_stepper(self, iterations=500, lr=1e-2, lr_camera=0.0, lambda_rgb=1.0, lambda_depth=0.0,
@@ -823,6 +862,16 @@ class SimpleGaussian:
                     self.move_seg = (FastConcaveHull2D(pts).mask(W, H) * 255).astype(np.uint8)
                     # cv2.erode(move_seg, ones((20, 20))): minimum over x-10 .. x+9, nothing eroded from the border
                     self.move_seg_erode = minimum_filter(self.move_seg, size=20, mode="constant", cval=255)
+            if getattr(self, "mask_prompt_pts", None) is not None:
+                # trainer.py:611-619: the first frame's mask prompt, carried by the splats that lay under it: the smoothed
+                # concave hull of where THOSE splats project now (the reference builds it after every joint train() once
+                # init_mask_prompt_pts has been called; host work, like move_seg)
+                from .hull import FastConcaveHull2D
+                m = self.mask_prompt_pts
+                p_uv = uv_d[:m.shape[0]][m]
+                p_uv = p_uv[_within(p_uv, W, H)]
+                if p_uv.shape[0] > 4:
+                    self.propagate_seg = (FastConcaveHull2D(p_uv.cpu().numpy()).mask(W, H) * 255).astype(np.uint8)
             self.last_still_mask = self.still_mask.detach()
             self.last_uv = uv_d
             self.last_depth = depth_d
@@ -843,6 +892,7 @@ class SimpleGaussian:
                 cs.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(cs):
                     parts_pin.copy_(parts_dev, non_blocking=True)
+                _PINNED.copied(parts_block, cs)
                 parts_dev.record_stream(cs)
                 if getattr(st, "copy_stream", None) is None:
                     st.copy_stream = cs
@@ -866,6 +916,7 @@ class SimpleGaussian:
             with torch.cuda.stream(st.copy_stream):
                 st.pin[:k].copy_(st.ring[:k], non_blocking=True)
                 self.engine.snapshot_ring_copied()                   # (an event: the ring is free again after it)
+            _PINNED.copied(st.pin_block, st.copy_stream)
             st.ring.record_stream(st.copy_stream)                    # (should the engine replace it by a larger one)
         if getattr(st, "copy_stream", None) is not None:
             if not lazy_images:
@@ -895,8 +946,15 @@ class SimpleGaussian:
         cur = torch.cuda.current_stream()
         aux = getattr(self, "_snap_aux", None)
         if aux is None or aux.cap < n or aux.K_cap < eng.K_cap:
+            if aux is not None:
+                # the engine grew.  The side stream may still be composing the previous snapshot from the old shadow's
+                # buffers (allocated on the fit stream, used over there): let it finish before they are freed -- a rare
+                # event, a wait of one snapshot -- and keep the SAME stream, so that everything that waits on
+                # ``st.snap_stream`` (the ring's growth, the final copy to the host) still sees its last write
+                self._snap_stream.synchronize()
+            else:
+                self._snap_stream = torch.cuda.Stream(device=dev)
             aux = self._snap_aux = FitEngine(self.W, self.H, max(eng.cap, n), dev, K_cap=eng.K_cap, bg=self.bg)
-            self._snap_stream = torch.cuda.Stream(device=dev)
             self._snap_done = None
         side = self._snap_stream
         if self._snap_done is not None:

@@ -11,6 +11,9 @@ boolean gathers and nested scatter-backs -- which is deliberately NOT how gflow_
   relabel       trainer.py:588-602,621-625  "post-update": still / moving labels from the epipolar move mask at the
                 splats' projected positions, the labels of earlier frames kept, and the ``last_*`` stash.
 
+  mask_prompt_points / propagated_points   trainer.py:290-330, 611-615  the splats under the first frame's mask prompt and
+                where they project after a later frame's fit (the points the reference hands to its concave hull).
+
 ``pix2world`` is the golden-pinned restatement of loss_oracle.py (tests/golden/pix2world.npz was captured from the
 reference's geometry.py).  Everything is index arithmetic on float32 inputs: the comparison is exact for the masks
 and to float32 rounding for the lifted positions."""
@@ -63,3 +66,23 @@ def relabel(uv, move_mask, n_now, last_still_mask=None):
     if last_still_mask is not None:
         still[:last_still_mask.shape[0]] = last_still_mask                 # :598-599
     return still, tentative
+
+
+def mask_prompt_points(uv, mask_prompt, W, H):
+    """trainer.py:309-330.  uv (N,2) projections after the first frame's fit, mask_prompt (H,W) bool / 0-1.
+    Returns mask_prompt_pts (N,) bool."""
+    uv_within = _inside(uv, W, H)                                          # :310
+    uvw = uv[uv_within]                                                    # :311
+    y = uvw[:, 1].long()                                                   # :313-314
+    x = uvw[:, 0].long()
+    pts = mask_prompt[y, x].bool()                                         # :328
+    out = uv_within.clone()                                                # :329
+    out[uv_within] = pts                                                   # :330
+    return out
+
+
+def propagated_points(uv, mask_prompt_pts, W, H):
+    """trainer.py:612-614: the projections (of the last render) of the prompt's splats that are inside the image -- what
+    FastConcaveHull2D is built from when there are more than four."""
+    p = uv[:mask_prompt_pts.shape[0]][mask_prompt_pts]                     # :612
+    return p[_inside(p, W, H)]                                             # :613-614

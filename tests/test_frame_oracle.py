@@ -44,3 +44,20 @@ def test_relabel_keeps_old_labels_and_defaults_to_still():
     still, tent = FR.relabel(uv, move, n_now=6, last_still_mask=torch.tensor([True, False, False]))
     assert tent.tolist() == [False, True, True, True, False, True]              # this frame's own labels
     assert still.tolist() == [True, False, False, True, False, True]            # rows 0..2 keep last frame's labels
+
+
+def test_mask_prompt_points_on_a_hand_worked_case():
+    """Five splats on an 8 x 6 image with a 2 x 2 prompt at pixels x 3..4, y 2..3: inside + under the prompt, inside +
+    beside it, on the image's border (not 'within': uv > 0 and < W - 1 are strict), outside, and truncation (3.9 -> 3)."""
+    import torch
+    from oracle import frame_oracle as FR
+    W, H = 8, 6
+    prompt = torch.zeros(H, W, dtype=torch.bool)
+    prompt[2:4, 3:5] = True
+    uv = torch.tensor([[3.2, 2.7], [5.5, 2.5], [0.0, 2.0], [9.0, 3.0], [4.9, 3.9]])
+    pts = FR.mask_prompt_points(uv, prompt, W, H)
+    assert pts.tolist() == [True, False, False, False, True]
+    # later: splat 0 has left the image, splat 4 has moved
+    uv2 = torch.tensor([[7.5, 2.0], [5.0, 2.0], [1.0, 1.0], [2.0, 2.0], [2.25, 4.5], [1.0, 1.0]])
+    out = FR.propagated_points(uv2, pts, W, H)
+    assert out.tolist() == [[2.25, 4.5]]

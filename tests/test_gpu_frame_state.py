@@ -150,3 +150,45 @@ def test_frame_boundaries_match_the_restatement(fused):
         assert not torch.equal(still, tentative)                                # ... and differ from this frame's own
         assert _edge_count(uv_i.cpu(), fr["move_mask"]) > 0
     assert all(w > 10 for w in warped)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_mask_prompt_points_and_their_propagation_match_the_restatement(fused):
+    """init_mask_prompt_pts (trainer.py:290-330; fit_video.py:155-157 calls it after the first frame with the first
+    frame's segmentation) and the propagated mask of every later joint train() (trainer.py:611-619): the prompt's splat
+    set exactly, the points handed to the hull exactly, and the hull mask itself -- built by gflow_amd.hull from exactly
+    those points -- covering the moving disc it started from once the disc has moved."""
+    import numpy as np
+    from gflow_amd.hull import FastConcaveHull2D
+    from gflow_amd.trainer import SimpleGaussian
+    frames = _clip(3)
+    f0 = frames[0]
+    tr = SimpleGaussian(f0["image"], f0["depth"], num_points=N0, device=DEV, seed=0, fused=fused)
+    tr.load_camera(focal=f0["focal"], pp=f0["pp"])
+    tr.init_gaussians_from_image(f0["image"], f0["depth"], num_points=N0)
+    common = dict(lambda_rgb=1.0, lambda_depth=1e-2, snapshot_interval=0)
+    tr.train(iterations=40, lr=4e-3, lambda_var=10.0, densify_interval=15, densify_times=1, move_mask=f0["move_mask"], **common)
+    assert not hasattr(tr, "propagate_seg")
+    prompt = f0["move_mask"]                                         # the first frame's segmentation of the object
+    pts = tr.init_mask_prompt_pts(prompt)
+    # (the reference renders anew there: the projections of the rows as the LAST Adam step left them, not last_uv)
+    with torch.no_grad():
+        uv0 = tr.project_points(tr.get_attribute("xyz").detach())[0].cpu()
+    assert torch.equal(pts.cpu(), FR.mask_prompt_points(uv0, prompt, W, H))
+    assert 20 < int(pts.sum()) < pts.shape[0]
+    for i in (1, 2):
+        fr = frames[i]
+        tr.set_gt_image(fr["image"]); tr.set_gt_depth(fr["depth"]); tr.set_gt_flow(frames[i - 1]["flow"])
+        tr.train(iterations=15, lr_camera=5e-4, lambda_flow=0.01, camera_only=True, move_mask=fr["move_mask"], **common)
+        tr.train(iterations=30, lr=1e-3, lambda_var=10.0, lambda_still=10.0, lambda_flow=0.01, densify_interval=20,
+                 densify_times=1, mask=fr["occ_mask"], move_mask=fr["move_mask"], **common)
+        uv = tr.last_uv.cpu()
+        want_pts = FR.propagated_points(uv, pts.cpu(), W, H)
+        assert want_pts.shape[0] > 4 and tr.mask_prompt_pts.shape[0] == pts.shape[0] < tr.current_pts_num()   # (rows were appended since)
+        seg = tr.propagate_seg
+        assert seg.dtype == np.uint8 and seg.shape == (H, W) and set(np.unique(seg)) <= {0, 255}
+        want = (FastConcaveHull2D(want_pts.numpy()).mask(W, H) * 255).astype(np.uint8)
+        assert np.array_equal(seg, want)
+        # the propagated mask follows the object: it overlaps this frame's disc much more than the background
+        gt = fr["move_mask"].numpy()
+        assert (seg[gt] > 0).mean() > 0.6 and (seg[~gt] > 0).mean() < 0.15, ((seg[gt] > 0).mean(), (seg[~gt] > 0).mean())

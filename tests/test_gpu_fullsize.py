@@ -259,3 +259,33 @@ def test_backward_blend_variants_agree_on_the_heavy_scene():
     p10, p6 = engs["all"].pose_m / 0.1, engs["geometry"].pose_m / 0.1
     assert float((p6 - p10).abs().max()) <= 2e-5 * float(p10.abs().max())
     np.testing.assert_allclose(engs["geometry"].ab_m.cpu().numpy(), engs["all"].ab_m.cpu().numpy(), rtol=1e-5)
+
+
+def test_1440p_has_14400_tiles_and_fits():
+    """2560 x 1440: 14 400 tiles = 56 KB of tile histogram in LDS.  (Round 3 had put 21 KB of static scheduler state beside
+    it and refused every grid above 10 752 tiles; the block plans' 16 KB now exist only for grids they are used on.)"""
+    from gflow_amd import synthetic as S
+    import gflow_amd.render as R
+    H2, W2, N2 = 1440, 2560, 30000
+    frame = S.make_clip(1, H2, W2, seed=2, device=DEV)[0]
+    frame = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in frame.items()}
+    raw = S.init_splats(frame, N2, seed=2, grown=True)
+    s = dict(W=W2, H=H2, intr=raw["intr"])
+    eng = _engine({k: raw[k] for k in NAMES}, s, frame["image"], frame["depth"], lr=2e-3, lr_camera=0.0, total_iters=10,
+                  lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0)
+    assert eng.T == 90 * 160
+    eng.forward()
+    eng.check_overflow()
+    act = [a.to(DEV) for a in FO.activate(raw)]
+    og = R.render_multiple([*act, raw["intr"].to(DEV), raw["extr"].to(DEV), 0.0, W2, H2], ["rgb", "depth_map"])
+    close_frac(eng.render, torch.cat([og["rgb"], og["depth_map"]]), 2e-5, 2e-6, bad_frac=1e-4, hard=2e-2,
+               what="1440p fused vs operator path")
+    losses = []
+    for _ in range(3):
+        eng.iteration()
+        l_rgb, l_depth = eng.loss_terms()
+        losses.append(float(l_rgb) + 0.1 * float(l_depth))
+    eng.check_overflow()
+    assert losses[2] < losses[0] and all(np.isfinite(losses))
+    sched = torch.cat(eng.schedule()).tolist()
+    assert sorted(sched) == list(range(eng.T))                      # every tile in exactly one queue
