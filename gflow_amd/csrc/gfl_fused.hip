@@ -673,6 +673,50 @@ __device__ __forceinline__ float rows_sum(float x) {
     return y0 + y1;
 }
 
+#define GFL_ROW_SHR(old, val, n) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)), __builtin_bit_cast(int, (val)), 0x110 + (n), 0xF, 0xF, false))
+
+// inclusive scans along the sixteen lanes of a row.  One DPP instruction per step: v_mul_f32_dpp x, x(row_shr:n), x -- a lane
+// whose source lies outside the row is DISABLED by the instruction (bound_ctrl off) and keeps its x, which is what an
+// inclusive scan wants.  (Written with update_dpp + multiply the compiler emitted three instructions per step: the
+// identity, the DPP move, the product.)  The s_nop covers the VALU-write -> DPP-read hazard hipcc does not pad inside asm.
+__device__ __forceinline__ float row_scan_mul(float x) {
+    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf"
+        : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ float row_scan_add(float x) {
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf"
+        : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ float row_sum16(float x) {          // sum over the sixteen lanes of the row, in every lane
+#define GFL_ROW_ROR(val, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (val)), 0x120 + (n), 0xF, 0xF, true))
+    x += GFL_ROW_ROR(x, 1);
+    x += GFL_ROW_ROR(x, 2);
+    x += GFL_ROW_ROR(x, 4);
+    x += GFL_ROW_ROR(x, 8);
+    return x;
+}
+__device__ __forceinline__ int row_max16(int x) {
+#define GFL_ROW_ROR_I(val, n) __builtin_amdgcn_update_dpp(0, (val), 0x120 + (n), 0xF, 0xF, true)
+    x = max(x, GFL_ROW_ROR_I(x, 1));
+    x = max(x, GFL_ROW_ROR_I(x, 2));
+    x = max(x, GFL_ROW_ROR_I(x, 4));
+    x = max(x, GFL_ROW_ROR_I(x, 8));
+    return x;
+}
+// lane 15 of the own row, in every lane of the row (ds_swizzle, bit-mask mode inside 32 lanes: lane' = (lane & 0x10) | 0x0f)
+__device__ __forceinline__ float row_last(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x10 | (0x0F << 5)));
+}
+
 __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(const float* __restrict__ rec,
                                                               const int32_t* __restrict__ ids,
                                                               const int32_t* __restrict__ tile_range, float bg, int W,
@@ -690,6 +734,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     // opacity 1).
     __shared__ RecLDS recs[FB + 1];          // recs[FB]: an all-zero record (opacity 0: never blends)
     __shared__ unsigned char s_mask[FB];
+    __shared__ unsigned char s_hits[4][FB];  // long first tiles: a wave's (= a 4x4 quarter's) hit list of the staged batch
     __shared__ int32_t s_ticket;
     __shared__ int32_t s_simd[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -730,21 +775,6 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     const bool first_tile = item.part >= 0;
     const int blk = (first_tile && end - start > split_min) ? item.part : -1;
     if (first_tile && blk < 0 && item.part > 0) continue;                     // not long enough: its own CU walks it whole
-    const int bs = blk < 0 ? 8 : 4;                                           // edge of a wave's pixel box
-    // wb: the wave's box inside the workgroup's area -- a quarter of the block (blk >= 0: wave k takes quarter k) or an
-    // 8x8 block of the whole tile, the one the item's plan names for this wave's SIMD
-    const unsigned plan = item.plan;
-    const bool plan_ok = blk < 0 && item.part <= 0 && simd_ok &&
-                         ((1 << (plan & 3)) | (1 << ((plan >> 2) & 3)) | (1 << ((plan >> 4) & 3)) | (1 << ((plan >> 6) & 3))) == 15;
-    const int wb = plan_ok ? (int)((plan >> (2 * simd)) & 3u) : wave;
-    const int org_x = tx * GFL_TILE + (blk < 0 ? 0 : (blk & 1) * 8), org_y = ty * GFL_TILE + (blk < 0 ? 0 : (blk >> 1) * 8);
-    const int px0w = org_x + (wb & 1) * bs, py0w = org_y + (wb >> 1) * bs;
-    const int px = px0w + (blk < 0 ? (lane & 7) : (lane & 3)), py = py0w + (blk < 0 ? (lane >> 3) : ((lane >> 2) & 3));
-    // (a block's wave: all four 16-lane rows carry the quarter's sixteen pixels -- four splats per step below --
-    //  and row 0 writes)
-    const bool inside = px < W && py < H;
-    const bool writer = blk < 0 || lane < 16;
-    const float fx = (float)px, fy = (float)py;
     // leave the per-pixel state at the split positions for the backward pass, which walks the first tile of each of
     // ITS queues in segments (first_slot: that queue, -1 for every other tile), at the place of the thread that owns the
     // pixel in the whole-tile layout
@@ -752,16 +782,217 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     const bool heavy = slot >= 0;
     const int parts = heavy ? heavy_parts(end - start) : 1;
     const int seg = heavy_seg(end - start, parts);
-    const bool ck_lane = blk < 0 || lane < 16;
-    const int ftid = blk < 0 ? wb * 64 + lane : blk * 64 + ((py - org_y) << 3) + (px - org_x);
-    float* ck = ckpt + (size_t)max(slot, 0) * (HEAVY_PARTS - 1) * 5 * 256 + ftid;
     int units = 0;                                   // work feedback for the forward schedule (wave-uniform)
+    if (blk >= 0) {
+        // ---- A long first tile: this workgroup walks its 8x8 block `blk`, wave k the block's 4x4 quarter k, SIXTEEN hit
+        // splats of the quarter per step (round 4; round 2 took four, one per 16-lane row, every row running the same chain).
+        // lane = (s, r): s = lane & 15 = the splat of the step, in list order along the sixteen lanes of a row; r = lane >> 4 =
+        // the pixel column of the quarter; four passes g over the quarter's pixel rows.  The transmittance along the sixteen
+        // splats is a ROW SCAN (four DPP multiplies) instead of a chain -- r_k = T_in * prod_{j<=k} (1 - a_j) --, a lane adds
+        // only its own splat's colour, and the sixteen partial sums of a pixel are folded at the checkpoints and at the end.
+        // ~35 VALU instructions per pass, ~150 per step of sixteen (splat, quarter) units, against ~100 per step of four:
+        // the chains of the piles that densification leaves in single tiles set the duration of this launch on real fits
+        // (tools/bwd_trace.py --fwd --fit: ~120 steps of 0.41 us in the slowest quarter of a 1 260-entry list).
+        // The products are formed in tree order: T differs from the one-splat-at-a-time walk in the last bit; the stop rule
+        // (the FIRST splat behind which T would fall below 1e-4) and the last contributor are found on the scanned values.
+        const int ls = lane & 15, lr = lane >> 4;
+        const int qx0 = tx * GFL_TILE + (blk & 1) * 8 + (wave & 1) * 4, qy0 = ty * GFL_TILE + (blk >> 1) * 8 + (wave >> 1) * 4;
+        const float fxq = (float)(qx0 + lr);
+        float Tq[4], c0q[4], c1q[4], c2q[4], c3q[4];
+        int lastq[4];
+        unsigned alive = 0;                          // bit g: pixel (column lr, row g) is in the image and has not stopped
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            Tq[g] = 1.f; c0q[g] = 0.f; c1q[g] = 0.f; c2q[g] = 0.f; c3q[g] = 0.f; lastq[g] = 0;
+            if (qx0 + lr < W && qy0 + g < H) alive |= 1u << g;
+        }
+        // (checkpoint layout of the backward pass: [boundary][T C0 C1 C2 C3][256 pixels of the tile, block-major])
+        float* ckq = ckpt + (size_t)max(slot, 0) * (HEAVY_PARTS - 1) * 5 * 256 + blk * 64 + ((((wave >> 1) * 4) << 3) | ((wave & 1) * 4 + lr));
+        auto write_ckpt = [&](int k) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float s0 = row_sum16(c0q[g]), s1 = row_sum16(c1q[g]), s2 = row_sum16(c2q[g]), s3 = row_sum16(c3q[g]);
+                if (ls == 0) {
+                    float* c5 = ckq + (size_t)(k - 1) * 5 * 256 + (g << 3);
+                    c5[0] = Tq[g]; c5[256] = s0; c5[512] = s1; c5[768] = s2; c5[1024] = s3;
+                }
+            }
+        };
+        int ck_nextq = 1;
+#ifdef GFL_TRACE
+        long long tq_stage = 0, tq_walk = 0, tq_mark = wall_clock64();
+        int tq_steps = 0;
+#endif
+        for (int base = start; base < end; base += FB) {
+#ifdef GFL_TRACE
+            { const long long now = wall_clock64(); tq_walk += now - tq_mark; tq_mark = now; }
+#endif
+            if (__syncthreads_and(alive == 0)) break;
+            const int idx = base + tid;
+            if (idx < end) {
+                const int gidx = ids[idx];
+                const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)gidx * REC);
+                float4 p0 = r4[0], p1 = r4[1], p2 = r4[2];
+                if (mode == 1) {
+                    const float3 col = cmap_nonzero_lookup(p2.y, cmap_mm, cmap_lut);
+                    p1.z = col.x; p1.w = col.y; p2.x = col.z;
+                } else if (mode == 2) {
+                    p0.z = 1.f; p0.w = 0.f; p1.x = 1.f; p1.y = 1.f;
+                    p2.z = p2.z < 0.f ? p2.z : alpha_cutoff(1.f, 1.f);
+                }
+                recs[tid].p0 = p0; recs[tid].p1 = p1; recs[tid].p2 = p2;
+                s_mask[tid] = (unsigned char)block_mask(p0, p1, p2.z, tx * GFL_TILE + (blk & 1) * 8, ty * GFL_TILE + (blk >> 1) * 8, 4);
+            }
+            __syncthreads();
+#ifdef GFL_TRACE
+            { const long long now = wall_clock64(); tq_stage += now - tq_mark; tq_mark = now; }
+#endif
+            const int cnt = min(FB, end - base);
+            if (__all(alive == 0)) continue;         // this wave is finished; keep meeting the barriers
+            // ---- the quarter's hit list of the batch (slot order = list order); gs[k]: hits in front of 64-slot group k.
+            // Once pixels have stopped, only splats that reach the box of the pixels still ALIVE matter (in a tile where
+            // densification piled up a thousand small splats the pile's own pixels stop early and the rest of the pile
+            // reaches no one else): the test of block_mask on that smaller box -- drops only what contributes nothing.
+            const bool all_alive = __all(alive == 0xFu);
+            float bx_lo = 0.f, bx_hi = 0.f, by_lo = 0.f, by_hi = 0.f;
+            if (!all_alive) {
+                unsigned arows = alive;
+                arows |= (unsigned)__shfl_xor((int)arows, 16);
+                arows |= (unsigned)__shfl_xor((int)arows, 32);           // pixel rows with an alive pixel (wave-uniform)
+                const unsigned long long acol = __ballot(alive != 0);   // lanes of the columns with an alive pixel
+                const unsigned cols = (unsigned)((acol & 1ull) | ((acol >> 15) & 2ull) | ((acol >> 30) & 4ull) | ((acol >> 45) & 8ull));
+                bx_lo = (float)(qx0 + __builtin_ctz(cols | 16u)); bx_hi = (float)(qx0 + 31 - __builtin_clz(cols | 1u));
+                by_lo = (float)(qy0 + __builtin_ctz(arows | 16u)); by_hi = (float)(qy0 + 31 - __builtin_clz(arows | 1u));
+            }
+            static_assert(FB == 256, "four 64-slot groups per staged batch");
+            int g1 = 0, g2 = 0, g3 = 0;                  // hits in front of the 64-slot groups 1, 2, 3 (group 0: none)
+            int n_hit = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k == 1) g1 = n_hit;
+                if (k == 2) g2 = n_hit;
+                if (k == 3) g3 = n_hit;
+                const int sl = 64 * k + lane;
+                bool hit = sl < cnt && ((s_mask[sl] >> wave) & 1);
+                if (!all_alive && hit) {
+                    const BlockTest t = block_test(recs[sl].p0, recs[sl].p1, recs[sl].p2.z);
+                    hit = box_hit(t, bx_lo, bx_hi, by_lo, by_hi);
+                }
+                const unsigned long long bal = __ballot(hit);
+                if (hit) s_hits[wave][n_hit + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0))] = (unsigned char)sl;
+                n_hit += (int)__popcll(bal);
+            }
+            units += n_hit;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the list is read back by other lanes of this wave)
+            // the steps, cut where the backward pass wants a checkpoint (a list position that is a multiple of 64)
+            int h = 0, k = 0;
+            for (;;) {
+                int h_hi = n_hit;
+                bool due = false;
+                for (; k < 4; ++k)
+                    if (64 * k < cnt && ck_nextq < parts && base - start + 64 * k == ck_nextq * seg) {
+                        h_hi = k == 0 ? 0 : (k == 1 ? g1 : (k == 2 ? g2 : g3));
+                        due = true;
+                        break;
+                    }
+                for (; h < h_hi && !__all(alive == 0); h += 16) {
+#ifdef GFL_TRACE
+                    ++tq_steps;
+#endif
+                    const bool have = h + ls < h_hi;
+                    const int j = have ? (int)s_hits[wave][h + ls] : FB;
+                    const int pos1 = base - start + j + 1;
+                    const float4 q0 = recs[j].p0, q1 = recs[j].p1, q2 = recs[j].p2;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float fyq = (float)(qy0 + g);
+                        float al, G;
+                        const bool val = splat_alpha2(q0, q1, fxq, fyq, al, G);
+                        const float a = val ? al : 0.f;
+                        const bool live = (alive >> g) & 1u;
+                        const float P = row_scan_mul(1.f - a);                    // prod_{j<=k} (1 - a_j) along the row
+                        const float Pex = GFL_ROW_SHR(1.0f, P, 1);                // prod_{j<k}
+                        const float Tin = live ? Tq[g] : 0.f;
+                        const float r = Tin * P, q = Tin * Pex;                   // T behind / in front of this lane's splat
+                        bool stopped = false;
+                        const unsigned long long sb = __ballot(live && r < GFL_T_MIN);
+                        if (sb != 0ull) {
+                            // (rare: a pixel stops at most once.)  Per row: the first lane whose splat would take T below the
+                            // threshold; it and everything behind it blend with weight 0, T keeps the value in front of it
+                            float t_new = Tq[g];
+                            int fs_mine = 16;
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) {
+                                const unsigned bits = (unsigned)(sb >> (16 * rr)) & 0xffffu;
+                                if (bits == 0u) continue;
+                                const int fs = __builtin_ctz(bits);
+                                const float t_before = fs == 0 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Tq[g]), 16 * rr))
+                                                               : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 16 * rr + fs - 1));
+                                if (lr == rr) { fs_mine = fs; t_new = t_before; }
+                            }
+                            stopped = ls >= fs_mine;
+                            if (fs_mine < 16) { Tq[g] = t_new; alive &= ~(1u << g); }
+                        }
+                        const float w = (stopped || !live) ? 0.f : a * q;
+                        c0q[g] = fmaf(q1.z, w, c0q[g]); c1q[g] = fmaf(q1.w, w, c1q[g]);
+                        c2q[g] = fmaf(q2.x, w, c2q[g]); c3q[g] = fmaf(q2.y, w, c3q[g]);
+                        lastq[g] = max(lastq[g], (val && live && !stopped) ? pos1 : 0);
+                        const float r15 = row_last(r);
+                        if ((alive >> g) & 1u) Tq[g] = r15;                        // (rows that stopped keep t_new)
+                    }
+                    // (Measured and dropped: the four passes as one branch-free block -- alphas and scans of all four first,
+                    //  ONE test for a stop, then the four accumulations --, so that a lone wave has four independent streams
+                    //  to issue from: the forward's average inside a clip fit went from 53.9 to 59.2 us; the sixteen values
+                    //  kept live across the phases cost more than the interleaving gave.)
+                }
+                h = h_hi;
+                if (!due) break;
+                write_ckpt(ck_nextq);
+                ++ck_nextq;
+                ++k;
+            }
+        }
+        // the wave stopped before a split position: every pixel's state is frozen, final = checkpoint
+        for (; ck_nextq < parts; ++ck_nextq) write_ckpt(ck_nextq);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float s0 = row_sum16(c0q[g]), s1 = row_sum16(c1q[g]), s2 = row_sum16(c2q[g]), s3 = row_sum16(c3q[g]);
+            const int lastp = row_max16(lastq[g]);
+            if (ls == 0 && qx0 + lr < W && qy0 + g < H) {
+                const size_t pix = (size_t)(qy0 + g) * W + (qx0 + lr), plane = (size_t)H * W;
+                const float Tf = Tq[g];
+                out[pix] = fmaf(Tf, bg, s0);
+                out[plane + pix] = fmaf(Tf, bg, s1);
+                out[2 * plane + pix] = fmaf(Tf, bg, s2);
+                out[3 * plane + pix] = fmaf(Tf, bg, s3);
+                final_T[pix] = Tf;
+                n_contrib[pix] = lastp;
+            }
+        }
+        if (mode == 0 && lane == 0) atomicAdd(&tile_work[4 * tile + blk], units + 1);
+#ifdef GFL_TRACE
+        if (lane == 0 && tile < 4096 && mode == 0) {
+            long long* t2 = g_fwd_trace2 + ((size_t)tile * 16 + blk * 4 + wave) * 4;
+            t2[0] = tq_stage; t2[1] = tq_walk + (wall_clock64() - tq_mark); t2[2] = tq_steps; t2[3] = units;
+        }
+#endif
+        continue;
+    }
+    // ---- every other tile: a wave walks an 8x8 block of the tile, the one the item's plan names for this wave's SIMD
+    const unsigned plan = item.plan;
+    const bool plan_ok = item.part <= 0 && simd_ok &&
+                         ((1 << (plan & 3)) | (1 << ((plan >> 2) & 3)) | (1 << ((plan >> 4) & 3)) | (1 << ((plan >> 6) & 3))) == 15;
+    const int wb = plan_ok ? (int)((plan >> (2 * simd)) & 3u) : wave;
+    const int org_x = tx * GFL_TILE, org_y = ty * GFL_TILE;
+    const int px0w = org_x + (wb & 1) * 8, py0w = org_y + (wb >> 1) * 8;
+    const int px = px0w + (lane & 7), py = py0w + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float fx = (float)px, fy = (float)py;
+    float* ck = ckpt + (size_t)max(slot, 0) * (HEAVY_PARTS - 1) * 5 * 256 + wb * 64 + lane;
     int ck_next = 1;                                 // next boundary to checkpoint: position ck_next * seg
 #ifdef GFL_TRACE
     const long long trace_t0 = wall_clock64();
     int trace_units = 0;
-    long long trace_stage = 0, trace_walk = 0, trace_mark = trace_t0;
-    int trace_steps = 0;
 #endif
 
     // Tw: working transmittance, set to 0 when the pixel stops (T would fall below 1e-4) so that
@@ -772,9 +1003,6 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     const unsigned long long alive0 = __ballot(inside);            // every pixel of the box that is in the image
 
     for (int base = start; base < end; base += FB) {
-#ifdef GFL_TRACE
-        { const long long now = wall_clock64(); trace_walk += now - trace_mark; trace_mark = now; }
-#endif
         if (__syncthreads_and(Tw == 0.f)) break;
         const int idx = base + tid;
         if (idx < end) {
@@ -789,21 +1017,16 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                 p2.z = p2.z < 0.f ? p2.z : alpha_cutoff(1.f, 1.f);
             }
             recs[tid].p0 = p0; recs[tid].p1 = p1; recs[tid].p2 = p2;
-            s_mask[tid] = (unsigned char)block_mask(p0, p1, p2.z, org_x, org_y, bs);
+            s_mask[tid] = (unsigned char)block_mask(p0, p1, p2.z, org_x, org_y);
         }
         __syncthreads();
-#ifdef GFL_TRACE
-        { const long long now = wall_clock64(); trace_stage += now - trace_mark; trace_mark = now; }
-#endif
         const int cnt = min(FB, end - base);
         if (__all(Tw == 0.f)) continue;      // this wave is finished; keep meeting the barriers
         for (int c0 = 0; c0 < cnt; c0 += 64) {
             if (__all(Tw == 0.f)) break;
             if (ck_next < parts && base - start + c0 == ck_next * seg) {
                 float* c5 = ck + (size_t)(ck_next - 1) * 5 * 256;
-                float c0_ = a0, c1_ = a1, c2_ = a2, c3_ = a3;
-                if (blk >= 0) { c0_ = rows_sum(a0); c1_ = rows_sum(a1); c2_ = rows_sum(a2); c3_ = rows_sum(a3); }
-                if (ck_lane) { c5[0] = T; c5[256] = c0_; c5[512] = c1_; c5[768] = c2_; c5[1024] = c3_; }
+                c5[0] = T; c5[256] = a0; c5[512] = a1; c5[768] = a2; c5[1024] = a3;
                 ++ck_next;
             }
             const int slot = c0 + lane;
@@ -815,22 +1038,14 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                 // beside it (the launch lasted as long as that one chain).  Test each slot's alpha >= 1/255 disc
                 // against the bounding box of the alive pixels (the test of block_mask, on a smaller box):
                 // drops only work that contributes exactly nothing.
-                const unsigned long long alive = __ballot(Tw != 0.f);   // lane = (y << 3) | x of the 8x8 block, (y << 2) | x of a quarter
+                const unsigned long long alive = __ballot(Tw != 0.f);   // lane = (y << 3) | x of the 8x8 block
                 if (alive != alive0) {
-                    int xl, xh, yl, yh;
-                    if (blk < 0) {
-                        unsigned long long a = alive | (alive >> 32);
-                        a |= a >> 16;
-                        a |= a >> 8;
-                        const unsigned cols = (unsigned)a & 0xffu;               // columns with an alive pixel
-                        xl = __builtin_ctz(cols); xh = 31 - __builtin_clz(cols);
-                        yl = (int)__builtin_ctzll(alive) >> 3; yh = (63 - (int)__builtin_clzll(alive)) >> 3;
-                    } else {
-                        const unsigned a16 = (unsigned)alive & 0xffffu;
-                        const unsigned cols = (a16 | (a16 >> 4) | (a16 >> 8) | (a16 >> 12)) & 0xfu;
-                        xl = __builtin_ctz(cols); xh = 31 - __builtin_clz(cols);
-                        yl = __builtin_ctz(a16) >> 2; yh = (31 - __builtin_clz(a16)) >> 2;
-                    }
+                    unsigned long long a = alive | (alive >> 32);
+                    a |= a >> 16;
+                    a |= a >> 8;
+                    const unsigned cols = (unsigned)a & 0xffu;               // columns with an alive pixel
+                    const int xl = __builtin_ctz(cols), xh = 31 - __builtin_clz(cols);
+                    const int yl = (int)__builtin_ctzll(alive) >> 3, yh = (63 - (int)__builtin_clzll(alive)) >> 3;
                     if (hit) {
                         const BlockTest t = block_test(recs[slot].p0, recs[slot].p1, recs[slot].p2.z);
                         hit = box_hit(t, (float)(px0w + xl), (float)(px0w + xh), (float)(py0w + yl), (float)(py0w + yh));
@@ -838,52 +1053,6 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                 }
             }
             unsigned long long bits = __ballot(hit);
-            if (blk >= 0) {
-                // A block's wave: FOUR hit splats per step, one per 16-lane row, each row the quarter's sixteen pixels.
-                // A row evaluates its splat's alpha; two permlane swaps hand every lane the four alphas of its pixel, and
-                // every row runs the SAME transmittance chain over them in list order (T, the stop rule and the last
-                // contributor are bit-identical to the one-splat-at-a-time walk); a row adds only its own splat's
-                // colour, the rows' sums are added up at the checkpoints and at the end.  ~22 instead of ~45 issue
-                // slots per (splat, quarter) unit: the chains of the longest tiles set the launch time.
-                const int row = lane >> 4;
-                while (bits) {
-                    units += min((int)__popcll(bits), 4);
-#ifdef GFL_TRACE
-                    ++trace_steps;
-#endif
-                    int j[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        j[u] = bits ? c0 + (int)__builtin_ctzll(bits) : FB;
-                        bits &= bits - 1;
-                    }
-                    const int js = row == 0 ? j[0] : (row == 1 ? j[1] : (row == 2 ? j[2] : j[3]));
-                    const float4 q0 = recs[js].p0, q1 = recs[js].p1, q2 = recs[js].p2;
-                    float al, G;
-                    const bool val = splat_alpha2(q0, q1, fx, fy, al, G);
-                    const float a_mine = val ? al : 0.f;
-                    float lo = a_mine, hi = a_mine;
-                    permlane32_swap(lo, hi);                 // lo = rows {0, 1, 0, 1}, hi = rows {2, 3, 2, 3}
-                    float av[4] = {lo, lo, hi, hi};
-                    permlane16_swap(av[0], av[1]);           // row 0 / row 1 in every row
-                    permlane16_swap(av[2], av[3]);
-                    float w_mine = 0.f;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float a = av[u];
-                        const float test_T = Tw * (1.f - a);
-                        const bool stop = test_T < GFL_T_MIN;
-                        const float w = stop ? 0.f : a * Tw;
-                        w_mine = row == u ? w : w_mine;
-                        T = stop ? T : test_T;
-                        Tw = stop ? 0.f : test_T;
-                        last = (a > 0.f && !stop) ? base - start + j[u] + 1 : last;
-                    }
-                    a0 = fmaf(q1.z, w_mine, a0); a1 = fmaf(q1.w, w_mine, a1); a2 = fmaf(q2.x, w_mine, a2); a3 = fmaf(q2.y, w_mine, a3);
-                    if (__all(Tw == 0.f)) break;
-                }
-                continue;
-            }
             // FWD_UNITS (4) hit splats per trip: their records are fetched and their alphas
             // evaluated together; only the T recurrence is serial.  The body is branch-free: a lane
             // that skips a splat contributes w = 0.  A wave issues one instruction at a time, so the
@@ -929,8 +1098,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
             }
         }
     }
-    if (blk >= 0) { a0 = rows_sum(a0); a1 = rows_sum(a1); a2 = rows_sum(a2); a3 = rows_sum(a3); }
-    if (inside && writer) {
+    if (inside) {
         const size_t pix = (size_t)py * W + px, plane = (size_t)H * W;
         out[pix] = fmaf(T, bg, a0);
         out[plane + pix] = fmaf(T, bg, a1);
@@ -939,17 +1107,13 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
         final_T[pix] = T;
         n_contrib[pix] = last;
     }
-    if (mode == 0 && lane == 0) atomicAdd(&tile_work[4 * tile + (blk < 0 ? wb : blk)], units + 1);     // per 8x8 block (gfl_sched.hpp: block plan)
+    if (mode == 0 && lane == 0) atomicAdd(&tile_work[4 * tile + wb], units + 1);     // per 8x8 block (gfl_sched.hpp: block plan)
     // the wave stopped before the split position: every pixel's state is frozen, final = checkpoint
     for (; ck_next < parts; ++ck_next) {
         float* c5 = ck + (size_t)(ck_next - 1) * 5 * 256;
-        if (ck_lane) { c5[0] = T; c5[256] = a0; c5[512] = a1; c5[768] = a2; c5[1024] = a3; }
+        c5[0] = T; c5[256] = a0; c5[512] = a1; c5[768] = a2; c5[1024] = a3;
     }
 #ifdef GFL_TRACE
-    if (blk >= 0 && lane == 0 && tile < 4096) {
-        long long* t2 = g_fwd_trace2 + ((size_t)tile * 16 + blk * 4 + wave) * 4;
-        t2[0] = trace_stage; t2[1] = trace_walk + (wall_clock64() - trace_mark); t2[2] = trace_steps; t2[3] = units;
-    }
     const int trace_done = __popcll(__ballot(Tw == 0.f && inside));
     if (lane == 0 && tile < 16384) {
         unsigned hw, xcc;
@@ -1334,25 +1498,6 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
 #define GFL_ROWS_BATCH 128
 #endif
 constexpr int RB_BATCH = GFL_ROWS_BATCH;   // staged splats per batch (LDS: 96 B per slot + 8 KB of pixel state -> 8 workgroups per CU at 128)
-
-#define GFL_ROW_SHR(old, val, n) \
-    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)), __builtin_bit_cast(int, (val)), 0x110 + (n), 0xF, 0xF, false))
-
-// inclusive scans along the sixteen lanes of a row (lanes shifted in from outside the row keep the identity)
-__device__ __forceinline__ float row_scan_mul(float x) {
-    x *= GFL_ROW_SHR(1.0f, x, 1);
-    x *= GFL_ROW_SHR(1.0f, x, 2);
-    x *= GFL_ROW_SHR(1.0f, x, 4);
-    x *= GFL_ROW_SHR(1.0f, x, 8);
-    return x;
-}
-__device__ __forceinline__ float row_scan_add(float x) {
-    x += GFL_ROW_SHR(0.0f, x, 1);
-    x += GFL_ROW_SHR(0.0f, x, 2);
-    x += GFL_ROW_SHR(0.0f, x, 4);
-    x += GFL_ROW_SHR(0.0f, x, 8);
-    return x;
-}
 
 // the 4x4 quarters of two 8x8 blocks (b0, b0 + 1) of a tile a staged splat reaches with alpha >= 1/255:
 // bit 4 * (b - b0) + c, c = the quarter inside the block (x fastest)
