@@ -622,7 +622,9 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* _
 constexpr int BLEND_WG_PER_CU = 8;
 constexpr int FWD_WG_PER_CU = 6;       // the forward blend trades two workgroups per CU for 72 VGPRs (FWD_UNITS)
 constexpr int FWD_UNITS = 4;
-constexpr int FWD_SPLIT_MIN = 256;     // forward: a queue's first tile is walked as four blocks on four CUs when its list is longer
+constexpr int FWD_SPLIT_MIN = 448;     // forward: a queue's first tile is walked as four blocks on four CUs when its list is longer
+                                       // (round 4 sweep, sixteen-splat steps: bench-scene forward 47.0 / 40.8 / 39.7 / 39.7 us and 4-frame clip
+                                       //  fit 0.483 / 0.485 / 0.490 / 0.523 s at 256 / 448 / 640 / never)
 constexpr int FB = 256;   // staged splats per batch (forward)
 constexpr int FBB = 192;  // backward: 18.6 KB of LDS per workgroup -> 8 workgroups per CU (the tile queues of
                           // gfl_sched.hpp assume that all workgroups of a blend launch are resident)

@@ -1,4 +1,7 @@
-for r in 1 2; do for m in 256 192 320 160; do
-  echo -n "split $m: clip "; GFL_FWD_SPLIT_MIN=$m python tools/profile_clip.py 8 10 | grep "^total" | cut -d= -f2
-  echo -n "split $m: step "; GFL_FWD_SPLIT_MIN=$m python bench.py --steps 200 --warmup 50 --no-clip --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['stage_ms']['blend_fwd'])"
-done; done
+for v in 256 448 640 896 100000; do
+  echo "== split_min $v"
+  GFL_FWD_SPLIT_MIN=$v python bench.py --no-clip --no-cpu-baseline --steps 100 --warmup 10 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); st=d['stage_ms']; print('  bench step %.4f ms  fwd %.1f us' % (d['ms_per_step'], 1e3*st['blend_fwd']))"
+  GFL_FWD_SPLIT_MIN=$v python tools/clip_repeat.py 5 4 2>&1 | tail -1 | cut -c1-110
+done
