@@ -1318,13 +1318,10 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
     if (tile < 0) break;
     const unsigned plan = item.plan;
     const bool plan_ok = simd_ok && ((1 << (plan & 3)) | (1 << ((plan >> 2) & 3)) | (1 << ((plan >> 4) & 3)) | (1 << ((plan >> 6) & 3))) == 15;
-#ifdef GFL_ROTATE_PARTS
-    // segments of one tile run side by side and their blocks differ a lot ([78 0 77 0] next to [0 69 0 65]): turn the plan by
-    // one SIMD per segment so that they do not all load the same two SIMDs at the same time
-    const int psimd = (simd + (item.part > 0 ? item.part : 0)) & 3;
-#else
-    const int psimd = simd;
-#endif
+    // segments of one tile run side by side on one CU and a pile sits in ONE of its blocks: from four segments on, segment
+    // p turns the plan by p SIMDs (the scheduler counts such a tile's blocks a quarter each on every SIMD: Sched.rotate)
+    const int n_parts_ = item.part >= 0 ? heavy_parts(tile_range[2 * tile + 1] - tile_range[2 * tile]) : 1;
+    const int psimd = (queue.rotate && n_parts_ >= 4) ? ((simd + item.part) & 3) : simd;
     const int blk = plan_ok ? (int)((plan >> (2 * psimd)) & 3u) : wave;         // the 8x8 block of the tile this wave walks
     const int tx = tile % gx, ty = tile / gx;
     const int px = tx * GFL_TILE + (blk & 1) * 8 + (lane & 7);
@@ -2467,6 +2464,19 @@ static int sched_xcd() {
     return v;
 }
 
+// GFL_BWD_ROTATE=1: the segments of a heavy first tile turn the block plan by one SIMD each, and the scheduler counts such a
+// tile's blocks a quarter each on every SIMD.  Built on the trace's finding that a CU ends with its busiest SIMD (a pile
+// in one 8x8 block puts 8 segments x 150 units on one SIMD); measured on one box, alternating, 4-frame clip fits: median
+// 0.4852 / 0.4869 s with it against 0.4782 / 0.4838 s without, bench step 0.2061 against 0.2057 ms.  Off.
+static int bwd_rotate() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GFL_BWD_ROTATE");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v;
+}
+
 // GFL_SCHED_NEXT=0: the tile queues are built in line by the scatter launch in every iteration (rounds 1-2), not at the end
 // of the previous iteration
 static bool next_sched_enabled() {
@@ -2648,7 +2658,9 @@ static FitWs carve(const gfl_fit_state* st) {
     w.sched.cap_q = (int)(((size_t)SCHED_MAX_QUEUES * sched_queue_capacity((int)T, 64)) / w.sched.nq);
     w.sched.split_min = 0;
     w.sched.xcd = sched_xcd();
+    w.sched.rotate = 0;
     w.sched_fwd = w.sched;
+    w.sched.rotate = bwd_rotate();
     w.sched_fwd.work = (int32_t*)p;
     p += up256(4 * T * sizeof(int32_t));
     w.sched_fwd.list = (int32_t*)p;
@@ -2784,7 +2796,7 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
     if (rc) return rc;
     {
         StageScope p(ST_BLEND_FWD, s);
-        const TileQueue q = {w.sched_fwd.list, w.sched_fwd.count, w.sched.counters, w.sched.nq, w.sched.cap_q};
+        const TileQueue q = {w.sched_fwd.list, w.sched_fwd.count, w.sched.counters, w.sched.nq, w.sched.cap_q, 0};
         fused_blend_fwd_kernel<<<blend_grid(T, FWD_WG_PER_CU), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx,
                                                              st->render, st->final_T, st->n_contrib, q, w.ckpt, 0, nullptr,
                                                              nullptr, fwd_split_min(), w.sched_fwd.work, w.sched.first_slot);
@@ -2880,7 +2892,7 @@ int gfl_fit_snapshot(const gfl_fit_state* st, const gfl_fit_hyper* hp, const flo
     if (st->N > 0) rec_depth_range_kernel<<<min((st->N + 255) / 256, 32), 256, 0, s>>>(st->rec, st->N, mm);
     for (int mode = 1; mode <= 2; ++mode) {
         // (the forward launch of the iteration used up the engine's own pull counters)
-        const TileQueue q = {w.sched_fwd.list, w.sched_fwd.count, pull + (mode - 1) * SCHED_MAX_QUEUES, w.sched.nq, w.sched.cap_q};
+        const TileQueue q = {w.sched_fwd.list, w.sched_fwd.count, pull + (mode - 1) * SCHED_MAX_QUEUES, w.sched.nq, w.sched.cap_q, 0};
         fused_blend_fwd_kernel<<<blend_grid(T, FWD_WG_PER_CU), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H,
                                                                             gx, mode == 1 ? img_dc : img_c, fT, nc, q, w.ckpt,
                                                                             mode, mm, lut, fwd_split_min(), w.sched_fwd.work,
@@ -2960,7 +2972,7 @@ int gfl_render_bwd(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float
     const FitWs w = carve(st);
     {
         StageScope p(ST_BLEND_BWD, s);
-        const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters + w.sched.nq, w.sched.nq, w.sched.cap_q};
+        const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters + w.sched.nq, w.sched.nq, w.sched.cap_q, w.sched.rotate};
         fused_blend_bwd_kernel<10><<<blend_grid(T), 256, 0, s>>>(st->rec, st->ids, st->tile_range, hp->bg, st->W, st->H, gx,
                                                                     st->final_T, st->n_contrib, d_render, w.pair_grad, q,
                                                                     w.sched.work, w.ckpt, st->render, LossTail{});
@@ -3023,7 +3035,7 @@ static int fit_backward_step_impl(const gfl_fit_state* st, const gfl_fit_hyper* 
     }
     {
         StageScope p(ST_BLEND_BWD, s);
-        const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters + w.sched.nq, w.sched.nq, w.sched.cap_q};
+        const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters + w.sched.nq, w.sched.nq, w.sched.cap_q, w.sched.rotate};
         const int sums = !bwd_geom_only() ? 10 : (hp->freeze_all_splats ? 6 : (hp->freeze_rgb ? 7 : 10));
         if (bwd_rows()) {
             auto kern = sums == 6 ? fused_blend_bwd_rows_kernel<6> : (sums == 7 ? fused_blend_bwd_rows_kernel<7> : fused_blend_bwd_rows_kernel<10>);

@@ -51,9 +51,26 @@ struct Sched {
     int cap_q;           // capacity of one queue
     int split_min;       // forward schedule: a first tile with a longer list is walked on four CUs; 0: never
     int xcd;             // 1: XCD-local bands + snake deal (schedule_tiles_xcd) instead of the batched LPT
+    int rotate;          // backward schedule: the segments of a queue's first tile (four or more of them) turn the block plan by
+                         // one SIMD each, so the tile's blocks count a quarter of its weight on every SIMD (see the kernel)
 };
 
 __host__ __device__ inline int sched_queue_capacity(int T, int nq) { return 2 * ((T + nq - 1) / nq) + 8; }
+
+// The heaviest tile of a queue is walked in up to HEAVY_PARTS segments of its list by as many
+// workgroups of the CU (backward); the forward pass leaves a checkpoint at every segment boundary.
+// heavy_parts: number of segments; heavy_seg: their length, a multiple of 64 (the last is shorter).
+#ifndef GFL_HEAVY_PARTS
+#define GFL_HEAVY_PARTS 8
+#endif
+#ifndef GFL_HEAVY_SEG
+#define GFL_HEAVY_SEG 160
+#endif
+constexpr int HEAVY_PARTS = GFL_HEAVY_PARTS;
+__device__ __forceinline__ int heavy_parts(int total) {
+    return total <= 128 ? 1 : min(HEAVY_PARTS, max(2, (total + GFL_HEAVY_SEG - 1) / GFL_HEAVY_SEG));
+}
+__device__ __forceinline__ int heavy_seg(int total, int parts) { return ((total + parts - 1) / parts + 63) & ~63; }
 
 // ---- block plan (round 3).  A blend workgroup has one wave on each of its CU's four SIMDs, a wave walks ONE 8x8 block of the
 // tile, and the blend kernels are issue bound: a CU is done when its BUSIEST SIMD is done.  Measured on a real fit
@@ -455,7 +472,12 @@ __device__ void schedule_tiles_xcd(const int32_t* __restrict__ tile_counts, int 
                 const int prio = k > 0 ? 0 : (wt * 5 >= target * 2 ? 3 : (wt * 4 >= target ? 2 : 1));
                 unsigned plan = ITEM_PLAN_IDENTITY;
                 if (frac4 && tile < SCHED_PLAN_TILES) {
-                    const uint32_t fr = frac4[tile];
+                    uint32_t fr = frac4[tile];
+                    // A first tile that the backward pass walks as four or more segments side by side: segment p turns the
+                    // plan by p SIMDs, so every SIMD sees every block in turn.  (One pile in one 8x8 block -- [57 0 153 0]
+                    // units per segment, eight segments -- otherwise puts 1 200 units on ONE SIMD of a CU whose fair share
+                    // per SIMD is 380; tools/bwd_trace.py --fit: CU end = 0.12 x its busiest SIMD's units + 13 us, r = 0.81.)
+                    if (sc.rotate && k == 0 && sc.first_slot && heavy_parts(tile_counts[tile]) >= 4) fr = 0x40404040u;
                     const int bw[4] = {(int)(fr & 255u) * wt, (int)((fr >> 8) & 255u) * wt, (int)((fr >> 16) & 255u) * wt,
                                        (int)(fr >> 24) * wt};
                     plan = plan_blocks(bw, key);
@@ -492,6 +514,7 @@ struct TileQueue {
     int32_t* counter;    // [nq] for this launch
     int nq;
     int cap_q;
+    int rotate;          // Sched.rotate of the schedule these queues come from
 };
 
 // Item of a queue.  part: -1 = the whole tile; 0 .. HEAVY_PARTS-1 = that segment of the queue's
@@ -502,21 +525,6 @@ struct TileItem {
     int queue;
     unsigned plan;   // block plan (ITEM_PLAN_*): plan >> (2 * simd) & 3 = the block the wave on that SIMD walks
 };
-
-// The heaviest tile of a queue is walked in up to HEAVY_PARTS segments of its list by as many
-// workgroups of the CU (backward); the forward pass leaves a checkpoint at every segment boundary.
-// heavy_parts: number of segments; heavy_seg: their length, a multiple of 64 (the last is shorter).
-#ifndef GFL_HEAVY_PARTS
-#define GFL_HEAVY_PARTS 8
-#endif
-#ifndef GFL_HEAVY_SEG
-#define GFL_HEAVY_SEG 160
-#endif
-constexpr int HEAVY_PARTS = GFL_HEAVY_PARTS;
-__device__ __forceinline__ int heavy_parts(int total) {
-    return total <= 128 ? 1 : min(HEAVY_PARTS, max(2, (total + GFL_HEAVY_SEG - 1) / GFL_HEAVY_SEG));
-}
-__device__ __forceinline__ int heavy_seg(int total, int parts) { return ((total + parts - 1) / parts + 63) & ~63; }
 
 // next item of this workgroup's queue.  Whole workgroup.  `split`: backward launch.
 __device__ __forceinline__ TileItem next_item(const TileQueue& q, int32_t* s_ticket, bool first, bool split) {
