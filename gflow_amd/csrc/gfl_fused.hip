@@ -620,7 +620,9 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* _
 
 // ------------------------------------------------------------------- blend (C = 4)
 constexpr int BLEND_WG_PER_CU = 8;
-constexpr int FWD_WG_PER_CU = 6;       // the forward blend trades two workgroups per CU for 72 VGPRs (FWD_UNITS)
+constexpr int FWD_WG_PER_CU = 5;       // the forward blend trades workgroups per CU for registers: 72 VGPRs for four splats per trip (six per CU,
+                                       // rounds 1-3); 96 since the long-tile walk keeps sixteen colour sums per lane (round 4: at six per CU the
+                                       // kernel spilled 23 registers -- 28 MB of scratch traffic per launch; five cost nothing measurable)
 constexpr int FWD_UNITS = 4;
 constexpr int FWD_SPLIT_MIN = 448;     // forward: a queue's first tile is walked as four blocks on four CUs when its list is longer
                                        // (round 4 sweep, sixteen-splat steps: bench-scene forward 47.0 / 40.8 / 39.7 / 39.7 us and 4-frame clip
