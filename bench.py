@@ -159,6 +159,10 @@ def reduce_and_report(local, dist, red_dev, rank, world, args, backend, size=Non
     vec = [local["elapsed"], float(local["steps"]), local["psnr_step"], float(local["K"])]
     if clip is not None:
         vec += [clip[k] for k in ("frames", "iterations", "rasterisations", "psnr_sum", "splats_final")] + [clip.get("clips", 1)]
+        # every rank's OWN clip wall time in a slot of its own: the one SUM hands rank 0 all of them (the shard's imbalance)
+        own = [0.0] * world
+        own[rank] = float(local.get("clip_wall_own", local["clip_wall"]))
+        vec += own
     stats = torch.tensor(vec, dtype=torch.float64, device=red_dev)
     tmax = torch.tensor([local["elapsed"], local["clip_wall"]], dtype=torch.float64, device=red_dev)
     if dist is not None:
@@ -194,7 +198,7 @@ def reduce_and_report(local, dist, red_dev, rank, world, args, backend, size=Non
                     "splats_final_mean": float(stats[8].item()) / max(float(stats[9].item()), 1.0),
                     "snapshot_interval": args.snapshot_interval,
                     "clips_per_rank": int(round(float(stats[9].item()) / world)),
-                    "rank_wall_s": local.get("rank_walls")}
+                    "rank_wall_s": [float(v) for v in stats[10:10 + world].tolist()]}
         workload += (f"; value = measured fit_video fit of one {args.clip_frames}-frame rigid synthetic clip per GPU "
                      f"(configs[2]: iterations 500 first / 150 camera-only + 300 joint per later frame, densification "
                      f"on, snapshots every {args.snapshot_interval} iterations); ms_per_step = iterations "
@@ -317,8 +321,7 @@ def main():
     # -------------------------------------------------------------- the metric
     # (first: its seconds of GPU work also bring the device to its working clocks before the short step timing below)
     clip = None
-    clip_wall = 0.0
-    rank_walls = None
+    clip_wall = own_wall = 0.0
     if not args.no_clip:
         c = max(1, args.clips_per_gpu)
         clips = [FV.upload_clip(S.make_clip(args.clip_frames, H, W, seed=rank * c + j, device=dev), dev) for j in range(c)]
@@ -337,12 +340,6 @@ def main():
         barrier()
         clip_wall = time.perf_counter() - t0
         del clips
-        if dist is not None:
-            walls = [None] * world
-            dist.all_gather_object(walls, own_wall)
-            rank_walls = [float(w) for w in walls]
-        else:
-            rank_walls = [own_wall]
 
     # ---------------------------------------------------------------- the step
     # (on a stream of its own, like the clip fit: the default stream is HIP's legacy NULL stream, which synchronises with
@@ -416,7 +413,7 @@ def main():
     del stepper, tr, eng, saved
 
     local = {"elapsed": elapsed, "steps": args.steps, "psnr_step": psnr_step, "K": K, "K_first": ks[0], "K_last": ks[-1],
-             "clip": clip, "clip_wall": clip_wall, "rank_walls": rank_walls, "kernels_ms": kern, "stage_ms": kern_all}
+             "clip": clip, "clip_wall": clip_wall, "clip_wall_own": own_wall, "kernels_ms": kern, "stage_ms": kern_all}
     out = reduce_and_report(local, dist, red_dev, rank, world, args, backend)
     if out is not None:
         if world == 1 and not args.no_clip and not args.no_coresident:

@@ -235,6 +235,7 @@ def test_bench_reduction_under_two_rank_gloo():
     assert abs(o["end_to_end_algorithmic_GBps"] - bytes_it * 8000.0 / 1e9) < 1e-6
     assert abs(o["end_to_end_algorithmic_GBps_per_gpu"] - bytes_it * 4000.0 / 1e9) < 1e-6
     assert abs(o["clip_fit"]["psnr_mean_db"] - 33.5) < 1e-9 and o["clip_fit"]["splats_final_mean"] == 68000.0
+    assert o["clip_fit"]["rank_wall_s"] == [1.0, 1.25] and o["clip_fit"]["clips_per_rank"] == 1
     # the roofline block describes rank 0's kernels on rank 0's scene
     assert o["roofline"]["kernel"] == "blend_bwd"
     want = (44 * 240000 + 24 * 480 * 854 + 40 * 60000) / 0.070e-3 / 1e9
