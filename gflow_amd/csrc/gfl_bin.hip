@@ -164,6 +164,8 @@ __device__ __forceinline__ void write_slot(float u, float v, int radius, int32_t
 
 #include "gfl_tile_sort.hpp"
 
+#include <stdlib.h>
+
 namespace gfl {
 }  // namespace gfl
 
@@ -252,9 +254,9 @@ int gfl_tile_sort_ordered(const int32_t* order, int W, int H, int K_cap, void* k
     if (W <= 0 || H <= 0 || K_cap < 0 || !order || !keys || !tile_range || (K_cap > 0 && !ids) || !rec || !slot_inv)
         return GFL_ERR_INVALID;
     const int gx = (W + GFL_TILE - 1) / GFL_TILE, gy = (H + GFL_TILE - 1) / GFL_TILE;
-    bin_tile_sort_kernel<<<gx * gy, SORT_THREADS, 0, (hipStream_t)stream>>>(nullptr, K_cap, (unsigned long long*)keys, ids,
-                                                                          tile_range, rec, slot_inv, slot_pool, gx, gy,
-                                                                          reinterpret_cast<const int4*>(order));
+    bin_tile_sort_kernel<<<SORT_MAX_SPLIT + gx * gy, SORT_THREADS, 0, (hipStream_t)stream>>>(
+        nullptr, K_cap, (unsigned long long*)keys, ids, tile_range, rec, slot_inv, slot_pool, gx, gy,
+        reinterpret_cast<const int4*>(order));
     return check_launch();
 }
 

@@ -26,6 +26,14 @@ inline int check(hipError_t e) {
 }
 
 constexpr int WAVE = 64;
+// tile sort: lists longer than SORT_SPLIT_MIN keys are cut at a pivot and sorted by two workgroups; at most SORT_MAX_SPLIT
+// tiles per launch (gfl_tile_sort.hpp; the list of such tiles is the trailer of the sort's order: gfl_fused.hip build_sort_order)
+#ifndef GFL_SORT_SPLIT_MIN
+#define GFL_SORT_SPLIT_MIN 768
+#endif
+constexpr int SORT_SPLIT_MIN = GFL_SORT_SPLIT_MIN;
+constexpr int SORT_MAX_SPLIT = 64;
+constexpr int SORT_ORDER_TRAILER = SORT_MAX_SPLIT + 4;      // ints behind order[T][4]: count, positions
 constexpr int SLOT_MAX = 32;   // fused backward: list positions kept per splat (tile rect <= 32 tiles)
 
 // Camera in wave-uniform registers: the 16 floats are read with scalar loads.

@@ -379,11 +379,14 @@ __device__ __forceinline__ bool sched_xcd_usable(const Sched& sc, int T, int blo
 // (list lengths -> offsets, heavy flags -> ranks).  {tile, start, end} per position: the sort reads ONE 16-byte item.
 __device__ void build_sort_order(const int32_t* __restrict__ tile_counts, int T, int4* __restrict__ sort_order,
                                  int32_t* __restrict__ wsum /* [BIN_BLOCK / 64] */) {
-    __shared__ int32_t hsum[BIN_BLOCK / 64], hstart[9];
+    __shared__ int32_t hsum[BIN_BLOCK / 64], hstart[9], s_nsplit;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int per = (T + BIN_BLOCK - 1) / BIN_BLOCK;
     const int t0 = tid * per;
     constexpr int PER_MAX = 8;
+    // the trailer behind order[T]: the positions of the lists the sort cuts in two (gfl_tile_sort.hpp), their number first
+    int32_t* trailer = reinterpret_cast<int32_t*>(sort_order + T);
+    if (tid == 0) s_nsplit = 0;
     if (per > PER_MAX) {                                 // more than 4096 tiles: the plain order (one lane; never hot)
         if (tid == 0) {
             int run = 0;
@@ -392,6 +395,7 @@ __device__ void build_sort_order(const int32_t* __restrict__ tile_counts, int T,
                 sort_order[t] = make_int4(t, run, run + c, 0);
                 run += c;
             }
+            trailer[0] = 0;
         }
         return;
     }
@@ -464,11 +468,19 @@ __device__ void build_sort_order(const int32_t* __restrict__ tile_counts, int T,
             const int hx = hstart[x], nh = (x < 7 ? hstart[x + 1] : hstart[8]) - hx;      // heavy tiles of this run
             const bool heavy = cnt[k] > thr;
             const int hr = H - hx;
-            sort_order[sx + (heavy ? hr : nh + (t - sx) - hr)] = make_int4(t, run, run + cnt[k], 0);
+            const int pos = sx + (heavy ? hr : nh + (t - sx) - hr);
+            int w = 0;
+            if (cnt[k] > SORT_SPLIT_MIN && cnt[k] <= 4 * BIN_BLOCK) {
+                const int j = atomicAdd(&s_nsplit, 1);       // (which extra workgroup takes which tile does not matter)
+                if (j < SORT_MAX_SPLIT) { w = 1 + j; trailer[1 + j] = pos; }
+            }
+            sort_order[pos] = make_int4(t, run, run + cnt[k], w);
             H += heavy ? 1 : 0;
             run += cnt[k];
         }
     }
+    __syncthreads();
+    if (tid == 0) trailer[0] = min((int)s_nsplit, SORT_MAX_SPLIT);
 }
 
 __global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* __restrict__ rec, int N, int gx, int gy,
@@ -2596,7 +2608,7 @@ size_t gfl_fit_workspace_bytes(int cap, int K_cap, int W, int H) {
            + up256(gfl_loss_workspace_bytes(W, H)) + 256
            + up256((size_t)6 * W * H * sizeof(float))                                  // SSIM statistics of the target
            + up256((size_t)fit_nblk(cap > 0 ? cap : 1) * sizeof(int32_t))              // rows of the scale term per block
-           + up256(T * 4 * sizeof(int32_t))                                            // the tile sort's order
+           + up256((T * 4 + SORT_ORDER_TRAILER) * sizeof(int32_t))                     // the tile sort's order (+ its split list)
            + up256((size_t)K_cap * sizeof(int32_t))                                    // second slot pool   } iterations take
            + up256((size_t)fit_nblk(cap > 0 ? cap : 1) * sizeof(int32_t));             // second scale rows  } turns ("next preprocess")
 }
@@ -2680,7 +2692,7 @@ static FitWs carve(const gfl_fit_state* st) {
     w.gt_stats = (float*)((char*)p + w.loss_ws_bytes + 256);
     w.scale_cnt = (int32_t*)((char*)w.gt_stats + up256((size_t)6 * st->W * st->H * sizeof(float)));
     w.sort_order = (int4*)((char*)w.scale_cnt + up256((size_t)fit_nblk(st->cap > 0 ? st->cap : 1) * sizeof(int32_t)));
-    w.slot_pool2 = (int32_t*)((char*)w.sort_order + up256(T * 4 * sizeof(int32_t)));
+    w.slot_pool2 = (int32_t*)((char*)w.sort_order + up256((T * 4 + SORT_ORDER_TRAILER) * sizeof(int32_t)));
     w.scale_cnt2 = (int32_t*)((char*)w.slot_pool2 + up256((size_t)st->K_cap * sizeof(int32_t)));
     return w;
 }

@@ -66,16 +66,18 @@ __device__ __forceinline__ void exchange_in_wave(unsigned long long (&key)[E], i
 constexpr int SORT_THREADS = 512;
 constexpr int SORT_XB = 4;         // keys of a lane exchanged through LDS per pair of barriers (16 KB of LDS)
 
+
 template <int E>
-__device__ __forceinline__ void sort_tile_regs(unsigned long long* __restrict__ seg, int n, int npow,
+__device__ __forceinline__ void sort_tile_regs(const unsigned long long* seg, int n, int npow,
                                                unsigned long long* __restrict__ sk, unsigned long long (&key)[E],
-                                               int sort_trace_row) {
+                                               int sort_trace_row, bool seg_in_sk = false) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int idx = tid * E + e;
         key[e] = idx < n ? seg[idx] : ~0ull;
     }
+    if (seg_in_sk) __syncthreads();      // (the keys were compacted into the exchange buffer: every lane has its own before it is re-used)
 #ifdef GFL_TRACE
     if (key[0] == 1ull) return;      // (forces the loads to complete before the time stamp)
     SORT_TRACE(1);
@@ -132,15 +134,15 @@ __device__ __forceinline__ void sort_tile_regs(unsigned long long* __restrict__ 
 }
 
 template <int E>
-__device__ __forceinline__ void sort_tile_and_emit(unsigned long long* __restrict__ seg, int n, int npow,
+__device__ __forceinline__ void sort_tile_and_emit(const unsigned long long* seg, int n, int npow,
                                                    unsigned long long* __restrict__ sk, int start, int tile,
                                                    int32_t* __restrict__ ids, const float* __restrict__ slot_rec,
                                                    int32_t* __restrict__ slot_inv, int32_t* __restrict__ slot_pool,
-                                                   int gx, int gy) {
+                                                   int gx, int gy, bool seg_in_sk = false) {
     unsigned long long key[E];
     const int sort_trace_row = tile;
     (void)sort_trace_row;
-    sort_tile_regs<E>(seg, n, npow, sk, key, tile);
+    sort_tile_regs<E>(seg, n, npow, sk, key, tile, seg_in_sk);
     SORT_TRACE(2);
     const int tid = threadIdx.x;
     // from here on only the splat ids are live (the depth halves of the keys would keep E more registers busy: at the
@@ -194,13 +196,38 @@ __global__ void __launch_bounds__(SORT_THREADS, 8) bin_tile_sort_kernel(const in
     // `order` (fused iteration): the XCD's tiles with the longest lists first -- {tile, start, end} per position, written
     // by the scatter launch.  Four 512-lane workgroups fit a CU at a time and a launch has six per CU: a 600-key tile
     // that started in the second round (4-6 us in) was the end of the launch (tools/sort_trace.py).
-    const int lb = xcd_logical_block((int)blockIdx.x, (int)gridDim.x);
+    // Round 4: a list of more than SORT_SPLIT_MIN keys -- the piles densification leaves in single tiles: 1 000-1 700 keys, a
+    // 2 048-key network of 16 us on eight waves while every other tile is done after 7-10 us (tools/sort_trace.py --fit) --
+    // is cut at a pivot key and sorted by TWO workgroups: this tile's own sorts the keys below the pivot, one of the
+    // SORT_MAX_SPLIT extra workgroups at the FRONT of the grid the others, each a list of half the length (fewer network
+    // steps, half the keys per lane), straight into its part of the tile's range.  No exchange between the two: both read
+    // all keys, both find the same pivot (the median of 32 keys at fixed positions of the unsorted list) and count the same
+    // lower half.  Which tiles: order[pos].w = 1 + j and trailer[1 + j] = pos for the j-th of them, trailer[0] = their number
+    // (the trailer follows order[T]; written with the order by the scatter launch).  (Two workgroups for EVERY position,
+    // the second leaving at once where there is nothing to split, cost the bench scene 6.7 us: 1 620 more 512-lane
+    // workgroups to dispatch.)
+    const int T_all = gx * gy;
+    int lb, half = 0;
+    bool flagged = false;
+    if (order) {
+        const int32_t* trailer = reinterpret_cast<const int32_t*>(order + T_all);
+        if ((int)blockIdx.x < SORT_MAX_SPLIT) {
+            if ((int)blockIdx.x >= min(trailer[0], SORT_MAX_SPLIT)) return;
+            lb = trailer[1 + blockIdx.x];
+            half = 1;
+        } else {
+            lb = xcd_logical_block((int)blockIdx.x - SORT_MAX_SPLIT, T_all);
+        }
+    } else {
+        lb = xcd_logical_block((int)blockIdx.x, (int)gridDim.x);
+    }
     int tile = lb, start, end;
     if (order) {
         const int4 it = order[lb];
         tile = it.x;
         start = min(it.y, K_cap);
         end = min(it.z, K_cap);
+        flagged = it.w != 0;
     } else {
         start = min(offsets[tile], K_cap);
         end = min(offsets[tile + 1], K_cap);
@@ -209,12 +236,79 @@ __global__ void __launch_bounds__(SORT_THREADS, 8) bin_tile_sort_kernel(const in
     (void)sort_trace_row;
     SORT_TRACE(0);
     const int n = end - start;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && half == 0) {
         tile_range[2 * tile] = n > 0 ? start : 0;
         tile_range[2 * tile + 1] = n > 0 ? end : 0;
     }
     if (n <= 0) return;
     unsigned long long* seg = keys + start;
+    const bool split = flagged && n >= 64 && n <= 4 * SORT_THREADS;       // (both workgroups of a tile decide alike)
+    if (half == 1 && !split) return;
+    if (split) {
+        // ---- pivot: the median of 32 keys at fixed positions (keys are unique: ranks are)
+        __shared__ unsigned long long s_pivot;
+        __shared__ int32_t s_cnt[SORT_THREADS / 64 + 1];
+        const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+        if (wid == 0) {
+            const unsigned long long mine = seg[(int)(((long long)n * (2 * (lane & 31) + 1)) >> 6)];
+            int rank = 0;
+            for (int j = 0; j < 32; ++j) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mine, j);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mine >> 32), j);
+                rank += ((((unsigned long long)hi << 32) | lo) < mine) ? 1 : 0;
+            }
+            if (lane < 32 && rank == 16) s_pivot = mine;
+        }
+        __syncthreads();
+        const unsigned long long pivot = s_pivot;
+        // ---- this half's keys, compacted into the exchange buffer (order does not matter: they are sorted next)
+        constexpr int EP = 4;                        // (n <= 4 x 512)
+        unsigned long long k4[EP];
+        bool keep[EP];
+        int mine_cnt = 0;
+#pragma unroll
+        for (int e = 0; e < EP; ++e) {
+            const int idx = tid + e * SORT_THREADS;              // (coalesced: the order inside the list is irrelevant here)
+            k4[e] = idx < n ? seg[idx] : ~0ull;
+            keep[e] = idx < n && ((k4[e] < pivot) == (half == 0));
+            mine_cnt += (int)__popcll(__ballot(keep[e]));
+        }
+        if (lane == 0) s_cnt[wid] = mine_cnt;
+        __syncthreads();
+        int base = 0, m = 0;
+#pragma unroll
+        for (int w = 0; w < SORT_THREADS / 64; ++w) {
+            const int c = s_cnt[w];
+            base += w < wid ? c : 0;
+            m += c;
+        }
+        const int n_lower = half == 0 ? m : n - m;
+        if (m <= SORT_XB * SORT_THREADS && n - m <= SORT_XB * SORT_THREADS) {
+#pragma unroll
+            for (int e = 0; e < EP; ++e) {
+                const unsigned long long bal = __ballot(keep[e]);
+                if (keep[e]) sk[base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0))] = k4[e];
+                base += (int)__popcll(bal);
+            }
+            __syncthreads();
+            if (m <= 0) return;
+            int np2 = 2;
+            while (np2 < m) np2 <<= 1;
+            const int E2 = np2 <= SORT_THREADS ? 1 : (np2 <= 2 * SORT_THREADS ? 2 : 4);
+            const int start2 = start + (half == 0 ? 0 : n_lower);
+            // (waves the shorter list does not need leave here; the barrier inside the key load counts only the others)
+            if ((int)threadIdx.x >= max(np2 / E2, 64)) return;
+            if (E2 == 1) sort_tile_and_emit<1>(sk, m, np2, sk, start2, tile, ids, slot_rec, slot_inv, slot_pool, gx, gy, true);
+            else if (E2 == 2) sort_tile_and_emit<2>(sk, m, np2, sk, start2, tile, ids, slot_rec, slot_inv, slot_pool, gx, gy, true);
+            else sort_tile_and_emit<4>(sk, m, np2, sk, start2, tile, ids, slot_rec, slot_inv, slot_pool, gx, gy, true);
+            SORT_TRACE(3);
+            return;
+        }
+        // (a pivot so lopsided that one half does not fit the buffer -- sampled medians do not do that, but it must be
+        //  right if they do --: the first workgroup sorts the whole list the ordinary way)
+        if (half == 1) return;
+        __syncthreads();
+    }
     int npow = 2;
     while (npow < n) npow <<= 1;
     // keys per lane: the smallest E with npow <= SORT_THREADS * E; the lanes beyond npow / E are not needed (whole

@@ -369,10 +369,16 @@ int gfl_tile_sort_only(const int32_t* tile_offsets, int T, int K_cap, void* keys
 int gfl_tile_sort_with_slots(const int32_t* tile_offsets, int W, int H, int K_cap, void* keys, int32_t* ids,
                              int32_t* tile_range, const float* rec, int32_t* slot_inv, int32_t* slot_pool,
                              gfl_stream_t stream);
-/* same, with the order the workgroups take the tiles in given by the caller: order[T][4] = {tile, start, end, 0} per
- * position (16-byte aligned; positions are assigned to the XCDs in contiguous runs, T / 8 each, like the tiles without it).
- * gfl_fit_iteration's scatter launch writes it with every XCD's longest lists first: their workgroups then start with the
- * launch instead of in its second round.  Any permutation that keeps a tile inside its XCD's run is as good for the result. */
+/* same, with the order the workgroups take the tiles in given by the caller: order[T][4] = {tile, start, end, split} per
+ * position (16-byte aligned; positions are assigned to the XCDs in contiguous runs, T / 8 each, like the tiles without it),
+ * followed by a trailer of GFL_SORT_ORDER_TRAILER ints: trailer[0] = n_split (0 .. GFL_SORT_MAX_SPLIT), trailer[1 + j] =
+ * the position of the j-th split list, whose order entry carries split = 1 + j (0 everywhere else).  A split list (64 ..
+ * 2048 keys) is cut at a pivot key and sorted by two workgroups, half each; the result is the same sorted list.
+ * gfl_fit_iteration's scatter launch writes all of it: every XCD's longest lists first (their workgroups then start with
+ * the launch instead of in its second round), the lists of more than 768 keys split.  Any permutation that keeps a tile
+ * inside its XCD's run, with or without split entries, is as good for the result. */
+#define GFL_SORT_MAX_SPLIT 64
+#define GFL_SORT_ORDER_TRAILER (GFL_SORT_MAX_SPLIT + 4)
 int gfl_tile_sort_ordered(const int32_t* order, int W, int H, int K_cap, void* keys, int32_t* ids, int32_t* tile_range,
                           const float* rec, int32_t* slot_inv, int32_t* slot_pool, gfl_stream_t stream);
 

@@ -195,14 +195,25 @@ def test_tile_sort_in_any_order_of_the_tiles():
         for j, t in enumerate(perm):
             order[s0 + j] = (t, offsets[t], offsets[t + 1], 0)
 
-    def run(ordered):
+    TRAILER = 68                                             # GFL_SORT_ORDER_TRAILER ints behind order[T][4]
+    heavy_pos = [p_ for p_ in range(T) if order[p_, 2] - order[p_, 1] > 200]
+    assert any(order[p_, 2] - order[p_, 1] > 1024 for p_ in heavy_pos) and len(heavy_pos) >= 3
+
+    def run(ordered, split=False):
         k = torch.from_numpy(keys.view(np.int64).copy()).to(dev)
         ids = torch.full((K,), -7, dtype=torch.int32, device=dev)
         tr = torch.full((T, 2), -7, dtype=torch.int32, device=dev)
         slot = torch.full((n, SLOT_MAX), -1, dtype=torch.int32, device=dev)
         rec_d = rec.to(dev)
         if ordered:
-            o = torch.from_numpy(order).to(dev)
+            o_np = np.concatenate([order.reshape(-1), np.zeros(TRAILER, dtype=np.int32)])
+            if split:
+                # the lists of more than 200 keys (up to > 1024: every register tier of the halves) cut in two
+                o_np[4 * T] = len(heavy_pos)
+                for j, p_ in enumerate(heavy_pos):
+                    o_np[4 * p_ + 3] = 1 + j
+                    o_np[4 * T + 1 + j] = p_
+            o = torch.from_numpy(o_np).to(dev)
             L.check(lib.gfl_tile_sort_ordered(L.ptr(o), W, H, K, L.ptr(k), L.ptr(ids), L.ptr(tr), L.ptr(rec_d), L.ptr(slot),
                                               None, L.stream()), "sort ordered")
         else:
@@ -215,6 +226,8 @@ def test_tile_sort_in_any_order_of_the_tiles():
     ids0, tr0, slot0 = run(False)
     ids1, tr1, slot1 = run(True)
     assert torch.equal(tr0, tr1) and torch.equal(ids0, ids1) and torch.equal(slot0, slot1)
+    ids2, tr2, slot2 = run(True, split=True)             # ... and with the long lists cut at a pivot, two workgroups each
+    assert torch.equal(tr0, tr2) and torch.equal(ids0, ids2) and torch.equal(slot0, slot2)
     # and the plain one is right: every list ascending in (depth, id), every pair's position in its splat's slot row
     for t in (0, 3 * gx + 4, T - 1):
         seg = ids0[offsets[t]:offsets[t + 1]].long()
