@@ -640,6 +640,10 @@ constexpr int FWD_SPLIT_MIN = 448;     // forward: a queue's first tile is walke
                                        // (round 4 sweep, sixteen-splat steps: bench-scene forward 47.0 / 40.8 / 39.7 / 39.7 us and 4-frame clip
                                        //  fit 0.483 / 0.485 / 0.490 / 0.523 s at 256 / 448 / 640 / never)
 constexpr int FB = 256;   // staged splats per batch (forward)
+#ifndef GFL_FWD_LONG_BATCH
+#define GFL_FWD_LONG_BATCH 256
+#endif
+constexpr int FBL = GFL_FWD_LONG_BATCH;   // ... of the long-tile walk (512: forward inside a clip fit 56.6 against 52.7 us, round 4)
 constexpr int FBB = 192;  // backward: 18.6 KB of LDS per workgroup -> 8 workgroups per CU (the tile queues of
                           // gfl_sched.hpp assume that all workgroups of a blend launch are resident)
 
@@ -748,15 +752,16 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     // lists with other per-splat values, made while a record is staged: mode 1 = colour := turbo map of the splat's
     // depth (apply_float_colormap(non_zero=True), range in cmap_mm), mode 2 = unit blob at the centre (conic 1 0 1,
     // opacity 1).
-    __shared__ RecLDS recs[FB + 1];          // recs[FB]: an all-zero record (opacity 0: never blends)
-    __shared__ unsigned char s_mask[FB];
-    __shared__ unsigned char s_hits[4][FB];  // long first tiles: a wave's (= a 4x4 quarter's) hit list of the staged batch
+    __shared__ RecLDS recs[FBL + 1];         // recs[FBL]: an all-zero record (opacity 0: never blends)
+    __shared__ unsigned char s_mask[FBL];
+    __shared__ unsigned short s_hits[4][FBL];        // long first tiles: a wave's (= a 4x4 quarter's) hit list of the staged batch
+    __shared__ int32_t s_gs[4][FBL / 64 + 1];        // ... and the number of hits in front of every 64-slot group
     __shared__ int32_t s_ticket;
     __shared__ int32_t s_simd[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid == 0) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        recs[FB].p0 = z; recs[FB].p1 = z; recs[FB].p2 = z;
+        recs[FBL].p0 = z; recs[FBL].p1 = z; recs[FBL].p2 = z;
     }
     // block plan (gfl_sched.hpp): which 8x8 block of a whole tile this wave walks follows from the SIMD it sits on
     unsigned hw_id;
@@ -839,31 +844,39 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
         long long tq_stage = 0, tq_walk = 0, tq_mark = wall_clock64();
         int tq_steps = 0;
 #endif
-        for (int base = start; base < end; base += FB) {
+        for (int base = start; base < end; base += FBL) {
 #ifdef GFL_TRACE
             { const long long now = wall_clock64(); tq_walk += now - tq_mark; tq_mark = now; }
 #endif
             if (__syncthreads_and(alive == 0)) break;
-            const int idx = base + tid;
-            if (idx < end) {
-                const int gidx = ids[idx];
-                const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)gidx * REC);
-                float4 p0 = r4[0], p1 = r4[1], p2 = r4[2];
-                if (mode == 1) {
-                    const float3 col = cmap_nonzero_lookup(p2.y, cmap_mm, cmap_lut);
-                    p1.z = col.x; p1.w = col.y; p2.x = col.z;
-                } else if (mode == 2) {
-                    p0.z = 1.f; p0.w = 0.f; p1.x = 1.f; p1.y = 1.f;
-                    p2.z = p2.z < 0.f ? p2.z : alpha_cutoff(1.f, 1.f);
+            {
+                // FBL / 256 entries per lane, their ids and then their records requested together
+                constexpr int PER = FBL / 256;
+                int gidx[PER];
+#pragma unroll
+                for (int e = 0; e < PER; ++e) gidx[e] = base + tid + 256 * e < end ? ids[base + tid + 256 * e] : -1;
+#pragma unroll 1
+                for (int e = 0; e < PER; ++e) {          // (one record at a time: two in flight spilled the walk's registers)
+                    if (gidx[e] < 0) continue;
+                    const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)gidx[e] * REC);
+                    float4 p0 = r4[0], p1 = r4[1], p2 = r4[2];
+                    if (mode == 1) {
+                        const float3 col = cmap_nonzero_lookup(p2.y, cmap_mm, cmap_lut);
+                        p1.z = col.x; p1.w = col.y; p2.x = col.z;
+                    } else if (mode == 2) {
+                        p0.z = 1.f; p0.w = 0.f; p1.x = 1.f; p1.y = 1.f;
+                        p2.z = p2.z < 0.f ? p2.z : alpha_cutoff(1.f, 1.f);
+                    }
+                    const int sl = tid + 256 * e;
+                    recs[sl].p0 = p0; recs[sl].p1 = p1; recs[sl].p2 = p2;
+                    s_mask[sl] = (unsigned char)block_mask(p0, p1, p2.z, tx * GFL_TILE + (blk & 1) * 8, ty * GFL_TILE + (blk >> 1) * 8, 4);
                 }
-                recs[tid].p0 = p0; recs[tid].p1 = p1; recs[tid].p2 = p2;
-                s_mask[tid] = (unsigned char)block_mask(p0, p1, p2.z, tx * GFL_TILE + (blk & 1) * 8, ty * GFL_TILE + (blk >> 1) * 8, 4);
             }
             __syncthreads();
 #ifdef GFL_TRACE
             { const long long now = wall_clock64(); tq_stage += now - tq_mark; tq_mark = now; }
 #endif
-            const int cnt = min(FB, end - base);
+            const int cnt = min(FBL, end - base);
             if (__all(alive == 0)) continue;         // this wave is finished; keep meeting the barriers
             // ---- the quarter's hit list of the batch (slot order = list order); gs[k]: hits in front of 64-slot group k.
             // Once pixels have stopped, only splats that reach the box of the pixels still ALIVE matter (in a tile where
@@ -882,14 +895,10 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                 bx_lo = (float)(qx0 + __builtin_ctz(cols | 16u)); bx_hi = (float)(qx0 + 31 - __builtin_clz(cols | 1u));
                 by_lo = (float)(qy0 + __builtin_ctz(arows | 16u)); by_hi = (float)(qy0 + 31 - __builtin_clz(arows | 1u));
             }
-            static_assert(FB == 256, "four 64-slot groups per staged batch");
-            int g1 = 0, g2 = 0, g3 = 0;                  // hits in front of the 64-slot groups 1, 2, 3 (group 0: none)
             int n_hit = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (k == 1) g1 = n_hit;
-                if (k == 2) g2 = n_hit;
-                if (k == 3) g3 = n_hit;
+            for (int k = 0; k < FBL / 64; ++k) {
+                if (lane == 0) s_gs[wave][k] = n_hit;
                 const int sl = 64 * k + lane;
                 bool hit = sl < cnt && ((s_mask[sl] >> wave) & 1);
                 if (!all_alive && hit) {
@@ -897,7 +906,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                     hit = box_hit(t, bx_lo, bx_hi, by_lo, by_hi);
                 }
                 const unsigned long long bal = __ballot(hit);
-                if (hit) s_hits[wave][n_hit + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0))] = (unsigned char)sl;
+                if (hit) s_hits[wave][n_hit + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0))] = (unsigned short)sl;
                 n_hit += (int)__popcll(bal);
             }
             units += n_hit;
@@ -907,9 +916,9 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
             for (;;) {
                 int h_hi = n_hit;
                 bool due = false;
-                for (; k < 4; ++k)
+                for (; k < FBL / 64; ++k)
                     if (64 * k < cnt && ck_nextq < parts && base - start + 64 * k == ck_nextq * seg) {
-                        h_hi = k == 0 ? 0 : (k == 1 ? g1 : (k == 2 ? g2 : g3));
+                        h_hi = s_gs[wave][k];
                         due = true;
                         break;
                     }
@@ -918,7 +927,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                     ++tq_steps;
 #endif
                     const bool have = h + ls < h_hi;
-                    const int j = have ? (int)s_hits[wave][h + ls] : FB;
+                    const int j = have ? (int)s_hits[wave][h + ls] : FBL;
                     const int pos1 = base - start + j + 1;
                     const float4 q0 = recs[j].p0, q1 = recs[j].p1, q2 = recs[j].p2;
 #pragma unroll
@@ -1084,12 +1093,12 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                 int j[FWD_UNITS];            // missing splats of the last trip: the null record
 #pragma unroll
                 for (int u = 0; u < FWD_UNITS; ++u) {
-                    j[u] = bits ? c0 + (int)__builtin_ctzll(bits) : FB;
+                    j[u] = bits ? c0 + (int)__builtin_ctzll(bits) : FBL;
                     bits &= bits - 1;        // no-op when bits is already 0
                 }
 #ifdef GFL_TRACE
 #pragma unroll
-                for (int u = 0; u < FWD_UNITS; ++u) trace_units += j[u] != FB ? 1 : 0;
+                for (int u = 0; u < FWD_UNITS; ++u) trace_units += j[u] != FBL ? 1 : 0;
 #endif
                 float4 q0[FWD_UNITS], q1[FWD_UNITS], q2[FWD_UNITS];
 #pragma unroll
