@@ -1,5 +1,6 @@
 """Per-frame PSNR / splat count / estimated camera of a fit of the rigid synthetic clip (analysis tool).
-    gpurun -- python tools/rigid_clip_probe.py [frames] [--gt-extr] [--h H --w W --n N]"""
+    gpurun -- python tools/rigid_clip_probe.py [frames] [--gt-extr] [--operator] [--h H --w W --n N]
+--operator: the reference's loop over the five msplat operators (fused=False) instead of the fused iteration."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,7 +26,7 @@ def spy(self, *a, **k):
     poses.append((k.get("camera_only", False), self.pose.detach().cpu().tolist()))
     return r
 TR.SimpleGaussian.train_steps = spy
-m = FV.fit_clip(frames, dev, dict(num_points=N), seed=0, log=logs.append)
+m = FV.fit_clip(frames, dev, dict(num_points=N), seed=0, log=logs.append, fused="--operator" not in sys.argv)
 for l in logs:
     print(l)
 for i, (cam, p) in enumerate(poses):
