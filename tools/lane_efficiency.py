@@ -55,6 +55,8 @@ def box_hit(u, v, cutoff, x_lo, x_hi, y_lo, y_hi):
     ddy = torch.clamp(torch.maximum(y_lo - v[:, None], v[:, None] - y_hi), min=0)
     return ddx * ddx + ddy * ddy <= cutoff[:, None]
 
+q_hits = torch.zeros(eng.T, 16, dtype=torch.long, device=dev)      # live (splat, 4x4 quarter) units per tile and quarter
+b_hits = torch.zeros(eng.T, 4, dtype=torch.long, device=dev)       # live (splat, 8x8 block) units per tile and block
 tot = dict(valid=0, valid_live=0, u8=0, u8_any=0, u8_any_live=0, u4=0, u4_any=0, u4_any_live=0, rows8=0, rows8_live=0,
            u8x4=0, u8x4_any=0)
 CH = 16384
@@ -90,6 +92,8 @@ for s in range(0, K, CH):
     v4 = valid.view(-1, 4, 4, 4, 4).permute(0, 1, 3, 2, 4).reshape(-1, 16, 16)
     l4 = live.view(-1, 4, 4, 4, 4).permute(0, 1, 3, 2, 4).reshape(-1, 16, 16)
     tot["u4"] += int(hit4.sum()); tot["u4_any"] += int(v4.any(-1).sum()); tot["u4_any_live"] += int(l4.any(-1).sum())
+    q_hits.index_add_(0, tile_of[sl], l4.any(-1).long())
+    b_hits.index_add_(0, tile_of[sl], l8.any(-1).long())
 
 print("scene:", "real first-frame fit" if REAL else "bench scene", " N", eng.N, " K", K)
 print("pixel-splat pairs with alpha >= 1/255: %d  (still needed by the backward pass: %d)" % (tot["valid"], tot["valid_live"]))
@@ -104,6 +108,14 @@ line("4x4 units with any visible pixel", tot["u4_any"] * 16)
 line("4x4 units with any LIVE pixel", tot["u4_any_live"] * 16)
 line("8x1 rows with any visible pixel", tot["rows8"] * 8)
 line("8x1 rows with any LIVE pixel", tot["rows8_live"] * 8)
+# a wave = an 8x8 block whose four 16-lane rows walk the block's four 4x4 quarters, each its own hit list, in lockstep:
+# steps = the longest of the four lists (quarter q of block b: (qy, qx) = (2 (b >> 1) + (q >> 1), 2 (b & 1) + (q & 1)))
+qh = q_hits.view(-1, 4, 4)                       # [tile][qy][qx]
+per_block = torch.stack([qh[:, 2 * (b >> 1):2 * (b >> 1) + 2, 2 * (b & 1):2 * (b & 1) + 2].reshape(-1, 4) for b in range(4)], dim=1)   # [tile][block][4 quarters]
+steps_q = int(per_block.max(-1).values.sum())
+print("backward, one splat per step and 8x8 block (shipped): %d steps;  four quarter rows in lockstep: %d steps (%.2fx), "
+      "their lists hold %d units (%.2f of a step's four slots used)" % (int(b_hits.sum()), steps_q, steps_q / max(int(b_hits.sum()), 1),
+                                                                         int(per_block.sum()), int(per_block.sum()) / max(4 * steps_q, 1)))
 
 if "--json" in sys.argv:
     import json
