@@ -55,12 +55,14 @@ SIGNATURES = {
     "gfl_tile_sort_only": (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),
     "gfl_tile_sort_with_slots": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "gfl_tile_sort_ordered": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "gfl_tile_sort_reserved": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "gfl_fit_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "gfl_fit_forward": (c_int, [_P, _P, _P]),          # struct pointers; typed in gflow_amd/fused.py
     "gfl_fit_backward_step": (c_int, [_P, _P, _P]),
     "gfl_fit_iteration": (c_int, [_P, _P, _P]),
     "gfl_fit_iterations": (c_int, [_P, _P, c_int, c_int, _P]),
     "gfl_fit_next_preprocess_supported": (c_int, [_P, _P]),
+    "gfl_fit_reserved_supported": (c_int, [_P, _P]),
     "gfl_fit_snapshot_stage": (c_int, [_P, _P, _P]),
     "gfl_fit_snapshot_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gfl_fit_snapshot": (c_int, [_P, _P, _P, _P, _P, c_size_t, _P]),

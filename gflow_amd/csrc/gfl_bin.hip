@@ -222,7 +222,7 @@ int gfl_bin_sort(const float* uv, const float* depth, const int32_t* radius, con
             bin_scatter_kernel<false><<<(N + 255) / 256, 256, 0, s>>>(uv, depth, radius, cutoff, N, gx, gy, tile_offsets,
                                                                       cursor, K_cap, keys, overflow);
     }
-    bin_tile_sort_kernel<<<T, SORT_THREADS, 0, s>>>(tile_offsets, K_cap, keys, ids, tile_range, nullptr, nullptr, nullptr, gx, gy, nullptr);
+    bin_tile_sort_kernel<<<T, SORT_THREADS, 0, s>>>(tile_offsets, K_cap, keys, ids, tile_range, nullptr, nullptr, nullptr, gx, gy, nullptr, nullptr, nullptr, nullptr);
     return check_launch();
 }
 
@@ -231,7 +231,7 @@ int gfl_tile_sort_only(const int32_t* tile_offsets, int T, int K_cap, void* keys
     if (T <= 0 || K_cap < 0 || !tile_offsets || !keys || !tile_range || (K_cap > 0 && !ids)) return GFL_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* k64 = (unsigned long long*)keys;
-    bin_tile_sort_kernel<<<T, SORT_THREADS, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, nullptr, nullptr, nullptr, 1, T, nullptr);
+    bin_tile_sort_kernel<<<T, SORT_THREADS, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, nullptr, nullptr, nullptr, 1, T, nullptr, nullptr, nullptr, nullptr);
     return check_launch();
 }
 
@@ -245,7 +245,7 @@ int gfl_tile_sort_with_slots(const int32_t* tile_offsets, int W, int H, int K_ca
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* k64 = (unsigned long long*)keys;
     bin_tile_sort_kernel<<<gx * gy, SORT_THREADS, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, rec, slot_inv, slot_pool, gx, gy,
-                                                        nullptr);
+                                                        nullptr, nullptr, nullptr, nullptr);
     return check_launch();
 }
 
@@ -256,7 +256,20 @@ int gfl_tile_sort_ordered(const int32_t* order, int W, int H, int K_cap, void* k
     const int gx = (W + GFL_TILE - 1) / GFL_TILE, gy = (H + GFL_TILE - 1) / GFL_TILE;
     bin_tile_sort_kernel<<<SORT_MAX_SPLIT + gx * gy, SORT_THREADS, 0, (hipStream_t)stream>>>(
         nullptr, K_cap, (unsigned long long*)keys, ids, tile_range, rec, slot_inv, slot_pool, gx, gy,
-        reinterpret_cast<const int4*>(order));
+        reinterpret_cast<const int4*>(order), nullptr, nullptr, nullptr);
+    return check_launch();
+}
+
+int gfl_tile_sort_reserved(const int32_t* order, const int32_t* fill, int32_t* tile_counts, int32_t* void_words, int W, int H,
+                           int K_cap, void* keys, int32_t* ids, int32_t* tile_range, const float* rec, int32_t* slot_inv,
+                           int32_t* slot_pool, gfl_stream_t stream) {
+    if (W <= 0 || H <= 0 || K_cap < 0 || !order || !fill || !tile_counts || !keys || !tile_range || (K_cap > 0 && !ids) ||
+        !rec || !slot_inv)
+        return GFL_ERR_INVALID;
+    const int gx = (W + GFL_TILE - 1) / GFL_TILE, gy = (H + GFL_TILE - 1) / GFL_TILE;
+    bin_tile_sort_kernel<<<SORT_MAX_SPLIT + gx * gy, SORT_THREADS, 0, (hipStream_t)stream>>>(
+        nullptr, K_cap, (unsigned long long*)keys, ids, tile_range, rec, slot_inv, slot_pool, gx, gy,
+        reinterpret_cast<const int4*>(order), fill, tile_counts, void_words);
     return check_launch();
 }
 

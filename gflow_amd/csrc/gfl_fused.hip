@@ -59,6 +59,7 @@ __device__ long long g_phase_trace[4 * PHASE_WAVES * 8];
 
 // pose [qx,qy,qz,qw,tx,ty,tz] -> camera (trainer.py:115-121)
 __device__ __forceinline__ Cam cam_from_pose(const float* __restrict__ intr, const float* __restrict__ pose) {
+#pragma clang fp contract(off)     // (no fused multiply-adds: the same bits in every kernel this is inlined into, and the oracle's arithmetic)
     Cam c;
     c.fx = intr[0]; c.fy = intr[1]; c.cx = intr[2]; c.cy = intr[3];
     float x = pose[0], y = pose[1], z = pose[2], w = pose[3];
@@ -82,6 +83,7 @@ struct Splat {           // activated parameters of one splat
 // the differentiable operator gfl_render_*, whose caller applies GFlow's activations in PyTorch (render.py:6-20)
 __device__ __forceinline__ Splat splat_from_row(const float4& a, const float4& b, const float4& c, const float4& d,
                                                 bool activated = false) {
+#pragma clang fp contract(off)     // (no fused multiply-adds: the same bits in every kernel this is inlined into, and the oracle's arithmetic)
     Splat s;
     s.x = a.x; s.y = a.y; s.z = a.z;
     s.raw_s[0] = a.w; s.raw_s[1] = b.x; s.raw_s[2] = b.y;
@@ -110,6 +112,7 @@ __device__ __forceinline__ Splat splat_from_row(const float4& a, const float4& b
 // squared radius of the disc outside which alpha < 1/255 for every pixel, with a
 // safety margin so that a culled (splat, tile) pair is skipped by the blend as well
 __device__ __forceinline__ float alpha_cutoff(float o, float lam) {
+#pragma clang fp contract(off)     // (no fused multiply-adds: the same bits in every kernel this is inlined into, and the oracle's arithmetic)
     if (o < GFL_ALPHA_MIN) return -1.0f;                 // never visible
     const float r = 255.0f * o;
     if (r < 1.05f) return 3.0e38f;                       // too close to the threshold: no culling
@@ -117,6 +120,7 @@ __device__ __forceinline__ float alpha_cutoff(float o, float lam) {
 }
 
 __device__ __forceinline__ bool tile_hit2(float u, float v, float cutoff, int tx, int ty) {
+#pragma clang fp contract(off)     // (no fused multiply-adds: the same bits in every kernel this is inlined into, and the oracle's arithmetic)
     const float x_lo = (float)(tx * GFL_TILE), x_hi = x_lo + (float)(GFL_TILE - 1);
     const float y_lo = (float)(ty * GFL_TILE), y_hi = y_lo + (float)(GFL_TILE - 1);
     const float ddx = fmaxf(fmaxf(x_lo - u, u - x_hi), 0.f);
@@ -154,9 +158,14 @@ struct PreArgs {
     int32_t* pre_valid;              // set by a tail that ran the preprocess, checked and cleared by the column scan
 };
 
-template <bool EWA_MFMA, bool PHASES>
+// BINNED (reserved tile regions, fused_preprocess_bin_kernel): the block's histogram stays in LDS -- the caller reserves the
+// block's part of every tile's region with it and scatters the keys itself -- and what the scatter needs of the splat comes
+// back in `po`.
+struct PreOut { float u, v, cutoff, depth; int rad; };
+
+template <bool EWA_MFMA, bool PHASES, bool BINNED = false>
 __device__ __forceinline__ void preprocess_block(const PreArgs& a, const float4 (&row_v)[4], unsigned own_flags, int i,
-                                                 int32_t* __restrict__ hist) {
+                                                 int32_t* __restrict__ hist, PreOut* po = nullptr) {
     // op_mode (gfl_render_fwd): activated attributes in the rows, camera = the extrinsic in extr_out
     // scale_rows_mode != 0 (lambda_scale): count the rows the scale term averages over, per block
     const int N = a.N, W = a.W, H = a.H, gx = a.gx, gy = a.gy;
@@ -219,6 +228,7 @@ __device__ __forceinline__ void preprocess_block(const PreArgs& a, const float4 
         r4[0] = make_float4(u, v, A, B);
         r4[1] = make_float4(C, s.o, s.c[0], s.c[1]);
         r4[2] = make_float4(s.c[2], depth, cutoff, __int_as_float(rad));
+        if (BINNED) { po->u = u; po->v = v; po->cutoff = cutoff; po->depth = depth; po->rad = rad; }
         in_scale_rows = a.scale_rows_mode && scale_row(u, v, W, H, own_flags, a.scale_rows_mode);
         int4* iv = reinterpret_cast<int4*>(a.slot_inv + (size_t)i * SLOT_MAX);
         const int4 none = make_int4(-1, -1, -1, -1);
@@ -271,6 +281,7 @@ __device__ __forceinline__ void preprocess_block(const PreArgs& a, const float4 
     if (PHASES) GFL_PHASE(0, 5);
     __syncthreads();
     if (PHASES) GFL_PHASE(0, 6);
+    if (BINNED) return;
     int32_t* row = a.hist_g + (size_t)blockIdx.x * T;
     for (int t = threadIdx.x; t < T; t += BIN_BLOCK) row[t] = hist[t];
     if (PHASES) GFL_PHASE(0, 7);
@@ -299,6 +310,125 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(const f
     preprocess_block<EWA_MFMA, true>(a, row_v, own_flags, i, hist);
 }
 
+// ------------------------------------------------------------------ reserved tile regions (round 4)
+// Preprocess + binning in ONE launch, for an iteration that follows another full iteration: the histogram rows, the column
+// scan and the scatter launch exist because a key's position in its tile's list needs every block's count of every tile --
+// a dependency across the whole launch.  But the lists of iteration i + 1 are the lists of iteration i but for one Adam step:
+// at the END of iteration i one workgroup of the per-splat launch (build_sort_order<.., true>) gives every tile a REGION of
+// the key array sized by what the tile holds now plus a margin (region_cap), and the next iteration's blocks reserve their
+// part of it with one returning atomicAdd per (block, tile with keys): fill[t] += the block's count (dense 4-byte counters:
+// 118 blocks x 1 620 tiles cost 2.1 us on top of the launch, tools/atomic_probe.hip; counters a cache line apart cost 7).
+// The order inside a region is whatever order the blocks arrived in -- the tile sort, which follows anyway, makes the lists
+// what the exact path's are (keys are unique: depth bits | splat id), so ids / tile ranges / everything downstream is
+// bit-identical but for the gaps between the lists.  A tile that outgrows its region voids the iteration: its surplus keys are
+// not written, nothing is stepped and the iteration is counted in overflow[1] (like K_cap overflow, but not sticky: the
+// regions reserved at the end of the void iteration are sized by what the tiles WANTED, so the next iteration fits), and the
+// host runs one more iteration for each (FitEngine.settle_overflow).  Launches per iteration: 8 -> 6.
+struct BinArgs {
+    const int2* region;              // [T] {start, capacity}, written at the end of the iteration before
+    int32_t* fill;                   // [T] keys counted so far (zeroed with the regions)
+    unsigned long long* keys;
+    int K_cap;
+    int32_t* regions_valid;          // set with the regions, checked and cleared here
+    const int32_t* extent_next;      // one past the last region ...
+    int32_t* extent;                 // ... published as the extent of THIS iteration's lists (gfl_fit_snapshot_stage)
+    int32_t* pull_counters; int n_pull;      // the blend launches' pull counters (a forward-only call may have used them since
+                                             //  the regions were reserved)
+};
+
+__host__ __device__ __forceinline__ int region_cap(int c) { return c + (c >> 2) + 32; }
+
+template <bool EWA_MFMA>
+__global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_bin_kernel(const float* __restrict__ params, PreArgs a,
+                                                                         const uint8_t* __restrict__ row_flags, BinArgs b) {
+    extern __shared__ int32_t hist[];               // [T] counts, then cursors; [T] limits behind them
+    const int T = a.gx * a.gy;
+    int32_t* lim = hist + T;
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * BIN_BLOCK + tid;
+    float4 row_v[4] = {};
+    unsigned own_flags = 0;
+    if (i < a.N) {
+        const float4* prow = reinterpret_cast<const float4*>(params + (size_t)i * ROW);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) row_v[q] = prow[q];
+        if (a.scale_rows_mode && row_flags) own_flags = row_flags[i];
+    }
+    // this lane's tiles' regions: requested here, used after the preprocess
+    constexpr int PER_MAX = 8;                       // (T <= 4096: fit_reserved_ok)
+    int2 reg[PER_MAX];
+#pragma unroll
+    for (int k = 0; k < PER_MAX; ++k) reg[k] = tid + k * BIN_BLOCK < T ? b.region[tid + k * BIN_BLOCK] : make_int2(0, 0);
+    if (blockIdx.x == 0 && tid == 0) {
+        if (*b.regions_valid == 0) *a.overflow = 2;      // the host asked for regions nobody has reserved
+        *b.regions_valid = 0;
+        *b.extent = *b.extent_next;
+    }
+    if (blockIdx.x == 0)
+        for (int c = tid; c < b.n_pull; c += BIN_BLOCK) b.pull_counters[c] = 0;
+    for (int t = tid; t < T; t += BIN_BLOCK) hist[t] = 0;
+    __syncthreads();
+    PreOut o = {0.f, 0.f, 0.f, 0.f, 0};
+    preprocess_block<EWA_MFMA, false, true>(a, row_v, own_flags, i, hist, &o);      // (ends behind a barrier)
+    // ---- this block's part of every tile's region
+    int got[PER_MAX], cnt[PER_MAX];
+#pragma unroll
+    for (int k = 0; k < PER_MAX; ++k) {
+        const int t = tid + k * BIN_BLOCK;
+        cnt[k] = t < T ? hist[t] : 0;
+        got[k] = cnt[k] > 0 ? atomicAdd(&b.fill[t], cnt[k]) : 0;
+    }
+    bool over = false, over_cap = false;
+#pragma unroll
+    for (int k = 0; k < PER_MAX; ++k) {
+        const int t = tid + k * BIN_BLOCK;
+        if (t < T) {
+            hist[t] = reg[k].x + got[k];
+            lim[t] = min(reg[k].x + reg[k].y, b.K_cap);
+            over |= got[k] + cnt[k] > reg[k].y;
+            over_cap |= reg[k].x + min(got[k] + cnt[k], reg[k].y) > b.K_cap;
+        }
+    }
+    // (a region cut short by K_cap is the lists' overflow: sticky, the lists have to grow; a tile that outgrew its region voids
+    //  THIS iteration only -- overflow[3], which the tile sort's launch moves to overflow[2] where the update launches look)
+    if (over_cap) *a.overflow = 1;
+    else if (over) a.overflow[3] = 1;
+    __syncthreads();
+    // ---- keys (the scatter launch's walk, with the cursors above)
+    const float u = o.u, v = o.v, cutoff = o.cutoff, depth = o.depth;
+    int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+    if (o.rad > 0) tile_rect(u, v, o.rad, a.gx, a.gy, x0, x1, y0, y1);
+    const int gx = a.gx, nx = x1 - x0, nt = nx * (y1 - y0);
+    const bool wide = nt > WIDE_TILES;
+    if (nt > 0 && !wide) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned long long)(unsigned)i;
+        for (int ty = y0; ty < y1; ++ty)
+            for (int tx = x0; tx < x1; ++tx) {
+                if (!tile_hit2(u, v, cutoff, tx, ty)) continue;
+                const int t = ty * gx + tx;
+                const int pos = atomicAdd(&hist[t], 1);
+                if (pos < lim[t]) __hip_atomic_store(&b.keys[pos], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+    }
+    const int lane = tid & 63;
+    unsigned long long todo = __ballot(wide);
+    while (todo) {
+        const int src = (int)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        const float su = __shfl(u, src), sv = __shfl(v, src), sc = __shfl(cutoff, src);
+        const int sx0 = __shfl(x0, src), sy0 = __shfl(y0, src), snx = __shfl(nx, src), snt = __shfl(nt, src);
+        const unsigned long long key =
+            ((unsigned long long)__float_as_uint(__shfl(depth, src)) << 32) | (unsigned long long)(unsigned)__shfl(i, src);
+        for (int q = lane; q < snt; q += 64) {
+            const int tx = sx0 + q % snx, ty = sy0 + q / snx;
+            if (!tile_hit2(su, sv, sc, tx, ty)) continue;
+            const int t = ty * gx + tx;
+            const int pos = atomicAdd(&hist[t], 1);
+            if (pos < lim[t]) __hip_atomic_store(&b.keys[pos], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // Columns of hist -> exclusive per-block bases (in place) and per-tile totals.
 // 32 tiles per workgroup, eight row groups per tile; loads are issued up to 24 at a time before any
 // store so that they overlap (an in-place load/store chain serialises on the L2 latency:
@@ -319,6 +449,7 @@ __global__ void __launch_bounds__(256) bin_colscan_kernel(int32_t* __restrict__ 
         // this forward has no preprocess launch of its own (expect_pre): the previous iteration's tail must have run it
         if (expect_pre && *pre_valid == 0) *overflow = 2;
         *pre_valid = 0;
+        overflow[2] = 0; overflow[3] = 0;      // (no reserved regions in this iteration: nothing can outgrow one)
     }
     // the pull counters of this iteration's two blend launches (the tile queues themselves may be older: they are
     // rebuilt at the END of an iteration, beside the per-splat launch)
@@ -377,18 +508,26 @@ __device__ __forceinline__ bool sched_xcd_usable(const Sched& sc, int T, int blo
 // inside every XCD's run of tiles (the sort keeps workgroup b's tile on XCD b % 8, gfl_tile_sort.hpp) the tiles with
 // more than twice the mean list length first, both classes in their old order -- a stable partition from two scans
 // (list lengths -> offsets, heavy flags -> ranks).  {tile, start, end} per position: the sort reads ONE 16-byte item.
+// RESERVE (reserved tile regions, fused_preprocess_bin_kernel): the same walk at the END of an iteration, for the NEXT one --
+// every tile gets region_cap(count) positions instead of count, {tile, start, capacity, split} per position and
+// region[tile] = {start, capacity} for the binning launch; the fill counters are zeroed; *extent_next = one past the last
+// region (beyond K_cap: overflow = 1, the lists must grow), *total = the pairs of the iteration that ends here.
+struct ReserveOut { int2* region; int32_t* fill; int32_t* extent_next; int32_t* total; int32_t* overflow; int K_cap; };
+
+template <int BLOCK, bool RESERVE>
 __device__ void build_sort_order(const int32_t* __restrict__ tile_counts, int T, int4* __restrict__ sort_order,
-                                 int32_t* __restrict__ wsum /* [BIN_BLOCK / 64] */) {
-    __shared__ int32_t hsum[BIN_BLOCK / 64], hstart[9], s_nsplit;
+                                 int32_t* __restrict__ wsum /* [BLOCK / 64] */, ReserveOut ro = ReserveOut{}) {
+    __shared__ int32_t hsum[BLOCK / 64], hstart[9], s_nsplit;
+    __shared__ int32_t csum[BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int per = (T + BIN_BLOCK - 1) / BIN_BLOCK;
+    const int per = (T + BLOCK - 1) / BLOCK;
     const int t0 = tid * per;
-    constexpr int PER_MAX = 8;
+    constexpr int PER_MAX = 4096 / BLOCK;
     // the trailer behind order[T]: the positions of the lists the sort cuts in two (gfl_tile_sort.hpp), their number first
     int32_t* trailer = reinterpret_cast<int32_t*>(sort_order + T);
     if (tid == 0) s_nsplit = 0;
     if (per > PER_MAX) {                                 // more than 4096 tiles: the plain order (one lane; never hot)
-        if (tid == 0) {
+        if (tid == 0 && !RESERVE) {                      // (no regions for such grids: fit_reserved_ok)
             int run = 0;
             for (int t = 0; t < T; ++t) {
                 const int c = tile_counts[t];
@@ -400,11 +539,23 @@ __device__ void build_sort_order(const int32_t* __restrict__ tile_counts, int T,
         return;
     }
     int cnt[PER_MAX];
-    int local = 0;
+    int local = 0, local_c = 0;
 #pragma unroll
     for (int k = 0; k < PER_MAX; ++k) {
-        cnt[k] = (k < per && t0 + k < T) ? tile_counts[t0 + k] : 0;
-        local += cnt[k];
+        const bool ok = k < per && t0 + k < T;
+        cnt[k] = ok ? tile_counts[t0 + k] : 0;
+        local += ok ? (RESERVE ? region_cap(cnt[k]) : cnt[k]) : 0;         // positions the tile gets
+        local_c += cnt[k];
+    }
+    if (RESERVE) {
+#pragma unroll
+        for (int k = 0; k < PER_MAX; ++k)
+            if (k < per && t0 + k < T) ro.fill[t0 + k] = 0;
+        // (mean list length for the heavy-tile threshold: from the counts, not from the regions)
+        int cs = local_c;
+#pragma unroll
+        for (int off = 32; off; off >>= 1) cs += __shfl_xor(cs, off);
+        if (lane == 0) csum[wid] = cs;
     }
     int sc = local;
 #pragma unroll
@@ -415,11 +566,21 @@ __device__ void build_sort_order(const int32_t* __restrict__ tile_counts, int T,
     if (lane == 63) wsum[wid] = sc;
     __syncthreads();
     int run = sc - local, total = 0;
-    for (int w = 0; w < BIN_BLOCK / 64; ++w) {
+    for (int w = 0; w < BLOCK / 64; ++w) {
         run += w < wid ? wsum[w] : 0;
         total += wsum[w];
     }
-    const int thr = max(2 * (total / max(T, 1)), 64);
+    int pairs = total;
+    if (RESERVE) {
+        pairs = 0;
+        for (int w = 0; w < BLOCK / 64; ++w) pairs += csum[w];
+        if (tid == 0) {
+            *ro.extent_next = min(total, ro.K_cap);
+            *ro.total = pairs;
+            if (total > ro.K_cap) *ro.overflow = 1;
+        }
+    }
+    const int thr = max(2 * (pairs / max(T, 1)), 64);
     int lh = 0;
 #pragma unroll
     for (int k = 0; k < PER_MAX; ++k) lh += cnt[k] > thr ? 1 : 0;
@@ -440,7 +601,7 @@ __device__ void build_sort_order(const int32_t* __restrict__ tile_counts, int T,
         // heavy tiles before each XCD's run: found by the lane that owns the run's first tile, below; runs that are empty
         // (fewer than eight tiles) keep the total
         int all = 0;
-        for (int w = 0; w < BIN_BLOCK / 64; ++w) all += hsum[w];
+        for (int w = 0; w < BLOCK / 64; ++w) all += hsum[w];
         hstart[tid] = all;
     }
     __syncthreads();
@@ -474,9 +635,11 @@ __device__ void build_sort_order(const int32_t* __restrict__ tile_counts, int T,
                 const int j = atomicAdd(&s_nsplit, 1);       // (which extra workgroup takes which tile does not matter)
                 if (j < SORT_MAX_SPLIT) { w = 1 + j; trailer[1 + j] = pos; }
             }
-            sort_order[pos] = make_int4(t, run, run + cnt[k], w);
+            const int size = RESERVE ? region_cap(cnt[k]) : cnt[k];
+            sort_order[pos] = make_int4(t, run, RESERVE ? size : run + cnt[k], w);
+            if (RESERVE) ro.region[t] = make_int2(run, size);
             H += heavy ? 1 : 0;
-            run += cnt[k];
+            run += size;
         }
     }
     __syncthreads();
@@ -491,12 +654,13 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* _
                                                                   int32_t* __restrict__ overflow,
                                                                   Sched sched_bwd, Sched sched_fwd,
                                                                   const int32_t* __restrict__ sched_valid,
-                                                                  int4* __restrict__ sort_order) {
+                                                                  int4* __restrict__ sort_order,
+                                                                  int32_t* __restrict__ extent) {
     extern __shared__ int32_t cursor[];
     __shared__ int32_t wsum[BIN_BLOCK / 64];
     const int T = gx * gy;
     if (sort_order && blockIdx.x == gridDim.x - 3) {     // (a workgroup of its own: in workgroup 0 it lengthened the launch)
-        build_sort_order(tile_counts, T, sort_order, wsum);
+        build_sort_order<BIN_BLOCK, false>(tile_counts, T, sort_order, wsum);
         return;
     }
     if (blockIdx.x >= gridDim.x - 2) {
@@ -577,7 +741,10 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_scatter_kernel(const float* _
                 }
             }
         }
-        if (blockIdx.x == 0 && tid == BIN_BLOCK - 1) tile_offsets[T] = run;
+        if (blockIdx.x == 0 && tid == BIN_BLOCK - 1) {
+            tile_offsets[T] = run;
+            if (extent) *extent = run;           // (the lists are gap-free here: extent = pairs)
+        }
     }
     GFL_PHASE(2, 2);
     __syncthreads();
@@ -1228,7 +1395,7 @@ struct LossTail {
     int step_affine;                        // hp->step_camera (after a densification nothing is stepped)
     int32_t* d_step;
     float* d_extr_out;                      // [12]: zeros (not computed in such an iteration)
-    int32_t* overflow;                      // [2]: the forward dropped pairs -> nothing is stepped, [1] counts the iteration
+    int32_t* overflow;                      // [4]: the forward dropped pairs ([0] | [2]) -> nothing is stepped, [1] counts the iteration
 };
 
 template <int B = 256>
@@ -1278,7 +1445,7 @@ __device__ void loss_tail(const LossTail& t) {
     if (threadIdx.x >= 16 && threadIdx.x < 28) t.d_extr_out[threadIdx.x - 16] = 0.f;
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (t.overflow && t.overflow[0] != 0) {
+        if (t.overflow && (t.overflow[0] | t.overflow[2]) != 0) {
             // The forward of this iteration dropped (splat, tile) pairs: its gradients are not the scene's.  Nothing is
             // stepped -- the per-splat launch skips its rows the same way --, the step counter stays, and the iteration is
             // counted so that the host can run it again once it has grown the lists (FitEngine.settle_overflow).
@@ -1939,7 +2106,7 @@ __device__ __forceinline__ void camera_tail(const CamTail& t, const float* parti
     __syncthreads();
     if (threadIdx.x == 0) {
         const int e = e_step;
-        if (t.overflow && t.overflow[0] != 0) {
+        if (t.overflow && (t.overflow[0] | t.overflow[2]) != 0) {
             t.overflow[1] += 1;
             return;
         }
@@ -1987,6 +2154,14 @@ struct NextSched {
     const int32_t* tile_counts;
     Sched bwd, fwd;
     int32_t* valid;
+    // a third workgroup reserves the next iteration's tile regions (fused_preprocess_bin_kernel)
+    int reserve;
+    int4* order_next;
+    ReserveOut ro;
+    int32_t* regions_valid;
+    int32_t* pool_counter;
+    int32_t* pull_counters;
+    int n_pull;
 };
 
 // OP = true is the differentiable operator's backward (gfl_render_bwd): the rows hold ACTIVATED attributes, the
@@ -2009,9 +2184,20 @@ __global__ void __launch_bounds__(BLOCK) fused_preprocess_bwd_adam_kernel(
     NextSched ns, PreArgs next, const int32_t* next_overflow) {
     extern __shared__ int32_t sched_scratch[];           // T ints: the scheduler's scratch, or (NEXT) the tile histogram
     if ((int)blockIdx.x >= ns.rows) {
+        __shared__ int32_t sched_wsum[BLOCK / 64];
+        if ((int)blockIdx.x == ns.rows + 2) {
+            // ... and a third the next iteration's tile regions, its sort order, and what the column scan of the exact path
+            // resets (the slot pool's counter, the blend launches' pull counters: both done with for this iteration)
+            build_sort_order<BLOCK, true>(ns.tile_counts, ns.T, ns.order_next, sched_wsum, ns.ro);
+            for (int c = threadIdx.x; c < ns.n_pull; c += BLOCK) ns.pull_counters[c] = 0;
+            if (threadIdx.x == 0) {
+                *ns.pool_counter = 0;
+                *ns.regions_valid = 1;
+            }
+            return;
+        }
         // the two workgroups behind the per-splat ones build the NEXT iteration's tile queues (see fused_scatter_kernel)
         __shared__ SchedLds sched_lds;
-        __shared__ int32_t sched_wsum[BLOCK / 64];
         const Sched sc = (int)blockIdx.x == ns.rows ? ns.bwd : ns.fwd;
         schedule_tiles_xcd<BLOCK>(ns.tile_counts, ns.T, sc, sched_scratch, sched_wsum, sched_lds,
                                   reinterpret_cast<uint32_t*>(sched_scratch + ns.T));      // (T <= SCHED_PLAN_TILES: next_sched_ok)
@@ -2024,7 +2210,8 @@ __global__ void __launch_bounds__(BLOCK) fused_preprocess_bwd_adam_kernel(
         for (int t = threadIdx.x; t < next.gx * next.gy; t += BLOCK) sched_scratch[t] = 0;
     }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool dropped = !OP && next_overflow != nullptr && next_overflow[0] != 0;      // the forward dropped pairs: no row is stepped
+    // the forward dropped pairs (the lists overflowed, [0], or a tile outgrew its reserved region, [2]): no row is stepped
+    const bool dropped = !OP && next_overflow != nullptr && (next_overflow[0] | next_overflow[2]) != 0;
     const int e_step = OP ? 0 : *d_step - ((rc.no_pose_grad && !dropped) ? 1 : 0);   // (the camera launch advances it -- or already has: LossTail)
     float scale_w = 0.f;                              // lambda_scale / rows of the scale term
     if (!OP && rc.lambda_scale != 0.f) {
@@ -2401,7 +2588,7 @@ __global__ void __launch_bounds__(1024) fused_camera_adam_kernel(
     __syncthreads();
     if (threadIdx.x == 0) {
         const int e = e_step;
-        if (overflow && overflow[0] != 0) {      // the forward dropped pairs: nothing is stepped, the iteration is counted (LossTail)
+        if (overflow && (overflow[0] | overflow[2]) != 0) {      // the forward dropped pairs: nothing is stepped, the iteration is counted (LossTail)
             overflow[1] += 1;
             return;
         }
@@ -2621,7 +2808,9 @@ size_t gfl_fit_workspace_bytes(int cap, int K_cap, int W, int H) {
            + up256((size_t)fit_nblk(cap > 0 ? cap : 1) * sizeof(int32_t))              // rows of the scale term per block
            + up256((T * 4 + SORT_ORDER_TRAILER) * sizeof(int32_t))                     // the tile sort's order (+ its split list)
            + up256((size_t)K_cap * sizeof(int32_t))                                    // second slot pool   } iterations take
-           + up256((size_t)fit_nblk(cap > 0 ? cap : 1) * sizeof(int32_t));             // second scale rows  } turns ("next preprocess")
+           + up256((size_t)fit_nblk(cap > 0 ? cap : 1) * sizeof(int32_t))              // second scale rows  } turns ("next preprocess")
+           + up256((T * 4 + SORT_ORDER_TRAILER) * sizeof(int32_t))                     // reserved tile regions: the next sort order,
+           + up256(T * sizeof(int2)) + up256(T * sizeof(int32_t));                      //   {start, capacity} per tile, fill counters
 }
 
 struct FitWs {
@@ -2645,6 +2834,13 @@ struct FitWs {
     int32_t* scale_cnt;      // [blocks of the preprocess launch] rows of the scale term (lambda_scale)
     int32_t* scale_cnt2;     //   (second set, by parity like slot_pool2)
     int4* sort_order;        // [T] {tile, start, end, 0}: the order the tile sort takes the tiles in (fused_scatter_kernel)
+    // reserved tile regions (fused_preprocess_bin_kernel): written at the end of an iteration for the next one
+    int4* sort_order_next;   // [T] {tile, start, capacity, split} + trailer
+    int2* region;            // [T] {start, capacity}
+    int32_t* fill;           // [T] keys binned so far
+    int32_t* regions_valid;  // != 0: the three arrays above are those of the coming iteration
+    int32_t* extent;         // one past the last list position of the last forward (exact path: the number of pairs)
+    int32_t* extent_next;    // ... of the regions
 };
 
 static FitWs carve(const gfl_fit_state* st) {
@@ -2666,6 +2862,9 @@ static FitWs carve(const gfl_fit_state* st) {
     w.pool_counter = (int32_t*)p;
     w.sched_valid = w.pool_counter + 16;
     w.pre_valid = w.pool_counter + 24;
+    w.regions_valid = w.pool_counter + 32;
+    w.extent = w.pool_counter + 40;
+    w.extent_next = w.pool_counter + 48;
     p += 256;
     w.slot_pool = (int32_t*)p;
     p += up256((size_t)st->K_cap * sizeof(int32_t));
@@ -2705,6 +2904,9 @@ static FitWs carve(const gfl_fit_state* st) {
     w.sort_order = (int4*)((char*)w.scale_cnt + up256((size_t)fit_nblk(st->cap > 0 ? st->cap : 1) * sizeof(int32_t)));
     w.slot_pool2 = (int32_t*)((char*)w.sort_order + up256((T * 4 + SORT_ORDER_TRAILER) * sizeof(int32_t)));
     w.scale_cnt2 = (int32_t*)((char*)w.slot_pool2 + up256((size_t)st->K_cap * sizeof(int32_t)));
+    w.sort_order_next = (int4*)((char*)w.scale_cnt2 + up256((size_t)fit_nblk(st->cap > 0 ? st->cap : 1) * sizeof(int32_t)));
+    w.region = (int2*)((char*)w.sort_order_next + up256((T * 4 + SORT_ORDER_TRAILER) * sizeof(int32_t)));
+    w.fill = (int32_t*)((char*)w.region + up256(T * sizeof(int2)));
     return w;
 }
 
@@ -2729,6 +2931,39 @@ static NextSched next_sched(const FitWs& w, int rows, int T) {
     ns.bwd = w.sched;
     ns.fwd = w.sched_fwd;
     ns.valid = w.sched_valid;
+    ns.reserve = 0;
+    ns.order_next = nullptr; ns.ro = ReserveOut{}; ns.regions_valid = nullptr; ns.pool_counter = nullptr;
+    ns.pull_counters = nullptr; ns.n_pull = 0;
+    return ns;
+}
+
+// GFL_RESERVED=0 switches the reserved tile regions off (every iteration takes the exact binning path).
+static bool reserved_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GFL_RESERVED");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+static bool next_pre_enabled();
+// Reserved tile regions: grids of up to 4096 tiles (the region workgroup holds a tile's count in registers: 16 per lane on
+// REDUCE_BLOCK lanes; the binning kernel 8 per lane on BIN_BLOCK), the tile sort's order in use, the scheduling workgroups
+// in the per-splat launch (the region workgroup is the third of them), not together with the "next preprocess" experiment.
+static bool fit_reserved_ok(const FitWs& w, int T) {
+    return reserved_enabled() && !next_pre_enabled() && next_sched_ok(w, T) && T <= 4096 && sort_heavy_first() &&
+           2 * (size_t)T * sizeof(int32_t) <= 57 * 1024;
+}
+static NextSched next_sched_reserving(const gfl_fit_state* st, const FitWs& w, int rows, int T) {
+    NextSched ns = next_sched(w, rows, T);
+    if (!fit_reserved_ok(w, T)) return ns;
+    ns.reserve = 1;
+    ns.order_next = w.sort_order_next;
+    ns.ro.region = w.region; ns.ro.fill = w.fill; ns.ro.extent_next = w.extent_next; ns.ro.total = st->tile_offsets + T;
+    ns.ro.overflow = st->overflow; ns.ro.K_cap = st->K_cap;
+    ns.regions_valid = w.regions_valid;
+    ns.pool_counter = w.pool_counter;
+    ns.pull_counters = w.sched.counters; ns.n_pull = 2 * w.sched.nq;
     return ns;
 }
 
@@ -2778,8 +3013,9 @@ static PreArgs pre_args(const gfl_fit_state* st, const gfl_fit_hyper* hp, const 
 
 // pre_done: this forward's preprocess has been run by the previous iteration's per-splat launch (its tail).
 // parity: which of the two slot pools / scale-row sets this iteration uses.
+// reserved: the tile regions the previous iteration's last launch reserved are used (one launch instead of three).
 static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream, int op_mode,
-                            int pre_done = 0, int parity = 0) {
+                            int pre_done = 0, int parity = 0, int reserved = 0) {
     int rc = fit_check(st, hp);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
@@ -2791,12 +3027,30 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
     // plans' 16 KB exist only for grids of up to 4096 tiles).  14 592 tiles: 2560 x 1440 has 14 400.
     if (lds > 57 * 1024) return GFL_ERR_INVALID;
     int32_t* slot_pool = parity ? w.slot_pool2 : w.slot_pool;
-    if (!pre_done) {
+    if (reserved) {
+        if (pre_done || op_mode || !fit_reserved_ok(w, T)) return GFL_ERR_INVALID;
+        {
+            StageScope p(ST_PREPROCESS, s);
+            BinArgs b;
+            b.region = w.region; b.fill = w.fill; b.keys = w.keys; b.K_cap = st->K_cap;
+            b.regions_valid = w.regions_valid; b.extent_next = w.extent_next; b.extent = w.extent;
+            b.pull_counters = w.sched.counters; b.n_pull = 2 * w.sched.nq;
+            auto kern = ewa_on_mfma() ? fused_preprocess_bin_kernel<true> : fused_preprocess_bin_kernel<false>;
+            kern<<<nblk, BIN_BLOCK, 2 * lds, s>>>(st->params, pre_args(st, hp, w, gx, gy, op_mode, parity), st->row_flags, b);
+        }
+        {
+            StageScope p(ST_TILE_SORT, s);
+            rc = gfl_tile_sort_reserved((const int32_t*)w.sort_order_next, w.fill, w.tile_counts, st->overflow + 2, st->W, st->H,
+                                        st->K_cap, w.keys, st->ids, st->tile_range, st->rec, w.slot_inv, slot_pool, stream);
+        }
+        if (rc) return rc;
+    }
+    if (!pre_done && !reserved) {
         StageScope p(ST_PREPROCESS, s);
         auto kern = ewa_on_mfma() ? fused_preprocess_fwd_kernel<true> : fused_preprocess_fwd_kernel<false>;
         kern<<<nblk, BIN_BLOCK, lds, s>>>(st->params, pre_args(st, hp, w, gx, gy, op_mode, parity), st->row_flags);
     }
-    {
+    if (!reserved) {
         StageScope p(ST_COLSCAN, s);
         bin_colscan_kernel<<<(T + CS_TILES - 1) / CS_TILES, 256, 0, s>>>(w.hist, nblk, T, w.tile_counts, w.pool_counter,
                                                                          w.sched.counters, 2 * w.sched.nq, w.pre_valid,
@@ -2805,13 +3059,13 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
     // (the order of the tile sort is built by one workgroup with up to eight tiles per lane in registers: beyond 4096 tiles
     //  -- 1080p has 8160 -- the sort takes the tiles in their own order)
     const bool ordered = sort_heavy_first() && T <= 8 * BIN_BLOCK;
-    {
+    if (!reserved) {
         StageScope p(ST_SCATTER, s);
         fused_scatter_kernel<<<nblk + 2 + (ordered ? 1 : 0), BIN_BLOCK, sched_dyn_lds(T), s>>>(st->rec, st->N, gx, gy, w.hist, w.tile_counts,
                                                               st->tile_offsets, st->K_cap, w.keys, st->overflow, w.sched, w.sched_fwd,
-                                                              w.sched_valid, ordered ? w.sort_order : nullptr);
+                                                              w.sched_valid, ordered ? w.sort_order : nullptr, w.extent);
     }
-    {
+    if (!reserved) {
         StageScope p(ST_TILE_SORT, s);
         if (ordered)
             rc = gfl_tile_sort_ordered((const int32_t*)w.sort_order, st->W, st->H, st->K_cap, w.keys, st->ids, st->tile_range,
@@ -2969,7 +3223,7 @@ int gfl_fit_snapshot_stage(const gfl_fit_state* src, const gfl_fit_state* dst, g
     const FitWs a = carve(src), b = carve(dst);
     if (a.sched_fwd.nq != b.sched_fwd.nq || a.sched_fwd.cap_q != b.sched_fwd.cap_q) return GFL_ERR_INVALID;
     StageCopy c;
-    c.k_ptr = src->tile_offsets + T;
+    c.k_ptr = a.extent;
     c.ids_cap = (unsigned)min(src->K_cap, dst->K_cap);
     c.seg[0] = {(const uint32_t*)src->ids, (uint32_t*)dst->ids, 0u};
     c.seg[1] = {(const uint32_t*)src->rec, (uint32_t*)dst->rec, (unsigned)((size_t)src->N * REC)};
@@ -3111,8 +3365,8 @@ static int fit_backward_step_impl(const gfl_fit_state* st, const gfl_fit_hyper* 
     }
     {
         StageScope p(ST_PRE_BWD_ADAM, s);
-        const NextSched ns = next_sched(w, rows, T);
-        fused_preprocess_bwd_adam_kernel<false, REDUCE_BLOCK, false><<<rows + next_sched_blocks(w, T), REDUCE_BLOCK, next_sched_lds(w, T), s>>>(
+        const NextSched ns = next_sched_reserving(st, w, rows, T);
+        fused_preprocess_bwd_adam_kernel<false, REDUCE_BLOCK, false><<<rows + next_sched_blocks(w, T) + ns.reserve, REDUCE_BLOCK, next_sched_lds(w, T), s>>>(
             st->params, st->adam_m, st->adam_v, st->intr, st->pose, st->rec, st->d_rec, w.pair_grad, slot_pool,
             st->tile_range, w.slot_inv, gx, gy, st->N, st->W, st->H, st->flow_target, st->flow_w, st->still_target,
             st->still_w, st->row_flags, rcfg, ac, st->step, w.partial, nullptr, nullptr, nullptr, scale_cnt, tail, ns, PreArgs{}, st->overflow);
@@ -3143,24 +3397,34 @@ static bool fit_next_pre_ok(const gfl_fit_state* st, const gfl_fit_hyper* hp, co
 }
 
 int gfl_fit_iterations(const gfl_fit_state* st, const gfl_fit_hyper* hp, int count, int flags, gfl_stream_t stream) {
-    if (count < 1 || (flags & ~(GFL_ITER_PRE_DONE | GFL_ITER_PRE_NEXT | GFL_ITER_ODD))) return GFL_ERR_INVALID;
+    if (count < 1 || (flags & ~(GFL_ITER_PRE_DONE | GFL_ITER_PRE_NEXT | GFL_ITER_ODD | GFL_ITER_RESERVED))) return GFL_ERR_INVALID;
     int rc = fit_check(st, hp);
     if (rc) return rc;
     const int T = ((st->W + GFL_TILE - 1) / GFL_TILE) * ((st->H + GFL_TILE - 1) / GFL_TILE);
     const FitWs w = carve(st);
     const bool ok = fit_next_pre_ok(st, hp, w, T);
     if ((flags & GFL_ITER_PRE_DONE) && !ok) return GFL_ERR_INVALID;
+    const bool res_ok = fit_reserved_ok(w, T) && st->N > 0;
+    if ((flags & GFL_ITER_RESERVED) && !res_ok) return GFL_ERR_INVALID;
     int parity = (flags & GFL_ITER_ODD) ? 1 : 0;
     for (int j = 0; j < count; ++j) {
         const int pre_done = j == 0 ? ((flags & GFL_ITER_PRE_DONE) ? 1 : 0) : (ok ? 1 : 0);
         const int do_next = ok && (j + 1 < count || (flags & GFL_ITER_PRE_NEXT));
-        rc = fit_forward_impl(st, hp, stream, 0, pre_done, parity);
+        // (every iteration of a call but the first follows a full iteration: its tile regions are reserved)
+        const int reserved = res_ok && (j > 0 || (flags & GFL_ITER_RESERVED)) ? 1 : 0;
+        rc = fit_forward_impl(st, hp, stream, 0, pre_done, parity, reserved);
         if (rc) return rc;
         rc = fit_backward_step_impl(st, hp, stream, do_next, parity);
         if (rc) return rc;
         if (ok) parity ^= 1;
     }
     return GFL_OK;
+}
+
+int gfl_fit_reserved_supported(const gfl_fit_state* st, const gfl_fit_hyper* hp) {
+    if (fit_check(st, hp) || st->N <= 0) return 0;
+    const int T = ((st->W + GFL_TILE - 1) / GFL_TILE) * ((st->H + GFL_TILE - 1) / GFL_TILE);
+    return fit_reserved_ok(carve(st), T) ? 1 : 0;
 }
 
 int gfl_fit_next_preprocess_supported(const gfl_fit_state* st, const gfl_fit_hyper* hp) {

@@ -16,6 +16,7 @@ struct Proj {
 
 __device__ __forceinline__ Proj project_fwd(const Cam& c, float x, float y, float z, int W, int H, float nearest,
                                             float extent) {
+#pragma clang fp contract(off)     // (no fused multiply-adds: the same bits in every kernel these are inlined into, and the oracle's arithmetic)
     Proj p;
     p.px = c.r00 * x + c.r01 * y + c.r02 * z + c.t0;
     p.py = c.r10 * x + c.r11 * y + c.r12 * z + c.t1;
@@ -54,12 +55,14 @@ __device__ __forceinline__ void cam_grad_to_world(const Cam& c, float x, float y
 // ------------------------------------------------------------------- cov3d (A5)
 // q = (w,x,y,z); Sigma = R diag(s^2) R^T; out = xx,xy,xz,yy,yz,zz
 __device__ __forceinline__ void quat_rot(float w, float x, float y, float z, float (&R)[9]) {
+#pragma clang fp contract(off)     // (no fused multiply-adds: the same bits in every kernel these are inlined into, and the oracle's arithmetic)
     R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - w * z); R[2] = 2.f * (x * z + w * y);
     R[3] = 2.f * (x * y + w * z); R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - w * x);
     R[6] = 2.f * (x * z - w * y); R[7] = 2.f * (y * z + w * x); R[8] = 1.f - 2.f * (x * x + y * y);
 }
 
 __device__ __forceinline__ void cov3d_fwd(const float (&s)[3], const float (&q)[4], float (&cov)[6]) {
+#pragma clang fp contract(off)     // (no fused multiply-adds: the same bits in every kernel these are inlined into, and the oracle's arithmetic)
     float R[9];
     quat_rot(q[0], q[1], q[2], q[3], R);
     const float a = s[0] * s[0], b = s[1] * s[1], c = s[2] * s[2];
@@ -112,6 +115,7 @@ struct Ewa {
 // VALU: 30 multiply-adds per splat in the lane that owns the splat.
 __device__ __forceinline__ void cov2d_valu(const float (&m0)[3], const float (&m1)[3], const float (&cov)[6], float& a,
                                            float& b, float& c) {
+#pragma clang fp contract(off)     // (no fused multiply-adds: the same bits in every kernel these are inlined into, and the oracle's arithmetic)
     const float s00 = cov[0] * m0[0] + cov[1] * m0[1] + cov[2] * m0[2];
     const float s01 = cov[1] * m0[0] + cov[3] * m0[1] + cov[4] * m0[2];
     const float s02 = cov[2] * m0[0] + cov[4] * m0[1] + cov[5] * m0[2];
@@ -183,6 +187,7 @@ __device__ __forceinline__ void cov2d_mfma(const float (&m0)[3], const float (&m
 }
 
 __device__ __forceinline__ void ewa_finish(Ewa& e, float a, float b, float c) {
+#pragma clang fp contract(off)     // (no fused multiply-adds: the same bits in every kernel these are inlined into, and the oracle's arithmetic)
     e.a = a + GFL_LOWPASS;
     e.b = b;
     e.c = c + GFL_LOWPASS;
@@ -193,6 +198,7 @@ __device__ __forceinline__ void ewa_finish(Ewa& e, float a, float b, float c) {
 }
 
 __device__ __forceinline__ void ewa_jacobian(const Cam& c, float px, float py, float pz, int W, int H, Ewa& e) {
+#pragma clang fp contract(off)     // (no fused multiply-adds: the same bits in every kernel these are inlined into, and the oracle's arithmetic)
     e.z = pz;
     const float limx = GFL_FOV_CLAMP * (float)W / (2.0f * c.fx);
     const float limy = GFL_FOV_CLAMP * (float)H / (2.0f * c.fy);

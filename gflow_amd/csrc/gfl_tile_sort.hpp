@@ -188,7 +188,10 @@ __global__ void __launch_bounds__(SORT_THREADS, 8) bin_tile_sort_kernel(const in
                                                                         const float* __restrict__ slot_rec,
                                                                         int32_t* __restrict__ slot_inv,
                                                                         int32_t* __restrict__ slot_pool, int gx, int gy,
-                                                                        const int4* __restrict__ order) {
+                                                                        const int4* __restrict__ order,
+                                                                        const int32_t* __restrict__ fill,
+                                                                        int32_t* __restrict__ counts_out,
+                                                                        int32_t* __restrict__ void_words) {
     __shared__ unsigned long long sk[SORT_XB * SORT_THREADS];      // cross-wave exchange buffer
     // XCD x sorts one contiguous range of tiles (the dispatcher places workgroup b on XCD b % 8): the records the slot
     // table needs (uv, radius of every key's splat) are those of neighbouring tiles; with block = tile every XCD pulled
@@ -206,6 +209,16 @@ __global__ void __launch_bounds__(SORT_THREADS, 8) bin_tile_sort_kernel(const in
     // (the trailer follows order[T]; written with the order by the scatter launch).  (Two workgroups for EVERY position,
     // the second leaving at once where there is nothing to split, cost the bench scene 6.7 us: 1 620 more 512-lane
     // workgroups to dispatch.)
+    // `fill` (reserved tile regions, gfl_fused.hip): the order was written at the END of the iteration before, with every
+    // tile's region {start, capacity} in place of {start, end}; the list's length is what the binning launch counted into
+    // fill[tile] (capped: what did not fit was not written, and the iteration steps nothing).  counts_out[tile] = what the
+    // tile wanted (the next regions are sized by it).  void_words: {this iteration is void, a tile outgrew its region}: the
+    // binning launch sets the second, this launch moves it into the first, where the update launches look -- a word nobody
+    // writes while they run.
+    if (void_words && blockIdx.x == 0 && threadIdx.x == 0) {
+        void_words[0] = void_words[1];
+        void_words[1] = 0;
+    }
     const int T_all = gx * gy;
     int lb, half = 0;
     bool flagged = false;
@@ -226,7 +239,7 @@ __global__ void __launch_bounds__(SORT_THREADS, 8) bin_tile_sort_kernel(const in
         const int4 it = order[lb];
         tile = it.x;
         start = min(it.y, K_cap);
-        end = min(it.z, K_cap);
+        end = min(fill ? it.y + min(fill[tile], it.z) : it.z, K_cap);
         flagged = it.w != 0;
     } else {
         start = min(offsets[tile], K_cap);
@@ -239,6 +252,7 @@ __global__ void __launch_bounds__(SORT_THREADS, 8) bin_tile_sort_kernel(const in
     if (threadIdx.x == 0 && half == 0) {
         tile_range[2 * tile] = n > 0 ? start : 0;
         tile_range[2 * tile + 1] = n > 0 ? end : 0;
+        if (counts_out) counts_out[tile] = fill ? fill[tile] : max(n, 0);
     }
     if (n <= 0) return;
     unsigned long long* seg = keys + start;

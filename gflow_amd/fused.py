@@ -119,7 +119,7 @@ class FitEngine:
         self.sums = torch.zeros(8, **f32)
         self.tile_offsets = torch.zeros(self.T + 1, **i32)
         self.tile_range = torch.zeros(self.T, 2, **i32)
-        self.overflow = torch.zeros(2, **i32)         # [0]: sticky flag, [1]: iterations that stepped nothing because of it
+        self.overflow = torch.zeros(4, **i32)         # [0]: sticky flag, [1]: iterations that stepped nothing, [2], [3]: this one is void (gflow_hip.h)
         self.gt_rgb = self.gt_depth = self.keep = None
         self.move_mask = self.foot_flags = None
         self.flow_target = self.flow_w = self.still_target = self.still_w = self.row_flags = None
@@ -127,6 +127,7 @@ class FitEngine:
         self.K_cap_req = K_cap
         self._graphs, self._graph_key = {}, None
         self._launched = False
+        self._reserved_N = -1          # N of the last full iteration whose last launch reserved the next one's tile regions
         self.busy = False              # checked out by the differentiable operator (gflow_amd.render)
         self._alloc(int(capacity))
 
@@ -162,6 +163,7 @@ class FitEngine:
         nbytes = self.lib.gfl_fit_workspace_bytes(self.cap, self.K_cap, self.W, self.H)
         self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.dev)   # the pool counter must start at 0
         self._state = None
+        self._reserved_N = -1
 
     def ensure_capacity(self, n):
         if n > self.cap:
@@ -199,6 +201,7 @@ class FitEngine:
             self.params[:n, a:b] = attrs[k].detach().reshape(n, b - a).to(self.dev)
         self.params[:n, 14:] = 0
         self._state = None
+        self._reserved_N = -1
 
     def views(self):
         """Live (N, k) views of the packed parameter rows."""
@@ -300,8 +303,24 @@ class FitEngine:
     def backward_step(self):
         L.check(self.lib.gfl_fit_backward_step(ctypes.byref(self.state()), ctypes.byref(self.hp), L.stream()),
                 "fit backward/step")
+        self._reserved_N = self.N
 
-    def iteration(self, use_graph=False, count=1, snapshot=False, flags=0):
+    GFL_ITER_RESERVED = 8
+
+    def _reserved_flag(self):
+        """GFL_ITER_RESERVED if the coming iteration may bin into the tile regions the last full iteration reserved
+        (include/gflow_hip.h): the same splats as then (appended rows land in tiles whose regions were sized without them:
+        not wrong -- the library notices a region that is too small and the iteration is run again -- but a wasted
+        iteration), and a state the library supports it for."""
+        if self._reserved_N != self.N or self.N <= 0:
+            return 0
+        key = (self.W, self.H, self.K_cap)
+        if getattr(self, "_reserved_sup", (None, 0))[0] != key:
+            self._reserved_sup = (key, int(self.lib.gfl_fit_reserved_supported(ctypes.byref(self.state()),
+                                                                                ctypes.byref(self.hp))))
+        return self.GFL_ITER_RESERVED if self._reserved_sup[1] else 0
+
+    def iteration(self, use_graph=False, count=1, snapshot=False, flags=0, reserved=None):
         """``count`` full iterations; ``snapshot=True`` (count 1): followed by gfl_fit_snapshot into the engine's own
         image buffer -- returns that (3, H, W, 3) uint8 tensor, which the NEXT snapshot overwrites -- so that the
         iteration and the eight launches of the snapshot replay as ONE graph (launched one by one they left ~6 us
@@ -309,7 +328,8 @@ class FitEngine:
         lazily, re-captured whenever a pointer, a size or a hyper-parameter changed); it is ignored
         while the library's stage profiler is recording events.  Several iterations in ONE graph save the
         2-6 us that pass between two graph launches (tools/graph_gap.py: 0.2094 -> 0.2028, 0.2079 -> 0.2058 ms per
-        iteration with two per graph)."""
+        iteration with two per graph).  An iteration that follows a full iteration on the same splats bins into the tile
+        regions that one reserved (GFL_ITER_RESERVED, include/gflow_hip.h): decided here, a graph per case."""
         if snapshot:
             from .color import lut
             assert count == 1
@@ -318,7 +338,9 @@ class FitEngine:
                 self._snap_ws = torch.empty(int(need), dtype=torch.uint8, device=self.dev)
                 self._snap_out = torch.empty(3, self.H, self.W, 3, dtype=torch.uint8, device=self.dev)
             snap_args = (L.ptr(lut("turbo", self.dev)), L.ptr(self._snap_out), L.ptr(self._snap_ws), self._snap_ws.numel())
-        gkey = ("snap", count) if snapshot else count
+        # (reserved=False: the first iteration of the call takes the exact binning path whatever came before)
+        reserved = 0 if (flags or reserved is False) else self._reserved_flag()
+        gkey = ("snap", count, reserved) if snapshot else (count, reserved)
         if use_graph and not PROFILE["mask"] and self._launched and not flags:
             key = bytes(self.state()) + bytes(self.hp)
             if self._graph_key != key:
@@ -349,8 +371,8 @@ class FitEngine:
                             try:
                                 # (several iterations in one call: between two plain ones the next preprocess runs in
                                 #  the tail of the per-splat launch, include/gflow_hip.h)
-                                L.check(self.lib.gfl_fit_iterations(ctypes.byref(st), ctypes.byref(hp), count, 0, L.stream()),
-                                        "fit iterations (capture)")
+                                L.check(self.lib.gfl_fit_iterations(ctypes.byref(st), ctypes.byref(hp), count, reserved,
+                                                                    L.stream()), "fit iterations (capture)")
                                 if snapshot:
                                     L.check(self.lib.gfl_fit_snapshot(ctypes.byref(st), ctypes.byref(hp), *snap_args,
                                                                       L.stream()), "snapshot (capture)")
@@ -362,9 +384,11 @@ class FitEngine:
                             _gc.enable()
                 self._graphs[gkey] = g
             g.replay()
+            self._reserved_N = self.N
             return self._snap_out if snapshot else None
-        L.check(self.lib.gfl_fit_iterations(ctypes.byref(self.state()), ctypes.byref(self.hp), count, int(flags), L.stream()),
-                "fit iterations")
+        L.check(self.lib.gfl_fit_iterations(ctypes.byref(self.state()), ctypes.byref(self.hp), count, int(flags) | reserved,
+                                            L.stream()), "fit iterations")
+        self._reserved_N = self.N
         self._launched = True          # every kernel is loaded now: capture is safe from here on
         if snapshot:
             L.check(self.lib.gfl_fit_snapshot(ctypes.byref(self.state()), ctypes.byref(self.hp), *snap_args, L.stream()),
@@ -404,6 +428,7 @@ class FitEngine:
         n = saved["N"]
         if n != self.N:
             raise RuntimeError("FitEngine.restore_state: the splat count has changed since save_state")
+        self._reserved_N = -1          # (the regions were sized for the splats as they are now, not as they were then)
         for dst, src in zip((self.params, self.adam_m, self.adam_v), saved["rows"]):
             torch.bitwise_or(src.view(torch.int32), 0, out=dst[:n].view(torch.int32))
         for k in self._STATE_TENSORS:
@@ -450,12 +475,18 @@ class FitEngine:
         """Blocking.  If a forward dropped (splat, tile) pairs since the last call: the lists are doubled, both words are
         cleared, and the number of iterations that stepped NOTHING meanwhile is returned (the library skips every update
         while the flag is set, include/gflow_hip.h) -- the caller runs that many iterations again and the fit is where a
-        fit that never overflowed would be.  0: nothing happened.  (K_cap is max(4 M, 8 x capacity), ~15 x what fits
+        fit that never overflowed would be.  The same count, without anything to grow, for iterations that were void
+        because a tile outgrew its reserved region.  0: nothing happened.  (K_cap is max(4 M, 8 x capacity), ~15 x what fits
         produce: this is the rare path, but a silent or fatal one it must not be.)"""
         self._ovf_event = None
-        code, skipped = (int(v) for v in self.overflow.tolist())                       # the host read
+        code, skipped = (int(v) for v in self.overflow[:2].tolist())                   # the host read
         if code == 0:
-            return 0
+            if skipped > 0:
+                # tiles outgrew the regions reserved for them in `skipped` iterations (GFL_ITER_RESERVED): those stepped
+                # nothing, the ones after them were fine again -- nothing to grow, that many iterations more to run
+                self.overflow[1:2].zero_()
+                self.regions_outgrown = getattr(self, "regions_outgrown", 0) + skipped
+            return max(skipped, 0)
         if code != 1:
             self.overflow.zero_()
             raise RuntimeError(self._overflow_message(code))
@@ -470,7 +501,8 @@ class FitEngine:
 
     def _overflow_message(self, code):
         if code == 2:
-            return "FitEngine: an iteration was told its preprocess had been run by the previous one's tail, and it had not"
+            return ("FitEngine: an iteration was told that the previous one had run its preprocess / reserved its tile regions, "
+                    "and it had not")
         return f"FitEngine: more than K_cap={self.K_cap} splat-tile pairs; raise K_cap"
 
     def watch_overflow(self):

@@ -266,13 +266,23 @@ typedef struct gfl_fit_state {
     float *render, *final_T;                    /* [4][H][W], [H][W] */
     int32_t* n_contrib;                         /* [H][W] */
     float *d_render, *err_px, *sums;            /* [4][H][W], [H][W], [8] as gfl_loss_fwd_bwd */
-    int32_t *tile_offsets, *ids, *tile_range, *overflow; /* [T+1], [K_cap], [T][2], [2].  overflow[0] is sticky: 1 = a
+    int32_t *tile_offsets, *ids, *tile_range, *overflow; /* [T+1], [K_cap], [T][2], [4].  overflow[0] is sticky: 1 = a
                                                           * forward produced more than K_cap pairs (or slot-pool entries) and
-                                                          * dropped some, 2 = GFL_ITER_PRE_DONE without a preprocess.  While it
+                                                          * dropped some, 2 = GFL_ITER_PRE_DONE without a preprocess or
+                                                          * GFL_ITER_RESERVED without reserved regions.  While it
                                                           * is set, gfl_fit_backward_step steps NOTHING (rows, moments, pose,
                                                           * depth affine and step counter stay) and adds 1 to overflow[1]: the
-                                                          * caller grows the lists, clears both words and runs overflow[1]
-                                                          * iterations again (gflow_amd/fused.py: settle_overflow) */
+                                                          * caller grows the lists, clears the words and runs overflow[1]
+                                                          * iterations again (gflow_amd/fused.py: settle_overflow).
+                                                          * overflow[2] != 0: THIS iteration is void (a tile outgrew its
+                                                          * reserved region: nothing is stepped, overflow[1] counts it, the
+                                                          * next iteration is fine again -- with overflow[0] == 0 the caller
+                                                          * just runs overflow[1] more iterations); overflow[3]: the same,
+                                                          * between the binning launch and the tile sort.
+                                                          * tile_offsets[0..T) is written by the exact binning path only;
+                                                          * tile_offsets[T] = the number of pairs, always; after an iteration
+                                                          * on reserved regions the lists in ids have gaps between them
+                                                          * (tile_range says where each one is) */
     void* workspace;
     size_t workspace_bytes;                     /* >= gfl_fit_workspace_bytes() */
 } gfl_fit_state;
@@ -315,12 +325,29 @@ int gfl_fit_iteration(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stre
  *                      otherwise *overflow becomes 2);
  *   GFL_ITER_ODD       the first iteration uses the second of the two slot-pool sets (iterations alternate between them:
  *                      pass it after an odd number of chained iterations).
- * gfl_fit_next_preprocess_supported: 1 if iterations with this state / these hyper-parameters take the short cut. */
+ * gfl_fit_next_preprocess_supported: 1 if iterations with this state / these hyper-parameters take the short cut.
+ *
+ * Reserved tile regions (round 4, the default): the last launch of every full iteration gives each tile a region of the
+ * key array sized by what the tile holds now plus a margin (count + count / 4 + 32), and an iteration that FOLLOWS a full
+ * iteration bins straight into those regions -- preprocess, column scan and scatter are one launch (one returning atomic
+ * per (block of 512 splats, tile) reserves the block's part of the region), six launches per iteration instead of eight.
+ * The sorted lists, the render and every gradient are those of the exact path; only the lists' positions in ids differ.
+ * Iterations 2 .. count of a call always take it; the first does with
+ *   GFL_ITER_RESERVED  the previous launches on this state were a full iteration (gfl_fit_iterations / gfl_fit_iteration /
+ *                      gfl_fit_backward_step) and the splats have not been replaced since (checked on the device as far
+ *                      as it can be: without reserved regions *overflow becomes 2).  The regions are a PREDICTION: a tile
+ *                      that outgrows its region voids that one iteration (overflow[2], counted in overflow[1]; the regions
+ *                      reserved at its end are sized by what the tiles wanted) -- whatever the host did to the splats in
+ *                      between, the result is never wrong.
+ * gfl_fit_reserved_supported: 1 if this state's iterations can (tile grids of up to 4096 tiles; GFL_RESERVED=0 in the
+ * environment switches it off). */
 #define GFL_ITER_PRE_DONE 1
 #define GFL_ITER_PRE_NEXT 2
 #define GFL_ITER_ODD 4
+#define GFL_ITER_RESERVED 8
 int gfl_fit_iterations(const gfl_fit_state* st, const gfl_fit_hyper* hp, int count, int flags, gfl_stream_t stream);
 int gfl_fit_next_preprocess_supported(const gfl_fit_state* st, const gfl_fit_hyper* hp);
+int gfl_fit_reserved_supported(const gfl_fit_state* st, const gfl_fit_hyper* hp);
 /* ---- the fused rasteriser as a differentiable operator (no loss, no optimiser) ------------------------
  * render(gaussians, camera) -> {rgb, depth_map, uv, depth} = render_multiple(input_group, ["rgb", "uv", "depth",
  * "depth_map"]) of render.py:6-108 in ONE call (last row), and its backward.
@@ -381,6 +408,12 @@ int gfl_tile_sort_with_slots(const int32_t* tile_offsets, int W, int H, int K_ca
 #define GFL_SORT_ORDER_TRAILER (GFL_SORT_MAX_SPLIT + 4)
 int gfl_tile_sort_ordered(const int32_t* order, int W, int H, int K_cap, void* keys, int32_t* ids, int32_t* tile_range,
                           const float* rec, int32_t* slot_inv, int32_t* slot_pool, gfl_stream_t stream);
+/* same for reserved tile regions: order[T][4] = {tile, start, capacity, split}; the list of `tile` is the first
+ * min(fill[tile], capacity) keys behind `start` (fill[T]: what the binning launch counted); tile_counts[tile] = fill[tile];
+ * void_words (may be NULL): void_words[0] = void_words[1], void_words[1] = 0 (gfl_fit_state.overflow + 2). */
+int gfl_tile_sort_reserved(const int32_t* order, const int32_t* fill, int32_t* tile_counts, int32_t* void_words, int W, int H,
+                           int K_cap, void* keys, int32_t* ids, int32_t* tile_range, const float* rec, int32_t* slot_inv,
+                           int32_t* slot_pool, gfl_stream_t stream);
 
 /* ---- optional per-stage timing of the fused iteration ---------------------------
  * HIP events are recorded on the launch stream around the stages whose bit is set in

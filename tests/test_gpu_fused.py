@@ -798,11 +798,13 @@ def test_overflowing_pair_lists_are_grown_and_the_skipped_iterations_run_again(s
         k = small.settle_overflow()
         if not k:
             break
-        assert k == 3
+        assert k == 3 or (grown >= 2 and 0 < k < 3)
         grown += 1
         for _ in range(k):
             small.iteration()
-    assert grown == 2 and small.K_cap == 4 * (K // 3) and small.pairs_grown == 2            # K/3 -> 2K/3 -> 4K/3
+    # K/3 -> 2K/3 -> 4K/3 hold the lists; the tile regions the iterations after the first bin into (count + count / 4 + 32
+    # positions per tile, include/gflow_hip.h) need one doubling more
+    assert grown == small.pairs_grown and grown in (2, 3) and small.K_cap == (K // 3) << grown
     for _ in range(3):
         big.iteration()
     torch.cuda.synchronize()
@@ -820,4 +822,113 @@ def test_overflowing_pair_lists_are_grown_and_the_skipped_iterations_run_again(s
     small2.reset_optimizer()
     small2.iteration(); small2.iteration()
     torch.cuda.synchronize()
-    assert torch.equal(small2.pose.cpu(), POSE) and int(small2.step.item()) == 0 and small2.overflow.tolist() == [1, 2]
+    assert torch.equal(small2.pose.cpu(), POSE) and int(small2.step.item()) == 0 and small2.overflow[:2].tolist() == [1, 2]
+
+
+# ---------------------------------------------------------------------------------------- reserved tile regions
+def _lists(eng):
+    """the sorted id list of every tile (the lists' positions in ``ids`` differ between the two binning paths)"""
+    tr = eng.tile_range.cpu()
+    ids = eng.ids.cpu()
+    return [ids[int(a):int(b)] for a, b in tr.tolist()]
+
+
+def _reserved_on(eng):
+    import ctypes
+    return eng.lib.gfl_fit_reserved_supported(ctypes.byref(eng.state()), ctypes.byref(eng.hp)) == 1
+
+
+@pytest.mark.parametrize("with_scale_term", [False, True])
+def test_reserved_tile_regions_give_the_lists_of_the_exact_binning_path(setup, with_scale_term):
+    """An iteration that follows a full iteration bins into the tile regions that one's last launch reserved (one launch in
+    place of preprocess + column scan + scatter).  Held against the exact path on the SAME rows: records, every tile's sorted
+    list, the render and the transmittance bit for bit; the stepped rows to the order of the backward's LDS adds."""
+    s, raw, img, dep = setup
+    hyper = dict(lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0, lr=4e-3, lr_camera=0.0, total_iters=100)
+    if with_scale_term:
+        hyper["lambda_scale"] = 0.5
+    a = _engine(raw, s, img, dep, pose=POSE, **hyper)
+    b = _engine(raw, s, img, dep, pose=POSE, **hyper)
+    if not _reserved_on(a):
+        pytest.skip("reserved tile regions are switched off (GFL_RESERVED=0 / GFL_NEXT_PRE=1)")
+    if with_scale_term:
+        flags = (torch.arange(a.cap, device=DEV) % 3).to(torch.uint8)
+        for e in (a, b):
+            e.set_regularisers(row_flags=flags)
+    a.iteration()                                    # exact (nothing reserved yet); its last launch reserves
+    assert a._reserved_flag() == a.GFL_ITER_RESERVED
+    _copy_engine_state(a, b)
+    b.iteration(reserved=False)                      # iteration 1 on the exact path
+    a.iteration()                                    # iteration 1 on the reserved regions
+    a.check_overflow(); b.check_overflow()
+    assert a.K == b.K > 0
+    assert torch.equal(a.rec[:a.N], b.rec[:b.N])
+    la, lb = _lists(a), _lists(b)
+    assert all(torch.equal(x, y) for x, y in zip(la, lb))
+    tr = a.tile_range.cpu()
+    live = tr[:, 1] > tr[:, 0]
+    assert bool((tr[live][1:, 0] >= tr[live][:-1, 1]).all())                 # regions in tile order, not overlapping
+    assert int((tr[:, 1] - tr[:, 0]).sum()) == a.K and int(tr[:, 1].max()) > a.K      # ... with gaps between them
+    assert torch.equal(a.render, b.render) and torch.equal(a.final_T, b.final_T) and torch.equal(a.n_contrib, b.n_contrib)
+    for name in ("params", "adam_m", "adam_v"):
+        x, y = getattr(a, name)[:a.N], getattr(b, name)[:b.N]
+        assert (x - y).abs().max().item() <= 1e-5 * max(1.0, y.abs().max().item()), name
+    assert int(a.step.item()) == int(b.step.item()) == 2
+    # ten more, inside graphs and several per call: the two fits stay together
+    for use_graph, count in ((False, 1), (True, 1), (True, 1), (True, 3), (True, 3), (False, 1)):
+        a.iteration(use_graph=use_graph, count=count)
+        for _ in range(count):
+            b.iteration(reserved=False)
+    a.check_overflow()
+    assert int(a.step.item()) == int(b.step.item()) == 12 and a.K == b.K
+    rel = ((a.params[:a.N] - b.params[:b.N]).norm() / b.params[:b.N].norm()).item()
+    assert rel < 1e-5, rel
+    assert (a.render - b.render).abs().max().item() < 1e-3
+
+
+def test_a_tile_that_outgrows_its_reserved_region_voids_that_iteration_only(setup):
+    """The regions are a prediction (count + count / 4 + 32 positions per tile).  Splats the host moves between two iterations
+    -- here: a third of them onto one spot -- make tiles outgrow theirs: that iteration is void (nothing is stepped, it is
+    counted), the regions reserved at its end are sized by what the tiles wanted, the next iteration is fine again, and
+    settle_overflow says how many iterations to run in addition."""
+    s, raw, img, dep = setup
+    hyper = dict(lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0, lr=2e-3, lr_camera=0.0, total_iters=50)
+    a = _engine(raw, s, img, dep, pose=POSE, **hyper)
+    b = _engine(raw, s, img, dep, pose=POSE, **hyper)
+    if not _reserved_on(a):
+        pytest.skip("reserved tile regions are switched off")
+    a.iteration(); b.iteration(reserved=False)
+    mid = torch.tensor([s["W"] / 2.0, s["H"] / 2.0], device=DEV)
+    centre = int((a.rec[:a.N, 0:2] - mid).norm(dim=1).argmin())
+    for e in (a, b):
+        e.params[0:e.N:3, 0:3] = e.params[centre, 0:3].clone()           # (in place: the engine does not know)
+    rows = a.params[:a.N].clone()
+    a.iteration()
+    torch.cuda.synchronize()
+    assert a.overflow[:3].tolist() == [0, 1, 1]                             # void, counted
+    assert torch.equal(a.params[:a.N], rows) and int(a.step.item()) == 1
+    a.check_overflow()                                                      # (not an error: nothing was lost)
+    a.iteration()
+    torch.cuda.synchronize()
+    assert a.overflow[:3].tolist() == [0, 1, 0] and int(a.step.item()) == 2
+    assert a.settle_overflow() == 1 and a.regions_outgrown == 1 and a.overflow.tolist() == [0, 0, 0, 0]
+    a.iteration()
+    b.iteration(reserved=False); b.iteration(reserved=False)
+    assert a.settle_overflow() == 0
+    assert int(a.step.item()) == int(b.step.item()) == 3 and a.K == b.K
+    assert all(torch.equal(x, y) for x, y in zip(_lists(a), _lists(b)))
+    rel = ((a.params[:a.N] - b.params[:b.N]).norm() / b.params[:b.N].norm()).item()
+    assert rel < 1e-5, rel
+
+
+def test_reserved_flag_without_reserved_regions_is_caught_on_the_device(setup):
+    import ctypes
+    from gflow_amd import _lib as L
+    s, raw, img, dep = setup
+    a = _engine(raw, s, img, dep, pose=POSE, lambda_rgb=1.0, lr=1e-3, lr_camera=0.0)
+    if not _reserved_on(a):
+        pytest.skip("reserved tile regions are switched off")
+    L.check(a.lib.gfl_fit_iterations(ctypes.byref(a.state()), ctypes.byref(a.hp), 1, a.GFL_ITER_RESERVED, L.stream()), "it")
+    with pytest.raises(RuntimeError, match="reserved"):
+        a.check_overflow()
+    assert int(a.step.item()) == 0
