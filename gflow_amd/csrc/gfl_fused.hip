@@ -341,10 +341,11 @@ __host__ __device__ __forceinline__ int region_cap(int c) { return c + (c >> 2) 
 template <bool EWA_MFMA>
 __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_bin_kernel(const float* __restrict__ params, PreArgs a,
                                                                          const uint8_t* __restrict__ row_flags, BinArgs b) {
-    extern __shared__ int32_t hist[];               // [T] counts, then cursors; [T] limits behind them
+    extern __shared__ int32_t hist[];               // [T] counts, then cursors; [T] limits behind them; 64 idle cursors
     const int T = a.gx * a.gy;
     int32_t* lim = hist + T;
     const int tid = threadIdx.x;
+    GFL_PHASE(1, 0);                                 // (the column scan's row of the phase trace: it does not run here)
     const int i = blockIdx.x * BIN_BLOCK + tid;
     float4 row_v[4] = {};
     unsigned own_flags = 0;
@@ -368,8 +369,10 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_bin_kernel(const f
         for (int c = tid; c < b.n_pull; c += BIN_BLOCK) b.pull_counters[c] = 0;
     for (int t = tid; t < T; t += BIN_BLOCK) hist[t] = 0;
     __syncthreads();
+    GFL_PHASE(1, 1);
     PreOut o = {0.f, 0.f, 0.f, 0.f, 0};
     preprocess_block<EWA_MFMA, false, true>(a, row_v, own_flags, i, hist, &o);      // (ends behind a barrier)
+    GFL_PHASE(1, 2);
     // ---- this block's part of every tile's region
     int got[PER_MAX], cnt[PER_MAX];
 #pragma unroll
@@ -393,7 +396,9 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_bin_kernel(const f
     //  THIS iteration only -- overflow[3], which the tile sort's launch moves to overflow[2] where the update launches look)
     if (over_cap) *a.overflow = 1;
     else if (over) a.overflow[3] = 1;
+    GFL_PHASE(1, 3);
     __syncthreads();
+    GFL_PHASE(1, 4);
     // ---- keys (the scatter launch's walk, with the cursors above)
     const float u = o.u, v = o.v, cutoff = o.cutoff, depth = o.depth;
     int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
@@ -401,15 +406,33 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_bin_kernel(const f
     const int gx = a.gx, nx = x1 - x0, nt = nx * (y1 - y0);
     const bool wide = nt > WIDE_TILES;
     if (nt > 0 && !wide) {
+        // Four tiles per trip: the cursor's LDS add returns the key's position, and a lane that waits for one add per trip
+        // spends the walk waiting (4.3 us of the launch's 17, tools/phase_trace.py; two waves per SIMD hide nothing).  Lanes
+        // without a hit add to a cursor of their own behind the limits, so that the four adds are straight-line code.
         const unsigned long long key = ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned long long)(unsigned)i;
-        for (int ty = y0; ty < y1; ++ty)
-            for (int tx = x0; tx < x1; ++tx) {
-                if (!tile_hit2(u, v, cutoff, tx, ty)) continue;
-                const int t = ty * gx + tx;
-                const int pos = atomicAdd(&hist[t], 1);
-                if (pos < lim[t]) __hip_atomic_store(&b.keys[pos], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int dummy = 2 * T + (tid & 63);
+        int cx = 0, cy = 0;
+        for (int q0 = 0; q0 < nt; q0 += 4) {
+            int t4[4];
+            bool h4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int tx = x0 + cx, ty = y0 + cy;
+                h4[e] = q0 + e < nt && tile_hit2(u, v, cutoff, tx, ty);
+                t4[e] = ty * gx + tx;
+                if (++cx == nx) { cx = 0; ++cy; }
             }
+            int pos4[4], lim4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pos4[e] = atomicAdd(&hist[h4[e] ? t4[e] : dummy], 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lim4[e] = lim[h4[e] ? t4[e] : 0];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (h4[e] && pos4[e] < lim4[e]) __hip_atomic_store(&b.keys[pos4[e]], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
+    GFL_PHASE(1, 5);
     const int lane = tid & 63;
     unsigned long long todo = __ballot(wide);
     while (todo) {
@@ -427,6 +450,7 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_bin_kernel(const f
             if (pos < lim[t]) __hip_atomic_store(&b.keys[pos], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    GFL_PHASE(1, 6);
 }
 
 // Columns of hist -> exclusive per-block bases (in place) and per-tile totals.
@@ -2952,7 +2976,7 @@ static bool next_pre_enabled();
 // in the per-splat launch (the region workgroup is the third of them), not together with the "next preprocess" experiment.
 static bool fit_reserved_ok(const FitWs& w, int T) {
     return reserved_enabled() && !next_pre_enabled() && next_sched_ok(w, T) && T <= 4096 && sort_heavy_first() &&
-           2 * (size_t)T * sizeof(int32_t) <= 57 * 1024;
+           (2 * (size_t)T + 64) * sizeof(int32_t) <= 57 * 1024;
 }
 static NextSched next_sched_reserving(const gfl_fit_state* st, const FitWs& w, int rows, int T) {
     NextSched ns = next_sched(w, rows, T);
@@ -3036,7 +3060,7 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
             b.regions_valid = w.regions_valid; b.extent_next = w.extent_next; b.extent = w.extent;
             b.pull_counters = w.sched.counters; b.n_pull = 2 * w.sched.nq;
             auto kern = ewa_on_mfma() ? fused_preprocess_bin_kernel<true> : fused_preprocess_bin_kernel<false>;
-            kern<<<nblk, BIN_BLOCK, 2 * lds, s>>>(st->params, pre_args(st, hp, w, gx, gy, op_mode, parity), st->row_flags, b);
+            kern<<<nblk, BIN_BLOCK, 2 * lds + 64 * sizeof(int32_t), s>>>(st->params, pre_args(st, hp, w, gx, gy, op_mode, parity), st->row_flags, b);
         }
         {
             StageScope p(ST_TILE_SORT, s);

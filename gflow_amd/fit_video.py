@@ -196,7 +196,9 @@ def fit_clip_steps(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=
     if tr.engine is not None:
         tr.engine.check_overflow()
     return dict(psnr_sum=float(psnr_sum), frames=len(frames), iterations=tr.iterations_done,
-                rasterisations=tr.rasterisations_done, clips=1, splats_final=tr.current_pts_num())
+                rasterisations=tr.rasterisations_done, clips=1, splats_final=tr.current_pts_num(),
+                # iterations that stepped nothing because a tile outgrew its reserved region, and were made up for
+                void_iterations=getattr(tr.engine, "regions_outgrown", 0) if tr.engine is not None else 0)
 
 
 def fit_clips_concurrent(clips, device, cfg=None, seeds=None, snapshot_interval=0, chunk=32):

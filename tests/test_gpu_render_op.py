@@ -101,8 +101,10 @@ def test_two_forwards_before_their_backwards_and_empty_input():
     alone_b, _ = run(sb)
     nested_a, nested_b = run(sa, together_with=lambda: run(sb)[0])
     for k in NAMES:
-        assert torch.allclose(alone_a[k], nested_a[k], rtol=1e-4, atol=1e-7), k
-        assert torch.allclose(alone_b[k], nested_b[k], rtol=1e-4, atol=1e-7), k
+        # (two runs of the same backward differ by the order of its LDS adds: ~1e-8 of the largest entry, which is more than
+        #  1e-4 of an entry that is itself a difference of large terms -- the absolute floor follows the tensor's scale)
+        for x, y in ((alone_a[k], nested_a[k]), (alone_b[k], nested_b[k])):
+            assert torch.allclose(x, y, rtol=1e-4, atol=1e-6 * float(y.abs().max()) + 1e-7), k
     # N = 0
     e = {k: sa[k][:0] for k in NAMES}
     out = R.render(e, dict(intr=sa["intr"], extr=sa["extr"], W=96, H=80), 0.33)

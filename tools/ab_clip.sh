@@ -4,7 +4,7 @@
 VAR=$1; A=$2; B=$3; R=${4:-2}
 for r in $(seq 1 $R); do
   for v in $A $B; do
-    echo -n "$VAR=$v  "; env $VAR=$v python tools/clip_repeat.py 6 4 2>&1 | tail -1 | cut -c1-100
+    echo -n "$VAR=$v  "; env $VAR=$v python tools/clip_repeat.py 6 4 2>&1 | tail -1 | cut -c1-140
   done
 done
 for v in $A $B; do

@@ -21,4 +21,4 @@ for r in range(runs):
     walls.append(time.perf_counter() - t0)
 w = np.array(walls)
 print(f"{n_frames} frames, {m['iterations']} iterations: min {w.min():.4f} s ({n_frames / w.min():.2f} frames/s, "
-      f"{m['iterations'] / w.min():.0f} it/s)  median {np.median(w):.4f} s  all {np.round(w, 4)}")
+      f"{m['iterations'] / w.min():.0f} it/s)  median {np.median(w):.4f} s  void {m.get('void_iterations')}  all {np.round(w, 4)}")

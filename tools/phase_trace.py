@@ -40,7 +40,8 @@ assert fn(buf, 4 * NW * 8) == 0
 a = np.frombuffer(buf, dtype=np.int64).reshape(4, NW, 8)
 NAMES = {0: ("preprocess", ["start", "hist zeroed", "row arrived", "project+cov3d", "ewa+hist+stores", "wide walk",
                             "barrier", "hist row out"]),
-         1: ("colscan", ["start", "column sums", "barrier", "bases out"]),
+         1: ("preprocess + binning (reserved tile regions; the exact path's column scan: start, column sums, barrier, bases out)",
+             ["start", "hist zeroed", "preprocess", "regions reserved", "barrier", "narrow scatter", "wide walk"]),
          2: ("scatter", ["start", "tile scan", "cursor built", "barrier", "rec arrived", "narrow scatter", "wide walk"]),
          3: ("pre_bwd_adam", ["start", "rows arrived", "gather", "wide gather", "camera", "chain rule", "adam out", "reduced"])}
 for k, (name, labels) in NAMES.items():
