@@ -223,7 +223,12 @@ def reduce_and_report(local, dist, red_dev, rank, world, args, backend, size=Non
         "data": "synthetic",
         "config": {"workload": workload, "iterations_per_frame": ITERS_PER_FRAME, "splat_tile_pairs_K": K_mean,
                    "step_window": {"iterations": [STEP_I0, STEP_I0 + STEP_WINDOW], "K_first": local.get("K_first"),
-                                   "K_last": local.get("K_last"), "K_mean": local["K"]},
+                                   "K_last": local.get("K_last"), "K_mean": local["K"],
+                                   # the window's first iteration follows restore_state and bins on the exact path (three
+                                   # launches); the other 19 bin into the tile regions the iteration before reserved (one)
+                                   "binning": ("reserved tile regions in %d of %d iterations" % (STEP_WINDOW - 1, STEP_WINDOW))
+                                   if local.get("reserved_on") else "exact path",
+                                   "void_iterations": local.get("void_iterations")},
                    "parallelism": f"clip-sharded x{world}", "collective_backend": backend},
         "value_kind": "measured clip fit" if clip is not None else "derived from the step",
         "clip_fit": clip_out,
@@ -372,19 +377,27 @@ def main():
             stepper.run(k)
             done += k
 
-    run_window(max(args.warmup, 7))   # (at least 4 + 2 + 1 untimed steps: the replayed graphs hold one, two or four iterations)
-    eng.restore_state(saved)
-    # timed region: exactly K steps, no instrumentation (an event pair between two kernels
-    # opens a 5-10 us bubble on the stream, measured with rocprofv3)
+    # (at least one whole window, a restore and 4 + 2 + 1 steps untimed: the replayed graphs hold one, two or four iterations,
+    #  and the one that follows a restore starts on the exact binning path -- every variant is captured before the clock runs)
+    # The interpreter's collection comes BEFORE the warm-up steps, not between them and the clock: it takes tens of
+    # milliseconds, the device sat idle meanwhile, and the first launches of a 4 ms timed region then ran on clocks that had
+    # dropped (--steps 20: 0.208 ms per step against 0.196 at --steps 200, the same kernels).
     import gc
     gc.collect()
     gc.disable()          # (a generation-2 collection of the interpreter inside a 4 ms timed region is not the kernels' time)
+    run_window(max(args.warmup, STEP_WINDOW + 7))
+    eng.restore_state(saved)
+    # timed region: exactly K steps, no instrumentation (an event pair between two kernels
+    # opens a 5-10 us bubble on the stream, measured with rocprofv3)
     barrier()
+    void0 = int(eng.overflow[1].item())
     t0 = time.perf_counter()
     run_window(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    # iterations of the timed region that stepped nothing because a tile outgrew its reserved region (FitEngine.settle_overflow)
+    void_iterations = int(eng.overflow[1].item()) - void0
     # the same K steps again with HIP events recorded by the library on the launch stream
     # around every stage: per-kernel durations for the roofline block; and the window's pair counts K
     kern_all = {}
@@ -407,13 +420,15 @@ def main():
             k_dev[i:i + 1].copy_(eng.tile_offsets[eng.T:eng.T + 1])
     kern = {k: kern_all[k] for k in ("blend_fwd", "loss", "blend_bwd") if k in kern_all}
     eng.check_overflow()                   # (the stepper is driven directly here: no train() looks at the pair lists' flag)
+    reserved_on = bool(eng._reserved_flag())
     ks = k_dev[:min(args.steps, STEP_WINDOW)].cpu().tolist()
     K = sum(ks) / len(ks)                  # mean over the window's iterations: what the kernels' average durations belong to
     psnr_step = float(tr.psnr_of(stepper.last_render))
     del stepper, tr, eng, saved
 
     local = {"elapsed": elapsed, "steps": args.steps, "psnr_step": psnr_step, "K": K, "K_first": ks[0], "K_last": ks[-1],
-             "clip": clip, "clip_wall": clip_wall, "clip_wall_own": own_wall, "kernels_ms": kern, "stage_ms": kern_all}
+             "clip": clip, "clip_wall": clip_wall, "clip_wall_own": own_wall, "kernels_ms": kern, "stage_ms": kern_all,
+             "void_iterations": void_iterations, "reserved_on": reserved_on}
     out = reduce_and_report(local, dist, red_dev, rank, world, args, backend)
     if out is not None:
         if world == 1 and not args.no_clip and not args.no_coresident:

@@ -325,8 +325,9 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(const f
 // regions reserved at the end of the void iteration are sized by what the tiles WANTED, so the next iteration fits), and the
 // host runs one more iteration for each (FitEngine.settle_overflow).  Launches per iteration: 8 -> 6.
 struct BinArgs {
-    const int2* region;              // [T] {start, capacity}, written at the end of the iteration before
-    int32_t* fill;                   // [T] keys counted so far (zeroed with the regions)
+    const int4* region;              // [T] {start, capacity, position in the sort's order}, written at the end of the iteration before
+    int32_t* fill;                   // [T] keys counted so far, BY POSITION: the sort's workgroup reads its count beside its order
+                                     // entry instead of behind it (zeroed with the regions)
     unsigned long long* keys;
     int K_cap;
     int32_t* regions_valid;          // set with the regions, checked and cleared here
@@ -357,9 +358,9 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_bin_kernel(const f
     }
     // this lane's tiles' regions: requested here, used after the preprocess
     constexpr int PER_MAX = 8;                       // (T <= 4096: fit_reserved_ok)
-    int2 reg[PER_MAX];
+    int4 reg[PER_MAX];
 #pragma unroll
-    for (int k = 0; k < PER_MAX; ++k) reg[k] = tid + k * BIN_BLOCK < T ? b.region[tid + k * BIN_BLOCK] : make_int2(0, 0);
+    for (int k = 0; k < PER_MAX; ++k) reg[k] = tid + k * BIN_BLOCK < T ? b.region[tid + k * BIN_BLOCK] : make_int4(0, 0, 0, 0);
     if (blockIdx.x == 0 && tid == 0) {
         if (*b.regions_valid == 0) *a.overflow = 2;      // the host asked for regions nobody has reserved
         *b.regions_valid = 0;
@@ -379,7 +380,7 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_bin_kernel(const f
     for (int k = 0; k < PER_MAX; ++k) {
         const int t = tid + k * BIN_BLOCK;
         cnt[k] = t < T ? hist[t] : 0;
-        got[k] = cnt[k] > 0 ? atomicAdd(&b.fill[t], cnt[k]) : 0;
+        got[k] = cnt[k] > 0 ? atomicAdd(&b.fill[reg[k].z], cnt[k]) : 0;
     }
     bool over = false, over_cap = false;
 #pragma unroll
@@ -534,9 +535,9 @@ __device__ __forceinline__ bool sched_xcd_usable(const Sched& sc, int T, int blo
 // (list lengths -> offsets, heavy flags -> ranks).  {tile, start, end} per position: the sort reads ONE 16-byte item.
 // RESERVE (reserved tile regions, fused_preprocess_bin_kernel): the same walk at the END of an iteration, for the NEXT one --
 // every tile gets region_cap(count) positions instead of count, {tile, start, capacity, split} per position and
-// region[tile] = {start, capacity} for the binning launch; the fill counters are zeroed; *extent_next = one past the last
+// region[tile] = {start, capacity, position} for the binning launch; the fill counters are zeroed; *extent_next = one past the last
 // region (beyond K_cap: overflow = 1, the lists must grow), *total = the pairs of the iteration that ends here.
-struct ReserveOut { int2* region; int32_t* fill; int32_t* extent_next; int32_t* total; int32_t* overflow; int K_cap; };
+struct ReserveOut { int4* region; int32_t* fill; int32_t* extent_next; int32_t* total; int32_t* overflow; int K_cap; };
 
 template <int BLOCK, bool RESERVE>
 __device__ void build_sort_order(const int32_t* __restrict__ tile_counts, int T, int4* __restrict__ sort_order,
@@ -661,7 +662,7 @@ __device__ void build_sort_order(const int32_t* __restrict__ tile_counts, int T,
             }
             const int size = RESERVE ? region_cap(cnt[k]) : cnt[k];
             sort_order[pos] = make_int4(t, run, RESERVE ? size : run + cnt[k], w);
-            if (RESERVE) ro.region[t] = make_int2(run, size);
+            if (RESERVE) ro.region[t] = make_int4(run, size, pos, 0);
             H += heavy ? 1 : 0;
             run += size;
         }
@@ -2834,7 +2835,7 @@ size_t gfl_fit_workspace_bytes(int cap, int K_cap, int W, int H) {
            + up256((size_t)K_cap * sizeof(int32_t))                                    // second slot pool   } iterations take
            + up256((size_t)fit_nblk(cap > 0 ? cap : 1) * sizeof(int32_t))              // second scale rows  } turns ("next preprocess")
            + up256((T * 4 + SORT_ORDER_TRAILER) * sizeof(int32_t))                     // reserved tile regions: the next sort order,
-           + up256(T * sizeof(int2)) + up256(T * sizeof(int32_t));                      //   {start, capacity} per tile, fill counters
+           + up256(T * sizeof(int4)) + up256(T * sizeof(int32_t));                      //   {start, capacity, position} per tile, fill counters
 }
 
 struct FitWs {
@@ -2860,8 +2861,8 @@ struct FitWs {
     int4* sort_order;        // [T] {tile, start, end, 0}: the order the tile sort takes the tiles in (fused_scatter_kernel)
     // reserved tile regions (fused_preprocess_bin_kernel): written at the end of an iteration for the next one
     int4* sort_order_next;   // [T] {tile, start, capacity, split} + trailer
-    int2* region;            // [T] {start, capacity}
-    int32_t* fill;           // [T] keys binned so far
+    int4* region;            // [T] {start, capacity, position in sort_order_next}
+    int32_t* fill;           // [T] keys binned so far, by position
     int32_t* regions_valid;  // != 0: the three arrays above are those of the coming iteration
     int32_t* extent;         // one past the last list position of the last forward (exact path: the number of pairs)
     int32_t* extent_next;    // ... of the regions
@@ -2929,8 +2930,8 @@ static FitWs carve(const gfl_fit_state* st) {
     w.slot_pool2 = (int32_t*)((char*)w.sort_order + up256((T * 4 + SORT_ORDER_TRAILER) * sizeof(int32_t)));
     w.scale_cnt2 = (int32_t*)((char*)w.slot_pool2 + up256((size_t)st->K_cap * sizeof(int32_t)));
     w.sort_order_next = (int4*)((char*)w.scale_cnt2 + up256((size_t)fit_nblk(st->cap > 0 ? st->cap : 1) * sizeof(int32_t)));
-    w.region = (int2*)((char*)w.sort_order_next + up256((T * 4 + SORT_ORDER_TRAILER) * sizeof(int32_t)));
-    w.fill = (int32_t*)((char*)w.region + up256(T * sizeof(int2)));
+    w.region = (int4*)((char*)w.sort_order_next + up256((T * 4 + SORT_ORDER_TRAILER) * sizeof(int32_t)));
+    w.fill = (int32_t*)((char*)w.region + up256(T * sizeof(int4)));
     return w;
 }
 

@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(SORT_THREADS, 8) bin_tile_sort_kernel(const in
     // workgroups to dispatch.)
     // `fill` (reserved tile regions, gfl_fused.hip): the order was written at the END of the iteration before, with every
     // tile's region {start, capacity} in place of {start, end}; the list's length is what the binning launch counted into
-    // fill[tile] (capped: what did not fit was not written, and the iteration steps nothing).  counts_out[tile] = what the
+    // fill[position] (capped: what did not fit was not written, and the iteration steps nothing).  counts_out[tile] = what the
     // tile wanted (the next regions are sized by it).  void_words: {this iteration is void, a tile outgrew its region}: the
     // binning launch sets the second, this launch moves it into the first, where the update launches look -- a word nobody
     // writes while they run.
@@ -234,12 +234,13 @@ __global__ void __launch_bounds__(SORT_THREADS, 8) bin_tile_sort_kernel(const in
     } else {
         lb = xcd_logical_block((int)blockIdx.x, (int)gridDim.x);
     }
-    int tile = lb, start, end;
+    int tile = lb, start, end, wanted = 0;
     if (order) {
+        wanted = fill ? fill[lb] : 0;                // (by position: requested beside the order entry, not behind it)
         const int4 it = order[lb];
         tile = it.x;
         start = min(it.y, K_cap);
-        end = min(fill ? it.y + min(fill[tile], it.z) : it.z, K_cap);
+        end = min(fill ? it.y + min(wanted, it.z) : it.z, K_cap);
         flagged = it.w != 0;
     } else {
         start = min(offsets[tile], K_cap);
@@ -252,7 +253,7 @@ __global__ void __launch_bounds__(SORT_THREADS, 8) bin_tile_sort_kernel(const in
     if (threadIdx.x == 0 && half == 0) {
         tile_range[2 * tile] = n > 0 ? start : 0;
         tile_range[2 * tile + 1] = n > 0 ? end : 0;
-        if (counts_out) counts_out[tile] = fill ? fill[tile] : max(n, 0);
+        if (counts_out) counts_out[tile] = fill ? wanted : max(n, 0);
     }
     if (n <= 0) return;
     unsigned long long* seg = keys + start;

@@ -409,7 +409,8 @@ int gfl_tile_sort_with_slots(const int32_t* tile_offsets, int W, int H, int K_ca
 int gfl_tile_sort_ordered(const int32_t* order, int W, int H, int K_cap, void* keys, int32_t* ids, int32_t* tile_range,
                           const float* rec, int32_t* slot_inv, int32_t* slot_pool, gfl_stream_t stream);
 /* same for reserved tile regions: order[T][4] = {tile, start, capacity, split}; the list of `tile` is the first
- * min(fill[tile], capacity) keys behind `start` (fill[T]: what the binning launch counted); tile_counts[tile] = fill[tile];
+ * min(fill[position], capacity) keys behind `start` (fill[T]: what the binning launch counted, by position in the order);
+ * tile_counts[tile] = fill[position];
  * void_words (may be NULL): void_words[0] = void_words[1], void_words[1] = 0 (gfl_fit_state.overflow + 2). */
 int gfl_tile_sort_reserved(const int32_t* order, const int32_t* fill, int32_t* tile_counts, int32_t* void_words, int W, int H,
                            int K_cap, void* keys, int32_t* ids, int32_t* tile_range, const float* rec, int32_t* slot_inv,

@@ -18,6 +18,10 @@ from collections import defaultdict
 
 STAGE_OF = {                       # kernel -> bench.py stage name
     "fused_preprocess_fwd_kernel": "preprocess", "bin_colscan_kernel": "colscan",
+    # reserved tile regions: ONE launch in place of the three above in every iteration that follows a full iteration (19 of
+    # the window's 20: the first after restore_state takes the exact path, so the "last 40 launches" of the three exact-path
+    # kernels reach back in front of the window)
+    "fused_preprocess_bin_kernel": "preprocess_bin",
     "fused_scatter_kernel": "scatter", "bin_tile_sort_kernel": "tile_sort",
     "fused_blend_fwd_kernel": "blend_fwd", "ssim_stats_kernel": "loss", "loss_grad_kernel": "loss",
     "fused_blend_bwd_kernel": "blend_bwd", "fused_preprocess_bwd_adam_kernel": "pre_bwd_adam",
