@@ -198,7 +198,10 @@ def reduce_and_report(local, dist, red_dev, rank, world, args, backend, size=Non
                     "splats_final_mean": float(stats[8].item()) / max(float(stats[9].item()), 1.0),
                     "snapshot_interval": args.snapshot_interval,
                     "clips_per_rank": int(round(float(stats[9].item()) / world)),
-                    "rank_wall_s": [float(v) for v in stats[10:10 + world].tolist()]}
+                    "rank_wall_s": [float(v) for v in stats[10:10 + world].tolist()],
+                    # rank 0's clips: iterations that stepped nothing because a tile outgrew its reserved region, and were
+                    # made up for (they are inside wall_s; `iterations` counts the ones that stepped)
+                    "void_iterations": (clip or {}).get("void_iterations")}
         workload += (f"; value = measured fit_video fit of one {args.clip_frames}-frame rigid synthetic clip per GPU "
                      f"(configs[2]: iterations 500 first / 150 camera-only + 300 joint per later frame, densification "
                      f"on, snapshots every {args.snapshot_interval} iterations); ms_per_step = iterations "

@@ -40,11 +40,12 @@ torch.cuda.synchronize()
 eng = tr.engine
 W, H, gx = eng.W, eng.H, (eng.W + 15) // 16
 rng = eng.tile_range.long()
-K = int(rng[:, 1].max())
-ids = eng.ids[:K].long()
-tile_of = torch.repeat_interleave(torch.arange(eng.T, device=dev), (rng[:, 1] - rng[:, 0]))
-assert tile_of.numel() == K
-pos = torch.arange(K, device=dev) - rng[tile_of, 0]
+# (the lists have gaps between them when the iteration binned into reserved tile regions: gathered by tile range)
+lens = rng[:, 1] - rng[:, 0]
+K = int(lens.sum())
+tile_of = torch.repeat_interleave(torch.arange(eng.T, device=dev), lens)
+pos = torch.arange(K, device=dev) - torch.repeat_interleave(torch.cumsum(lens, 0) - lens, lens)
+ids = eng.ids[rng[tile_of, 0] + pos].long()
 rec = eng.rec[ids]                                                   # [K, 12]
 u, v, A, B, C, o, cutoff = rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3], rec[:, 4], rec[:, 5], rec[:, 10]
 tx, ty = (tile_of % gx) * 16, (tile_of // gx) * 16
