@@ -79,28 +79,33 @@ def test_fullsize_fused_iteration_matches_oracle(which):
     loss, info = FO.fit_loss(rc, pose, ab, raw["intr"], dict(image=frame["image"], depth=frame["depth"]), 0.0,
                              lam["lambda_rgb"], lam["lambda_depth"], lam["lambda_var"])
     loss.backward()
-    # observed (round 3, gpurun_out/observed_parity.log): 1-2e-5 of the pixels off the 1e-4 tolerance, largest error 1.5e-3 /
-    # 2.3e-3 (threshold flips of single splats at single pixels), 99.99th percentile 9e-6
-    close_frac(eng.render, info["render4"], 1e-4, 1e-5, bad_frac=1e-4, hard=1e-2, what=f"{which}: render vs oracle")
+    # observed (round 4, gpurun_out/observed_parity.log): NO pixel off the 1e-4 tolerance, largest error 1.1e-5 / 1.7e-6,
+    # 99.99th percentile 1.2e-6 -- since the forward geometry is compiled without fused multiply-adds (the oracle's
+    # arithmetic; rounds 1-3: 1-2e-5 of the pixels off, largest error 1.5e-3 / 2.3e-3, threshold flips of single splats at
+    # single pixels, and bounds of 1e-4 of the pixels / 1e-2)
+    close_frac(eng.render, info["render4"], 1e-4, 1e-5, bad_frac=1e-5, hard=1e-3, what=f"{which}: render vs oracle")
     assert eng.K <= info["K"]                                   # exact-disc culling only ever drops pairs
     l_rgb, l_depth = eng.loss_terms()
-    assert abs(l_rgb.item() - info["l_rgb"].item()) <= 1e-4 * abs(info["l_rgb"].item())
-    assert abs(l_depth.item() - info["l_depth"].item()) <= 1e-4 * abs(info["l_depth"].item())
+    assert abs(l_rgb.item() - info["l_rgb"].item()) <= 5e-5 * abs(info["l_rgb"].item())          # (observed: 9e-6)
+    assert abs(l_depth.item() - info["l_depth"].item()) <= 5e-5 * abs(info["l_depth"].item())    # (observed: 2e-7)
     g_all = (eng.adam_m[:n] / 0.1).cpu()
     for k, (a, b) in COLS.items():
         ref = rc[k].grad.reshape(n, b - a)
         rel = ((g_all[:, a:b] - ref).norm() / ref.norm()).item()
-        assert rel < 2e-3, f"{which}: d_{k} relative L2 error {rel:.2e}"
+        # (observed, round 4: 1.3e-5 .. 2.8e-5 for the five attributes on both scenes; the bound was 2e-3 while single
+        #  splats flipped the alpha threshold at single pixels)
+        assert rel < 2e-4, f"{which}: d_{k} relative L2 error {rel:.2e}"
     if which == "densified_scene":
         # the rows this scene is about: the pile and the wide splats
         for k, (a, b) in COLS.items():
             ref = rc[k].grad.reshape(n, b - a)[-1524:]
             rel = ((g_all[-1524:, a:b] - ref).norm() / ref.norm()).item()
-            assert rel < 3e-3, f"{which}: d_{k} of the pile / wide rows {rel:.2e}"
+            print(f"observed {which}: d_{k} of the pile / wide rows {rel:.2e}")
+            assert rel < 5e-4, f"{which}: d_{k} of the pile / wide rows {rel:.2e}"
     gp = (eng.pose_m / 0.1).cpu()
     rel = ((gp - pose.grad).norm() / pose.grad.norm()).item()
-    assert rel < 2e-3, f"{which}: d_pose {rel:.2e}"
-    np.testing.assert_allclose((eng.ab_m / 0.1).cpu().numpy(), ab.grad.numpy(), rtol=2e-3)
+    assert rel < 2e-4, f"{which}: d_pose {rel:.2e}"                     # (observed: 4e-6 .. 7e-6)
+    np.testing.assert_allclose((eng.ab_m / 0.1).cpu().numpy(), ab.grad.numpy(), rtol=5e-4)
 
 
 def test_config3_shape_eight_frame_clip_at_480p_60k():
