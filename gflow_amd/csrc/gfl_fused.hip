@@ -21,6 +21,10 @@
 //                 keys[tile_offsets[t] + base[b][t] + rank];
 //   tile sort   : per-tile bitonic sort of the unique 64-bit keys (gfl_bin.hip) ->
 //                 order is independent of the LDS-atomic arrival order.
+// That is the EXACT path: the first iteration on a set of splats.  Every iteration that follows a full iteration (round 4)
+// takes "reserved tile regions" instead -- preprocess, column scan and scatter in ONE launch, with one returning global
+// atomic per (block, tile): see fused_preprocess_bin_kernel below.  (The 258k atomics above were one per PAIR on counters
+// nobody had arranged; 118 blocks x 26 wave-level atomics on dense counters cost 2 us, tools/atomic_probe.hip.)
 #include "gfl_math.hpp"
 #include "gfl_profile.hpp"
 #include "gfl_sched.hpp"
