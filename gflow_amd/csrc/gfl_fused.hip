@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(const f
 // a dependency across the whole launch.  But the lists of iteration i + 1 are the lists of iteration i but for one Adam step:
 // at the END of iteration i one workgroup of the per-splat launch (build_sort_order<.., true>) gives every tile a REGION of
 // the key array sized by what the tile holds now plus a margin (region_cap), and the next iteration's blocks reserve their
-// part of it with one returning atomicAdd per (block, tile with keys): fill[t] += the block's count (dense 4-byte counters:
+// part of it with one returning atomicAdd per (block, tile with keys): fill[position] += the block's count (dense 4-byte counters:
 // 118 blocks x 1 620 tiles cost 2.1 us on top of the launch, tools/atomic_probe.hip; counters a cache line apart cost 7).
 // The order inside a region is whatever order the blocks arrived in -- the tile sort, which follows anyway, makes the lists
 // what the exact path's are (keys are unique: depth bits | splat id), so ids / tile ranges / everything downstream is
