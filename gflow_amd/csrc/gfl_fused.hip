@@ -3116,6 +3116,9 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
             // rebinds move_mask = move_gs_mask | move_mask inside its loop (trainer.py:451).  The caller
             // initialises keep = !move_mask (all zero for a non-black background, where every pixel of the
             // extra render is > 0).
+            // (Round 4: the footprint needs the sorted lists, not the render -- launched BESIDE the forward blend on a second
+            //  stream, forked and joined with events inside the captured graph, 4-frame clip fits took 0.455-0.456 s against
+            //  0.445-0.455 s with it behind the forward: like the snapshot before it, a fork inside a graph does not pay.)
             if (!st->keep) return GFL_ERR_INVALID;
             if (!(hp->bg > 0.f) && st->N > 0)
                 footprint_kernel<<<T, 256, 0, s>>>(st->rec, st->ids, st->tile_range, st->foot_flags, st->W, st->H, gx,
