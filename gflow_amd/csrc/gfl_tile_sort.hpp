@@ -63,7 +63,12 @@ __device__ __forceinline__ void exchange_in_wave(unsigned long long (&key)[E], i
     }
 }
 
-constexpr int SORT_THREADS = 512;
+// (round 4, -DGFL_SORT_THREADS=256 on the build with the pivot split: bench-window sort 15.6 against 16.1 us by events,
+//  4-frame clip fits 0.458 / 0.473 s against 0.452 / 0.459 s -- the halves of the piles' lists on four waves again)
+#ifndef GFL_SORT_THREADS
+#define GFL_SORT_THREADS 512
+#endif
+constexpr int SORT_THREADS = GFL_SORT_THREADS;
 constexpr int SORT_XB = 4;         // keys of a lane exchanged through LDS per pair of barriers (16 KB of LDS)
 
 
@@ -257,7 +262,7 @@ __global__ void __launch_bounds__(SORT_THREADS, 8) bin_tile_sort_kernel(const in
     }
     if (n <= 0) return;
     unsigned long long* seg = keys + start;
-    const bool split = flagged && n >= 64 && n <= 4 * SORT_THREADS;       // (both workgroups of a tile decide alike)
+    const bool split = flagged && n >= 64 && n <= 2048;       // (both workgroups of a tile decide alike)
     if (half == 1 && !split) return;
     if (split) {
         // ---- pivot: the median of 32 keys at fixed positions (keys are unique: ranks are)
@@ -277,7 +282,7 @@ __global__ void __launch_bounds__(SORT_THREADS, 8) bin_tile_sort_kernel(const in
         __syncthreads();
         const unsigned long long pivot = s_pivot;
         // ---- this half's keys, compacted into the exchange buffer (order does not matter: they are sorted next)
-        constexpr int EP = 4;                        // (n <= 4 x 512)
+        constexpr int EP = 2048 / SORT_THREADS;      // (n <= 2048)
         unsigned long long k4[EP];
         bool keep[EP];
         int mine_cnt = 0;
