@@ -85,3 +85,25 @@ def test_library_and_oracle_use_the_same_constants():
             MO.ALPHA_MAX, MO.T_MIN]
     for got, ref in zip(out, want):
         assert abs(got - ref) <= 1e-7 * max(1.0, abs(ref)), (list(out), want)
+
+
+def test_iteration_flags_of_the_host_side_are_the_headers():
+    """FitEngine passes GFL_ITER_RESERVED as a literal (the reserved tile regions of include/gflow_hip.h): it must be the
+    header's value, and the flags must be distinct bits."""
+    from gflow_amd.fused import FitEngine
+    hdr = open(os.path.join(ROOT, "include", "gflow_hip.h")).read()
+    flags = {m.group(1): int(m.group(2)) for m in re.finditer(r"^#define (GFL_ITER_[A-Z_]+) (\d+)$", hdr, flags=re.M)}
+    assert set(flags) == {"GFL_ITER_PRE_DONE", "GFL_ITER_PRE_NEXT", "GFL_ITER_ODD", "GFL_ITER_RESERVED"}
+    assert FitEngine.GFL_ITER_RESERVED == flags["GFL_ITER_RESERVED"]
+    bits = sorted(flags.values())
+    assert all(b & (b - 1) == 0 for b in bits) and len(set(bits)) == len(bits)
+
+
+def test_reserved_entry_points_reject_bad_arguments_without_a_gpu():
+    """gfl_tile_sort_reserved / gfl_fit_reserved_supported validate their arguments before anything is launched."""
+    import ctypes
+    from gflow_amd import _lib
+    lib = _lib.load()
+    null = ctypes.c_void_p(0)
+    assert lib.gfl_tile_sort_reserved(null, null, null, null, 64, 64, 16, null, null, null, null, null, null, null) != 0
+    assert lib.gfl_fit_reserved_supported(null, null) == 0
