@@ -932,3 +932,34 @@ def test_reserved_flag_without_reserved_regions_is_caught_on_the_device(setup):
     with pytest.raises(RuntimeError, match="reserved"):
         a.check_overflow()
     assert int(a.step.item()) == 0
+
+
+def test_reserved_tile_regions_on_a_720p_tile_grid():
+    """3 600 tiles: the binning launch holds up to eight tiles' regions per lane, the region workgroup sixteen counts per
+    lane (both sized for grids of up to 4 096 tiles); splats spread thin enough that most (block, tile) cells are empty."""
+    s = random_scene(6000, 1280, 720, seed=5, sigma_px=6.0, tilt=False)
+    raw = _raw_from_scene(s)
+    img, dep = _targets(s["H"], s["W"], 7)
+    hyper = dict(lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0, lr=2e-3, lr_camera=0.0, total_iters=100)
+    a = _engine(raw, s, img, dep, pose=POSE, **hyper)
+    b = _engine(raw, s, img, dep, pose=POSE, **hyper)
+    if not _reserved_on(a):
+        pytest.skip("reserved tile regions are switched off")
+    assert a.T == 80 * 45
+    a.iteration()
+    _copy_engine_state(a, b)
+    for _ in range(3):
+        a.iteration()
+        b.iteration(reserved=False)
+    a.check_overflow(); b.check_overflow()
+    assert a.overflow.tolist() == [0, 0, 0, 0]
+    assert a.K == b.K > 0 and int(a.step.item()) == int(b.step.item()) == 4
+    tr = a.tile_range.cpu()
+    assert int(tr[:, 1].max()) > a.K                                         # (regions: gaps between the lists)
+    rel = ((a.params[:a.N] - b.params[:b.N]).norm() / b.params[:b.N].norm()).item()
+    assert rel < 1e-5, rel
+    # the forward of the same rows: lists and render bit for bit
+    _copy_engine_state(a, b)
+    a.iteration(); b.iteration(reserved=False)
+    assert all(torch.equal(x, y) for x, y in zip(_lists(a), _lists(b)))
+    assert torch.equal(a.render, b.render) and torch.equal(a.rec[:a.N], b.rec[:b.N])
