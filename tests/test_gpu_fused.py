@@ -963,3 +963,31 @@ def test_reserved_tile_regions_on_a_720p_tile_grid():
     a.iteration(); b.iteration(reserved=False)
     assert all(torch.equal(x, y) for x, y in zip(_lists(a), _lists(b)))
     assert torch.equal(a.render, b.render) and torch.equal(a.rec[:a.N], b.rec[:b.N])
+
+
+def test_a_void_iteration_inside_a_four_iteration_graph(setup):
+    """The same inside one graph launch of four iterations: the first is void, the other three step, one is owed."""
+    s, raw, img, dep = setup
+    hyper = dict(lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0, lr=2e-3, lr_camera=0.0, total_iters=50)
+    a = _engine(raw, s, img, dep, pose=POSE, **hyper)
+    b = _engine(raw, s, img, dep, pose=POSE, **hyper)
+    if not _reserved_on(a):
+        pytest.skip("reserved tile regions are switched off")
+    a.iteration(); b.iteration(reserved=False)
+    a.iteration(use_graph=True, count=4); a.iteration(use_graph=True, count=4)        # (captured, replayed once)
+    for _ in range(8):
+        b.iteration(reserved=False)
+    mid = torch.tensor([s["W"] / 2.0, s["H"] / 2.0], device=DEV)
+    centre = int((a.rec[:a.N, 0:2] - mid).norm(dim=1).argmin())
+    for e in (a, b):
+        e.params[0:e.N:3, 0:3] = e.params[centre, 0:3].clone()
+    a.iteration(use_graph=True, count=4)
+    torch.cuda.synchronize()
+    assert a.overflow[:3].tolist() == [0, 1, 0] and int(a.step.item()) == 9 + 3
+    assert a.settle_overflow() == 1
+    a.iteration()
+    for _ in range(4):
+        b.iteration(reserved=False)
+    assert int(a.step.item()) == int(b.step.item()) == 13 and a.K == b.K
+    rel = ((a.params[:a.N] - b.params[:b.N]).norm() / b.params[:b.N].norm()).item()
+    assert rel < 1e-5, rel
