@@ -20,13 +20,14 @@ _lib = None
 
 c_void_p, c_int, c_float, c_size_t, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_int64
 
+MIN_VERSION = 300          # GFL_VERSION of the include/gflow_hip.h this binding mirrors (overflow[4], sort-order trailer)
+
 # name -> (restype, argtypes); mirrors include/gflow_hip.h one to one
 _P = c_void_p
 SIGNATURES = {
     "gfl_version": (c_int, []),
     "gfl_constants": (c_int, [_P]),
     "gfl_ewa_on_mfma": (c_int, []),
-    "gfl_bwd_rows_on": (c_int, []),
     "gfl_status_string": (ctypes.c_char_p, [c_int]),
     "gfl_last_hip_error": (c_int, []),
     "gfl_reduce_workspace_bytes": (c_size_t, [c_int]),
@@ -61,7 +62,6 @@ SIGNATURES = {
     "gfl_fit_backward_step": (c_int, [_P, _P, _P]),
     "gfl_fit_iteration": (c_int, [_P, _P, _P]),
     "gfl_fit_iterations": (c_int, [_P, _P, c_int, c_int, _P]),
-    "gfl_fit_next_preprocess_supported": (c_int, [_P, _P]),
     "gfl_fit_reserved_supported": (c_int, [_P, _P]),
     "gfl_fit_snapshot_stage": (c_int, [_P, _P, _P]),
     "gfl_fit_snapshot_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -105,6 +105,9 @@ def load():
             fn = getattr(lib, name)          # AttributeError if the ABI drifted
             fn.restype = res
             fn.argtypes = args
+        if lib.gfl_version() < MIN_VERSION:
+            raise RuntimeError(f"{LIB_PATH} is version {lib.gfl_version()}, this binding needs >= {MIN_VERSION}: rebuild it "
+                               "(make -C gflow_amd/csrc)")
         _lib = lib
         return lib
 

@@ -163,7 +163,7 @@ using namespace gfl;
 
 extern "C" {
 
-int gfl_version(void) { return 200; }
+int gfl_version(void) { return GFL_VERSION; }
 
 int gfl_constants(float* out10) {
     if (!out10) return GFL_ERR_INVALID;

@@ -51,8 +51,6 @@ struct Sched {
     int cap_q;           // capacity of one queue
     int split_min;       // forward schedule: a first tile with a longer list is walked on four CUs; 0: never
     int xcd;             // 1: XCD-local bands + snake deal (schedule_tiles_xcd) instead of the batched LPT
-    int rotate;          // backward schedule: the segments of a queue's first tile (four or more of them) turn the block plan by
-                         // one SIMD each, so the tile's blocks count a quarter of its weight on every SIMD (see the kernel)
 };
 
 __host__ __device__ inline int sched_queue_capacity(int T, int nq) { return 2 * ((T + nq - 1) / nq) + 8; }
@@ -472,12 +470,7 @@ __device__ void schedule_tiles_xcd(const int32_t* __restrict__ tile_counts, int 
                 const int prio = k > 0 ? 0 : (wt * 5 >= target * 2 ? 3 : (wt * 4 >= target ? 2 : 1));
                 unsigned plan = ITEM_PLAN_IDENTITY;
                 if (frac4 && tile < SCHED_PLAN_TILES) {
-                    uint32_t fr = frac4[tile];
-                    // A first tile that the backward pass walks as four or more segments side by side: segment p turns the
-                    // plan by p SIMDs, so every SIMD sees every block in turn.  (One pile in one 8x8 block -- [57 0 153 0]
-                    // units per segment, eight segments -- otherwise puts 1 200 units on ONE SIMD of a CU whose fair share
-                    // per SIMD is 380; tools/bwd_trace.py --fit: CU end = 0.12 x its busiest SIMD's units + 13 us, r = 0.81.)
-                    if (sc.rotate && k == 0 && sc.first_slot && heavy_parts(tile_counts[tile]) >= 4) fr = 0x40404040u;
+                    const uint32_t fr = frac4[tile];
                     const int bw[4] = {(int)(fr & 255u) * wt, (int)((fr >> 8) & 255u) * wt, (int)((fr >> 16) & 255u) * wt,
                                        (int)(fr >> 24) * wt};
                     plan = plan_blocks(bw, key);
@@ -514,7 +507,6 @@ struct TileQueue {
     int32_t* counter;    // [nq] for this launch
     int nq;
     int cap_q;
-    int rotate;          // Sched.rotate of the schedule these queues come from
 };
 
 // Item of a queue.  part: -1 = the whole tile; 0 .. HEAVY_PARTS-1 = that segment of the queue's

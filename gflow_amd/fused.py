@@ -55,8 +55,6 @@ def _declare(lib):
         fn.argtypes = [ctypes.POINTER(FitState), ctypes.POINTER(FitHyper), _P]
     lib.gfl_fit_iterations.restype = ctypes.c_int
     lib.gfl_fit_iterations.argtypes = [ctypes.POINTER(FitState), ctypes.POINTER(FitHyper), ctypes.c_int, ctypes.c_int, _P]
-    lib.gfl_fit_next_preprocess_supported.restype = ctypes.c_int
-    lib.gfl_fit_next_preprocess_supported.argtypes = [ctypes.POINTER(FitState), ctypes.POINTER(FitHyper)]
     lib.gfl_fit_snapshot.restype = ctypes.c_int
     lib.gfl_fit_snapshot.argtypes = [ctypes.POINTER(FitState), ctypes.POINTER(FitHyper), _P, _P, _P, ctypes.c_size_t, _P]
     lib.gfl_render_bwd.restype = ctypes.c_int
@@ -190,6 +188,14 @@ class FitEngine:
         self.N = int(n)
         if self._state is not None:
             self._state.N = self.N
+        self._reserved_N = -1
+
+    def invalidate_regions(self):
+        """The host has written pose, intrinsics or parameter rows (through ``views()``, ``pose.copy_`` ...) since the last
+        iteration: the tile regions that iteration reserved describe other splats.  Not WRONG to use them -- a tile that
+        outgrows its region voids the iteration and it is run again -- but a wasted iteration, predictably at the first
+        iteration of every frame and stage; the next iteration bins on the exact path instead."""
+        self._reserved_N = -1
 
     def set_splats(self, attrs):
         """attrs: dict xyz (N,3), scale (N,3), rotate (N,4), opacity (N,1), rgb (N,3) RAW values.
@@ -369,8 +375,6 @@ class FitEngine:
                         with torch.cuda.stream(side):
                             g.capture_begin(capture_error_mode="thread_local")
                             try:
-                                # (several iterations in one call: between two plain ones the next preprocess runs in
-                                #  the tail of the per-splat launch, include/gflow_hip.h)
                                 L.check(self.lib.gfl_fit_iterations(ctypes.byref(st), ctypes.byref(hp), count, reserved,
                                                                     L.stream()), "fit iterations (capture)")
                                 if snapshot:

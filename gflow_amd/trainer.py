@@ -215,6 +215,7 @@ class SimpleGaussian:
         the way the reference does (slower, same results)."""
         self.fused = bool(fused)
         self.async_snapshots = True      # snapshots composed on a side stream from a copy of the forward's state (make_stepper)
+        self.exact_snapshots = True      # iterations whose forward is looked at are never void or behind (make_stepper: one_iteration)
         self.use_graph = True          # replay the fused iteration as a hipGraph when nothing else happens in it
         self.engine = None
         self.device = torch.device(device if device is not None else "cuda")
@@ -578,6 +579,7 @@ class SimpleGaussian:
         self.lr, self.lr_camera = lr, lr_camera
         eng = self._pack_to_engine()
         eng.pose.copy_(self.pose.detach())
+        eng.invalidate_regions()                   # (new pose, new frame's warp of the moving splats: the first iteration bins exactly)
         self.pose = eng.pose                       # live: get_extr() follows the optimised pose
         eng.depth_ab.zero_()                                         # trainer.py:145-146: (a, b) = (1, 0) on every train()
         eng.depth_ab[0:1].fill_(1.0)                                 # (fills, not torch.tensor(..., device=): that copy blocks)
@@ -639,17 +641,19 @@ class SimpleGaussian:
             eng.set_footprint_mask(move_mask if move_mask is not None else torch.zeros(H, W, dtype=torch.bool),
                                    ~self.still_mask_tentative)
 
-        def settle():
-            """The pair lists overflowed since the last look?  Then the library has stepped nothing since (the iterations
-            ran, their updates were skipped): grow the lists and run those iterations again -- plain ones: what a snapshot
-            taken meanwhile shows is not repeated.  Blocking; called where the host stops anyway (before a densification
-            reads the error map) and at the end of the call."""
+        def settle(last=None):
+            """Iterations that stepped NOTHING since the last look (the pair lists overflowed: they are grown first; or a tile
+            outgrew its reserved region: that one iteration was void) are run again, so that the fit is where one that never
+            skipped an update is.  ``last``: what to run as the LAST of them instead of a plain iteration (an iteration
+            whose forward the host looks at is taken again: one_iteration).  One blocking read of two words."""
             while True:
                 k = eng.settle_overflow()
                 if not k:
                     return
-                for _ in range(k):
+                for _ in range(k - 1 if last else k):
                     eng.iteration(use_graph=False)
+                if last:
+                    last()
 
         st.settle = settle
 
@@ -657,6 +661,16 @@ class SimpleGaussian:
             iteration = st.iteration
             n_rendered = eng.N                       # rows this iteration projects (densification appends afterwards)
             snap = bool(snapshot_interval) and iteration % snapshot_interval == 0
+            # Somebody LOOKS at this iteration's forward (snapshot, log entry, the error map of a densification).  An iteration
+            # can step nothing (settle, above) -- and its forward is then a render of truncated lists, and the ones before
+            # it may be waiting to be made up for, i.e. the splats are k optimiser steps behind the reference's at this
+            # index.  So such an iteration (a) bins on the exact path, where no tile can outgrow a region, and (b) is
+            # followed by ONE look at the two words: if k iterations have to be made up for (5 in the 27 050 of a 60-frame
+            # clip, all in the first steps of the first frame), k - 1 plain ones run and then this one AGAIN -- snapshot
+            # slot, loss sums and error map are overwritten by the forward of the splats after exactly ``iteration`` steps,
+            # as in the reference (trainer.py:573-582).  The look stops the host, not the device: the snapshot's side
+            # stream (or the other clips on the device) has ~130 us of composites to run meanwhile.
+            looked_at = not is_plain(iteration)
             if tentative:
                 self.rasterisations_done += 1                # the reference's extra render of the moving set
             if snap:
@@ -692,18 +706,24 @@ class SimpleGaussian:
                 st.frames.append(st.pin[k, 0])
                 st.frames_depth.append(st.pin[k, 1])
                 st.frames_center.append(st.pin[k, 2])
-            if snap and not self.async_snapshots:
-                # (several fits sharing the device -- fit_clips_concurrent -- already fill each other's gaps, and a side
-                #  stream and a shadow engine per clip cost them more than they give: 12.7 -> 10.9 frames/s with two clips.
-                #  There the snapshot stays behind the iteration, in the same graph launch; an elementwise kernel moves it
-                #  into the ring: ``copy_`` goes through the runtime's blit kernel, 47 us for these 3.7 MB)
-                imgs = eng.iteration(use_graph=self.use_graph, snapshot=True)
-                torch.bitwise_or(imgs, 0, out=st.ring[k])
-            else:
-                eng.iteration(use_graph=self.use_graph)      # one call (or one hipGraph replay)
-                if snap:
-                    self._snapshot_async(st.ring[k], n_rendered)
-                    st.snap_stream = self._snap_stream
+            def launch():
+                if snap and not self.async_snapshots:
+                    # (several fits sharing the device -- fit_clips_concurrent -- already fill each other's gaps, and a side
+                    #  stream and a shadow engine per clip cost them more than they give: 12.7 -> 10.9 frames/s with two clips.
+                    #  There the snapshot stays behind the iteration, in the same graph launch; an elementwise kernel moves it
+                    #  into the ring: ``copy_`` goes through the runtime's blit kernel, 47 us for these 3.7 MB)
+                    imgs = eng.iteration(use_graph=self.use_graph, snapshot=True, reserved=False)
+                    torch.bitwise_or(imgs, 0, out=st.ring[k])
+                else:
+                    # one call (or one hipGraph replay)
+                    eng.iteration(use_graph=self.use_graph, reserved=None if not looked_at else False)
+                    if snap:
+                        self._snapshot_async(st.ring[k], n_rendered)
+                        st.snap_stream = self._snap_stream
+
+            launch()
+            if looked_at and self.exact_snapshots:
+                settle(last=launch)
             self.rasterisations_done += 1
             self.iterations_done += 1
             rec_now = eng.rec                        # (densification may re-allocate the engine's buffers below)
@@ -719,9 +739,9 @@ class SimpleGaussian:
 
             # ---- densification (trainer.py:560-571)
             densified = False
-            if (not camera_only and densify_interval and (iteration + 1) % densify_interval == 0
-                    and (iteration + 1) // densify_interval <= densify_times):
-                settle()                             # (the error map below must be the scene's; this event reads back anyway)
+            if not self.exact_snapshots and (not camera_only and densify_interval and (iteration + 1) % densify_interval == 0
+                                             and (iteration + 1) // densify_interval <= densify_times):
+                settle(last=launch)                  # (the error map below must be the scene's; this event reads back anyway)
             if not camera_only and iteration == 0 and later_frame and mask is not None:
                 # (an empty mask appends nothing: densify_by_pixels's own single host read decides, there is no
                 #  separate ``mask.sum() > 0`` read as in trainer.py:563)

@@ -14,10 +14,14 @@
  *   - no allocation and no host synchronisation inside: the caller supplies outputs and
  *     workspaces, all work is enqueued on `stream` (graph-capturable).  Process-wide state
  *     is limited to: the thread-local last HIP error (gfl_last_hip_error), the cached
- *     CU count of the device, the optional stage profiler (gfl_profile_*) and two
- *     environment switches read once: GFL_EWA_MFMA=1 (J Sigma J^T on the matrix cores; same results to rounding) and
- *     GFL_FWD_SPLIT_MIN=<n> (list length from which the forward blend walks a long tile on four CUs; scheduling only,
- *     results do not depend on it);
+ *     CU count of the device, the optional stage profiler (gfl_profile_*) and THREE
+ *     environment switches, read once per process -- every switch the library has:
+ *       GFL_EWA_MFMA=1        J Sigma J^T on the matrix cores (same results to rounding; gfl_ewa_on_mfma() reports it);
+ *       GFL_RESERVED=0        every iteration bins on the exact three-launch path (no reserved tile regions): the sorted
+ *                             lists, render and gradients are bit-identical either way;
+ *       GFL_FWD_SPLIT_MIN=<n> list length from which the forward blend walks a long tile on four CUs: scheduling only;
+ *     tests/test_gpu_switches.py flips each one in a process of its own and holds the results against the defaults.
+ *     (Rounds 3-4 had fourteen; the measured-and-rejected variants behind the others now live in tools/experiments/.)
  *   - return value: GFL_OK or a negative gfl_status; HIP launch errors are
  *     returned as GFL_ERR_HIP and the hipError_t is kept in gfl_last_hip_error();
  *   - *_bwd functions OVERWRITE their gradient outputs (they zero what they
@@ -80,15 +84,17 @@ typedef enum gfl_status {
 #endif
 #define GFL_MAX_BLEND_CHANNELS 4 /* per launch; the host splits wider features */
 
+/* 300 (round 5): gfl_fit_state.overflow is int32[4] (was [1] before 200's reserved regions), gfl_tile_sort_ordered reads a
+ * trailer of GFL_SORT_ORDER_TRAILER ints behind order[T][4], gfl_fit_iterations' flags are GFL_ITER_RESERVED only
+ * (GFL_ITER_PRE_DONE / _PRE_NEXT / _ODD, gfl_fit_next_preprocess_supported and gfl_bwd_rows_on are gone), the fit
+ * workspace is smaller (one slot pool).  A binding checks gfl_version() >= GFL_VERSION of the header it was written for. */
+#define GFL_VERSION 300
 int gfl_version(void);
 /* out[10] = TILE, NEAREST, EXTENT, FOV_CLAMP, LOWPASS, EIG_FLOOR, RADIUS_SIGMA, ALPHA_MIN, ALPHA_MAX, T_MIN of this build */
 int gfl_constants(float* out10);
 /* 1 when this process runs the J Sigma J^T contraction of gfl_fit_forward / gfl_render_fwd on the matrix cores
  * (GFL_EWA_MFMA=1 in the environment when the library first looked), 0 for the VALU form */
 int gfl_ewa_on_mfma(void);
-/* 1 when this process runs the backward blend of the fit iteration in its "rows" formulation (GFL_BWD_ROWS=1: a measured
- * alternative, off by default) */
-int gfl_bwd_rows_on(void);
 const char* gfl_status_string(int status);
 int gfl_last_hip_error(void);
 /* bytes of scratch any *_bwd that reduces camera gradients needs for N splats */
@@ -268,8 +274,10 @@ typedef struct gfl_fit_state {
     float *d_render, *err_px, *sums;            /* [4][H][W], [H][W], [8] as gfl_loss_fwd_bwd */
     int32_t *tile_offsets, *ids, *tile_range, *overflow; /* [T+1], [K_cap], [T][2], [4].  overflow[0] is sticky: 1 = a
                                                           * forward produced more than K_cap pairs (or slot-pool entries) and
-                                                          * dropped some, 2 = GFL_ITER_PRE_DONE without a preprocess or
-                                                          * GFL_ITER_RESERVED without reserved regions.  While it
+                                                          * dropped some, 2 = GFL_ITER_RESERVED without reserved regions.
+                                                          * It is only ever raised by the binning launches of a forward --
+                                                          * never by a launch that also reads it --, so every update launch of
+                                                          * one iteration sees the same value.  While it
                                                           * is set, gfl_fit_backward_step steps NOTHING (rows, moments, pose,
                                                           * depth affine and step counter stay) and adds 1 to overflow[1]: the
                                                           * caller grows the lists, clears the words and runs overflow[1]
@@ -312,20 +320,7 @@ int gfl_fit_forward(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream
 /* loss + backward + optimiser step on the state gfl_fit_forward left behind */
 int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream);
 int gfl_fit_iteration(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream);
-/* ``count`` iterations back to back (trainer.py:387-558 ``count`` times; what a caller captures into ONE graph).  Between
- * two plain iterations whose camera cannot move (step_camera / lr_camera as above, not the camera-only stage, no
- * footprint mask) the NEXT iteration's preprocess -- activations, projection, EWA, tile histogram of the row Adam has
- * just stepped -- runs in the tail of the per-splat backward + Adam launch: the next iteration has no preprocess launch
- * of its own (one launch and one read of the rows less; results bit-identical to ``count`` calls of gfl_fit_iteration
- * up to the order of the backward's LDS adds, which differs from run to run anyway).  flags, for callers that chain
- * calls themselves (0 is always right):
- *   GFL_ITER_PRE_NEXT  the LAST iteration's tail prepares the next call's first forward as well; rec / uv / depth then
- *                      describe the NEXT forward, not the last one -- the next call must pass GFL_ITER_PRE_DONE;
- *   GFL_ITER_PRE_DONE  the first forward's preprocess has been run by the previous call's tail (checked on the device:
- *                      otherwise *overflow becomes 2);
- *   GFL_ITER_ODD       the first iteration uses the second of the two slot-pool sets (iterations alternate between them:
- *                      pass it after an odd number of chained iterations).
- * gfl_fit_next_preprocess_supported: 1 if iterations with this state / these hyper-parameters take the short cut.
+/* ``count`` iterations back to back (trainer.py:387-558 ``count`` times; what a caller captures into ONE graph).
  *
  * Reserved tile regions (round 4, the default): the last launch of every full iteration gives each tile a region of the
  * key array sized by what the tile holds now plus a margin (count + count / 4 + 32), and an iteration that FOLLOWS a full
@@ -337,16 +332,13 @@ int gfl_fit_iteration(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stre
  *                      gfl_fit_backward_step) and the splats have not been replaced since (checked on the device as far
  *                      as it can be: without reserved regions *overflow becomes 2).  The regions are a PREDICTION: a tile
  *                      that outgrows its region voids that one iteration (overflow[2], counted in overflow[1]; the regions
- *                      reserved at its end are sized by what the tiles wanted) -- whatever the host did to the splats in
- *                      between, the result is never wrong.
+ *                      reserved at its end are sized by what the tiles wanted): nothing is stepped by it, but what its
+ *                      forward left behind -- render, lists, loss sums -- is TRUNCATED; a caller that looks at those
+ *                      (snapshot, log entry) checks overflow[2] first and runs the iteration again (gflow_amd/trainer.py).
  * gfl_fit_reserved_supported: 1 if this state's iterations can (tile grids of up to 4096 tiles; GFL_RESERVED=0 in the
  * environment switches it off). */
-#define GFL_ITER_PRE_DONE 1
-#define GFL_ITER_PRE_NEXT 2
-#define GFL_ITER_ODD 4
 #define GFL_ITER_RESERVED 8
 int gfl_fit_iterations(const gfl_fit_state* st, const gfl_fit_hyper* hp, int count, int flags, gfl_stream_t stream);
-int gfl_fit_next_preprocess_supported(const gfl_fit_state* st, const gfl_fit_hyper* hp);
 int gfl_fit_reserved_supported(const gfl_fit_state* st, const gfl_fit_hyper* hp);
 /* ---- the fused rasteriser as a differentiable operator (no loss, no optimiser) ------------------------
  * render(gaussians, camera) -> {rgb, depth_map, uv, depth} = render_multiple(input_group, ["rgb", "uv", "depth",

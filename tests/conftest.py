@@ -41,7 +41,4 @@ def _expected_library_switches():
     if os.environ.get("GFL_EXPECT_EWA_MFMA") == "1":
         from gflow_amd import _lib
         assert _lib.load().gfl_ewa_on_mfma() == 1, "GFL_EWA_MFMA=1 did not reach the library"
-    if os.environ.get("GFL_EXPECT_BWD_ROWS") == "1":
-        from gflow_amd import _lib
-        assert _lib.load().gfl_bwd_rows_on() == 1, "GFL_BWD_ROWS=1 did not reach the library"
     yield

@@ -538,7 +538,7 @@ def test_fused_iteration_on_odd_sizes_matches_operator_path(W, H, N):
 
 def test_iterations_that_do_not_move_the_camera_take_the_short_cut_with_the_same_result(setup):
     """lr_camera = 0 (first frame, joint stages): no camera launch, no pose gradient -- the loss sums, the depth affine and
-    the step counter come from a workgroup of the backward blend launch (LossTail, gfl_fused.hip).  Against the same
+    the step counter come from a workgroup of the backward blend launch (LossTail, gfl_fit_bwd.hip).  Against the same
     iterations with the gradient asked for (step_camera = 2: the camera launch as before): rows, moments, depth
     affine, loss sums and step counter agree (the two folds add the same partials in trees of different width), the
     pose does not move in either, and only the long way round reports d_extr."""
@@ -675,73 +675,9 @@ def _copy_engine_state(src, dst):
         getattr(dst, a).copy_(getattr(src, a))
 
 
-def _next_pre_on():
-    import ctypes
-    from gflow_amd import _lib as L
-    return os.environ.get("GFL_NEXT_PRE") == "1"
-
-
-def test_next_preprocess_variant_in_a_process_of_its_own():
-    """GFL_NEXT_PRE=1 (read once per process): the two tests below, which skip themselves without the switch."""
-    import subprocess
-    import sys
-    if _next_pre_on():
-        pytest.skip("already inside that process")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
-           "tests/test_gpu_fused.py::test_next_preprocess_in_the_adam_tail_is_the_standalone_preprocess",
-           "tests/test_gpu_fused.py::test_four_iterations_in_one_call_track_four_single_iterations"]
-    r = subprocess.run(cmd, env=dict(os.environ, GFL_NEXT_PRE="1"), cwd=root, capture_output=True, text=True, timeout=900)
-    tail = (r.stdout + r.stderr)[-4000:]
-    assert r.returncode == 0 and "3 passed" in r.stdout, tail
-
-
-@pytest.mark.parametrize("with_scale_term", [False, True])
-def test_next_preprocess_in_the_adam_tail_is_the_standalone_preprocess(setup, with_scale_term):
-    """gfl_fit_iterations: between two plain iterations the NEXT iteration's preprocess runs in the tail of the per-splat
-    backward + Adam launch.  Held against the stand-alone launch on the SAME stepped rows: records, pair count, sorted
-    ids and tile ranges bit for bit (GFL_ITER_PRE_NEXT leaves the next forward's records behind; a second engine that is
-    given the stepped rows runs the ordinary forward)."""
-    from gflow_amd import _lib as L
-    import ctypes
-    if not _next_pre_on():
-        pytest.skip("needs GFL_NEXT_PRE=1 (test_next_preprocess_variant_in_a_process_of_its_own starts it)")
-    s, raw, img, dep = setup
-    hyper = dict(lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0, lr=4e-3, lr_camera=0.0, total_iters=100)
-    if with_scale_term:
-        hyper["lambda_scale"] = 0.5
-    a = _engine(raw, s, img, dep, pose=POSE, **hyper)
-    b = _engine(raw, s, img, dep, pose=POSE, **hyper)
-    if with_scale_term:
-        flags = (torch.arange(a.cap, device=DEV) % 3).to(torch.uint8)          # still / moving / unlabelled rows
-        for e in (a, b):
-            e.set_regularisers(row_flags=flags)
-    assert a.lib.gfl_fit_next_preprocess_supported(ctypes.byref(a.state()), ctypes.byref(a.hp)) == 1
-    PRE_DONE, PRE_NEXT, ODD = 1, 2, 4
-    a.iteration(count=1, flags=PRE_NEXT)             # iteration 0; its tail prepares iteration 1's forward
-    rec_next = a.rec[:a.N].clone()
-    _copy_engine_state(a, b)
-    b.forward()                                      # the ordinary forward on the same stepped rows
-    assert torch.equal(rec_next, b.rec[:b.N])
-    a.iteration(count=1, flags=PRE_DONE | ODD)       # iteration 1 without a preprocess launch of its own
-    a.check_overflow()
-    assert a.K == b.K > 0
-    assert torch.equal(a.tile_range, b.tile_range) and torch.equal(a.ids[:a.K], b.ids[:b.K])
-    assert torch.equal(a.render, b.render)
-    b.backward_step()
-    for name in ("params", "adam_m", "adam_v"):
-        x, y = getattr(a, name)[:a.N], getattr(b, name)[:b.N]
-        assert (x - y).abs().max().item() <= 1e-5 * max(1.0, y.abs().max().item()), name
-    assert int(a.step.item()) == int(b.step.item()) == 2
-    # a claim without a preprocess is caught on the device
-    a.iteration(count=1, flags=PRE_DONE)
-    with pytest.raises(RuntimeError, match="preprocess"):
-        a.check_overflow()
-
-
 def test_four_iterations_in_one_call_track_four_single_iterations(setup):
-    if not _next_pre_on():
-        pytest.skip("needs GFL_NEXT_PRE=1 (test_next_preprocess_variant_in_a_process_of_its_own starts it)")
+    """gfl_fit_iterations(count = 4), launched one by one and replayed as ONE graph, against four single iterations (the
+    iterations of a call but the first bin into reserved tile regions; the single ones do too, through FitEngine)."""
     s, raw, img, dep = setup
     hyper = dict(lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0, lr=4e-3, lr_camera=0.0, total_iters=100)
     a = _engine(raw, s, img, dep, pose=POSE, **hyper)
@@ -758,11 +694,8 @@ def test_four_iterations_in_one_call_track_four_single_iterations(setup):
     assert (a.render - b.render).abs().max().item() < 1e-3
     assert torch.allclose(a.rec[:a.N], b.rec[:b.N], rtol=1e-3, atol=1e-3)       # rec = the LAST forward's in both
     assert torch.allclose(a.depth_ab, b.depth_ab, rtol=1e-5, atol=1e-7) and torch.allclose(a.sums, b.sums, rtol=1e-4)
-    # the camera-only stage and a moving camera do not qualify: same entry, ordinary launches
-    import ctypes
-    assert a.lib.gfl_fit_next_preprocess_supported(ctypes.byref(a.state()), ctypes.byref(a.hp)) == 1
+    # a moving camera: same entry, with the camera launch
     a.hp.lr_camera = 1e-3
-    assert a.lib.gfl_fit_next_preprocess_supported(ctypes.byref(a.state()), ctypes.byref(a.hp)) == 0
     b.hp.lr_camera = 1e-3
     a.iteration(count=2)
     b.iteration(); b.iteration()
@@ -850,7 +783,7 @@ def test_reserved_tile_regions_give_the_lists_of_the_exact_binning_path(setup, w
     a = _engine(raw, s, img, dep, pose=POSE, **hyper)
     b = _engine(raw, s, img, dep, pose=POSE, **hyper)
     if not _reserved_on(a):
-        pytest.skip("reserved tile regions are switched off (GFL_RESERVED=0 / GFL_NEXT_PRE=1)")
+        pytest.skip("reserved tile regions are switched off (GFL_RESERVED=0)")
     if with_scale_term:
         flags = (torch.arange(a.cap, device=DEV) % 3).to(torch.uint8)
         for e in (a, b):

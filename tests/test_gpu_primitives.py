@@ -68,28 +68,6 @@ def test_oracle_parity_holds_with_the_matrix_core_contraction():
     assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], tail
 
 
-def test_oracle_parity_holds_with_the_rows_formulation_of_the_backward_blend():
-    """GFL_BWD_ROWS=1: the backward blend as sixteen splats x four pixels per step with the recurrences as row scans
-    (fused_blend_bwd_rows_kernel; measured slower, kept behind the switch).  All fused gradients, the regularisers, the
-    heavy-tile segments and the full-size iterations (bench scene and the scene with a 1 500-splat pile) against the
-    ORACLE again, in a process of its own (the library reads the switch once)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GFL_BWD_ROWS="1", GFL_EXPECT_BWD_ROWS="1")
-    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
-           "tests/test_gpu_fused.py::test_fused_gradients_match_oracle",
-           "tests/test_gpu_fused.py::test_fused_regularisers_and_masks",
-           "tests/test_gpu_fused.py::test_fused_gradients_with_four_segment_heavy_tiles",
-           "tests/test_gpu_fused.py::test_fused_iteration_on_odd_sizes_matches_operator_path",
-           "tests/test_gpu_fullsize.py::test_fullsize_fused_iteration_matches_oracle"]
-    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=1500)
-    tail = (r.stdout + r.stderr)[-4000:]
-    assert r.returncode == 0, tail
-    assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], tail
-
-
 @pytest.mark.parametrize("box", [8, 4])
 def test_block_culling_never_drops_a_visible_pixel(box):
     """The blend kernels skip a (splat, pixel box) unit when `block_mask` says the splat cannot reach the box with
