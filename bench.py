@@ -232,7 +232,10 @@ def reduce_and_report(local, dist, red_dev, rank, world, args, backend, size=Non
                                    "binning": ("reserved tile regions in %d of %d iterations" % (STEP_WINDOW - 1, STEP_WINDOW))
                                    if local.get("reserved_on") else "exact path",
                                    "void_iterations": local.get("void_iterations")},
-                   "parallelism": f"clip-sharded x{world}", "collective_backend": backend},
+                   # (--clips-per-gpu c > 1: the throughput mode of a node with more clips than GPUs -- every rank fits c clips
+                   #  at the same time; the metric is quoted on 1)
+                   "parallelism": f"clip-sharded x{world}", "clips_per_gpu": max(1, getattr(args, "clips_per_gpu", 1)),
+                   "collective_backend": backend},
         "value_kind": "measured clip fit" if clip is not None else "derived from the step",
         "clip_fit": clip_out,
         "iterations_per_s": it_per_s,

@@ -83,7 +83,17 @@ def test_fullsize_fused_iteration_matches_oracle(which):
     # 99.99th percentile 1.2e-6 -- since the forward geometry is compiled without fused multiply-adds (the oracle's
     # arithmetic; rounds 1-3: 1-2e-5 of the pixels off, largest error 1.5e-3 / 2.3e-3, threshold flips of single splats at
     # single pixels, and bounds of 1e-4 of the pixels / 1e-2)
-    close_frac(eng.render, info["render4"], 1e-4, 1e-5, bad_frac=1e-5, hard=1e-3, what=f"{which}: render vs oracle")
+    bad_frac, hard = 1e-5, 1e-3
+    if eng.lib.gfl_ewa_on_mfma():
+        # GFL_EWA_MFMA=1 (a process of its own, tests/test_gpu_primitives.py): the matrix cores accumulate the three products
+        # of every element of M Sigma M^T with fused multiply-adds -- the conic differs from the oracle's unfused sums in the
+        # last bit, and where that moves a splat across the alpha >= 1/255 threshold at a pixel, the pixel changes by up to
+        # one contribution AT the threshold: (1 / 255) x the largest feature value (the depth plane: up to ~5).  Round 4
+        # observed 4.3e-6 of the pixels off and 9.5e-4 against the VALU build's bounds (1e-5 / 1e-3): this variant gets the
+        # bound its arithmetic implies, with the observed figures printed (close_frac) -- 5 x margin on the share.
+        bad_frac, hard = 5e-5, float(frame["depth"].max()) / 255.0
+    close_frac(eng.render, info["render4"], 1e-4, 1e-5, bad_frac=bad_frac, hard=hard, what=f"{which}: render vs oracle"
+               + (" [GFL_EWA_MFMA=1]" if eng.lib.gfl_ewa_on_mfma() else ""))
     assert eng.K <= info["K"]                                   # exact-disc culling only ever drops pairs
     l_rgb, l_depth = eng.loss_terms()
     assert abs(l_rgb.item() - info["l_rgb"].item()) <= 5e-5 * abs(info["l_rgb"].item())          # (observed: 9e-6)
@@ -106,6 +116,40 @@ def test_fullsize_fused_iteration_matches_oracle(which):
     rel = ((gp - pose.grad).norm() / pose.grad.norm()).item()
     assert rel < 2e-4, f"{which}: d_pose {rel:.2e}"                     # (observed: 4e-6 .. 7e-6)
     np.testing.assert_allclose((eng.ab_m / 0.1).cpu().numpy(), ab.grad.numpy(), rtol=5e-4)
+
+
+@pytest.mark.parametrize("which", ["bench_scene", "densified_scene"])
+def test_fullsize_reserved_regions_against_the_exact_path(which):
+    """Reserved tile regions at the size the bench and the clip fits run them (19 iterations of 20): the SECOND iteration on
+    480x854 / 60 000 splats bins into the regions the first one reserved, a copy of the same rows bins on the exact path --
+    records, every tile's sorted list, render, transmittance and contributor counts bit for bit, on the bench scene and on the
+    scene with a 1 500-splat pile in one tile (the tile whose region is outgrown first, and whose list the sort cuts in two)."""
+    from tests.test_gpu_fused import _copy_engine_state, _lists, _reserved_on
+    frame, raw = _bench_scene() if which == "bench_scene" else _densified_scene()
+    s = dict(W=W, H=H, intr=raw["intr"])
+    hyper = dict(lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0, lr=1e-3, lr_camera=0.0, total_iters=500)
+    a = _engine({k: raw[k] for k in NAMES}, s, frame["image"], frame["depth"], **hyper)
+    b = _engine({k: raw[k] for k in NAMES}, s, frame["image"], frame["depth"], **hyper)
+    if not _reserved_on(a):
+        pytest.skip("reserved tile regions are switched off (GFL_RESERVED=0)")
+    a.iteration()
+    assert a._reserved_flag() == a.GFL_ITER_RESERVED
+    _copy_engine_state(a, b)
+    for it in (1, 2, 3):
+        b.iteration(reserved=False)
+        a.iteration()
+        torch.cuda.synchronize()
+        assert a.overflow.tolist() == [0, 0, 0, 0], (it, a.overflow.tolist())       # not void: every tile fitted its region
+        assert a.K == b.K > 0
+        tr = a.tile_range.cpu()
+        assert int(tr[:, 1].max()) > a.K                                         # the lists sit in regions (gaps between them)
+        assert torch.equal(a.rec[:a.N], b.rec[:b.N])
+        assert all(torch.equal(x, y) for x, y in zip(_lists(a), _lists(b))), f"iteration {it}: a tile's sorted list differs"
+        assert torch.equal(a.render, b.render) and torch.equal(a.final_T, b.final_T) and torch.equal(a.n_contrib, b.n_contrib)
+        # the next comparison starts from the same rows again (the backward's LDS adds are unordered: last bits)
+        _copy_engine_state(a, b)
+    if which == "densified_scene":
+        assert int((tr[:, 1] - tr[:, 0]).max()) > 1200
 
 
 def test_config3_shape_eight_frame_clip_at_480p_60k():
