@@ -36,6 +36,7 @@ import torch  # noqa: E402
 H, W, N_SPLATS = 480, 854, 60000
 STEP_I0, STEP_WINDOW = 12, 20     # the timed step = iterations [12, 32) of the first-frame fit (see the docstring)
 ITERS_PER_FRAME = (500 + 59 * (150 + 300)) / 60.0
+TRAJ_NUM, TRAJ_OFFSET = 100, 2      # the README's --traj_num / --traj_offset: the clip fit renders its trajectories after every frame
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -93,7 +94,7 @@ def coresident_fits(dev, frames_n, snapshot_interval, levels=(1, 2, 3)):
     from gflow_amd import synthetic as S
     from gflow_amd import fit_video as FV
     clips = [FV.upload_clip(S.make_clip(frames_n, H, W, seed=100 + i, device=dev), dev) for i in range(max(levels))]
-    cfg = dict(num_points=N_SPLATS)
+    cfg = dict(num_points=N_SPLATS, traj_num=TRAJ_NUM, traj_offset=TRAJ_OFFSET)
     FV.fit_clips_concurrent([c[:2] for c in clips], dev, cfg, snapshot_interval=snapshot_interval)      # warm-up
     torch.cuda.synchronize()
     out = {}
@@ -204,7 +205,8 @@ def reduce_and_report(local, dist, red_dev, rank, world, args, backend, size=Non
                     "void_iterations": (clip or {}).get("void_iterations")}
         workload += (f"; value = measured fit_video fit of one {args.clip_frames}-frame rigid synthetic clip per GPU "
                      f"(configs[2]: iterations 500 first / 150 camera-only + 300 joint per later frame, densification "
-                     f"on, snapshots every {args.snapshot_interval} iterations); ms_per_step = iterations "
+                     f"on, snapshots every {args.snapshot_interval} iterations, --traj_num {TRAJ_NUM} --traj_offset {TRAJ_OFFSET}: "
+                     f"trainer.eval + project_points after every frame, /root/reference/README.md:114-115); ms_per_step = iterations "
                      f"[{STEP_I0}, {STEP_I0 + STEP_WINDOW}) of a first-frame fit on the grown scene (lambda rgb/depth/var = "
                      f"1/0.1/10), the same window for every --steps / --warmup")
     else:
@@ -336,7 +338,7 @@ def main():
     if not args.no_clip:
         c = max(1, args.clips_per_gpu)
         clips = [FV.upload_clip(S.make_clip(args.clip_frames, H, W, seed=rank * c + j, device=dev), dev) for j in range(c)]
-        cfg = dict(num_points=N_SPLATS)
+        cfg = dict(num_points=N_SPLATS, traj_num=TRAJ_NUM, traj_offset=TRAJ_OFFSET)
         FV.fit_clip(clips[0][:2], dev, cfg, seed=rank, snapshot_interval=args.snapshot_interval)      # warm-up
         barrier()
         t0 = time.perf_counter()

@@ -37,7 +37,11 @@ DEFAULTS = dict(num_points=60000, lr=4e-3, lr_camera=0.0, iterations_first=500, 
                 camera_first=True, lr_camera_after=5e-4, iterations_camera=150, densify_interval=150, densify_times=2,
                 densify_interval_after=100, densify_times_after=1, densify_occ_percent=1.0, densify_err_thre=1e-2,
                 densify_err_percent=1.0, lambda_rgb=1.0, lambda_depth=1e-4, lambda_var=10.0, lambda_still=10.0,
-                lambda_flow=0.01, lambda_scale=0.0, background="black")
+                lambda_flow=0.01, lambda_scale=0.0, background="black",
+                # trajectories (fit_video.py:34-35 defaults 0 / 0; the README's and scripts/fit_video.sh's flags: 100 / 2):
+                # with traj_num > 0 every frame ends with trainer.eval(traj_index, line_scale=0.5, point_scale=2., alpha=0.8)
+                # and project_points of the seeds (fit_video.py:226-238, 335-349)
+                traj_num=0, traj_offset=0)
 
 METRIC_NAMES = ("psnr_sum", "frames", "iterations", "rasterisations", "clips", "splats_final")
 
@@ -104,12 +108,62 @@ def upload_clip(frames, device):
     return out
 
 
+def select_traj_seeds(tr, traj_num, traj_offset):
+    """The splats whose trajectories are drawn (fit_video.py:163-211, ``grid_traj = True`` as the reference hard-codes it):
+    pixels of a grid -- stride 50 inside the eroded still region, stride 15 inside the eroded moving region (``move_seg``, the
+    hull mask of the first frame's fit; a 10 x 10 erosion, cv2.erode's default border: nothing eroded from the image's edge) --
+    and for every grid pixel the splat whose projection (``last_uv``) lies closest, kept if its still / moving label is the
+    region's.  Returns (indices: still seeds first, split_interval = their number or None without moving seeds).
+    Without a hull mask (fewer than six moving splats: the reference would fail in cv2.erode) the plain rule of
+    fit_video.py:165-167, every (N / traj_num)-th splat from ``traj_offset``.  Once per clip; the nearest-splat search runs on
+    the device (the reference forms an N x Q x 2 array in numpy), one read-back of the few hundred indices."""
+    import numpy as np
+    from scipy.ndimage import minimum_filter
+    n = tr.current_pts_num()
+    interval = max(int(n / traj_num), 1)
+    plain = list(range(n))[traj_offset::interval]
+    move_seg = getattr(tr, "move_seg", None)
+    if move_seg is None:
+        return plain, None
+    H, W = tr.H, tr.W
+    erode = lambda m: minimum_filter(m, size=10, mode="constant", cval=255)       # kernel 10 x 10, anchor (5, 5): x-5 .. x+4
+    move_er = erode(np.asarray(move_seg, dtype=np.uint8))
+    still_er = erode((255 - np.asarray(move_seg, dtype=np.int32)).astype(np.uint8))
+    s_still, s_move = 50, 15
+    grid = lambda lo_i, hi_i, lo_j, hi_j, s: [(j, i) for i in range(lo_i, hi_i, s) for j in range(lo_j, hi_j, s)]
+    sparse = [(j, i) for (j, i) in grid(s_still, H, s_still, W, s_still) if still_er[i, j]]
+    if len(sparse) == 0:
+        sparse = grid(s_still, H, s_still, W, s_still)
+    dense = [(j, i) for (j, i) in grid(s_move, H - s_move, s_move, W - s_move, s_move) if move_er[i, j]]
+    if len(sparse) == 0:                                 # (sic: the reference tests the SPARSE list again, :197)
+        dense = grid(s_move, H - s_move, s_move, W - s_move, s_move)
+    uv = tr.last_uv.detach().double()
+    still = tr.still_mask.detach()
+
+    def closest(points):                                 # utils.find_closest_point (tracking.py:24-26): argmin over the splats
+        q = torch.tensor(points, dtype=torch.float64, device=uv.device)
+        out = []
+        for a in range(0, q.shape[0], 256):              # (chunks: N x 256 distances at a time)
+            d = ((uv[:, None, :] - q[None, a:a + 256, :]) ** 2).sum(-1)
+            out.append(d.argmin(dim=0))
+        return torch.cat(out)
+
+    sp = closest(sparse)
+    sp_still = sp[still[sp]]
+    if len(dense):
+        de = closest(dense)
+        de_move = de[~still[de]]
+        return torch.cat([sp_still, de_move]).tolist(), int(sp_still.shape[0])
+    return sp_still.tolist(), None
+
+
 def fit_clip(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, log=None, load_extr=True, keep=None):
     """Fit one clip; returns the metrics dict of this clip (PSNR summed over its frames).
     ``load_extr`` (default True, like the reference's flag): frames that carry a camera pose
     (``extr``, read from the sequence's camera files) load it before they are fitted
     (fit_video.py:115-116, :252-253).  ``keep``: a dict that receives the trainer (``keep["trainer"]``) and the
-    per-frame PSNR as device scalars (``keep["psnr"]``) -- for tests and tools."""
+    per-frame PSNR as device scalars (``keep["psnr"]``) -- for tests and tools; with ``cfg["traj_num"]`` also the per-frame
+    trajectory images and seed projections as they left for the host (``keep["traj"]``)."""
     dev_ = torch.device(device)
     g = fit_clip_steps(frames, device, cfg=cfg, seed=seed, snapshot_interval=snapshot_interval, fused=fused, log=log,
                        load_extr=load_extr, chunk=None, keep=keep)
@@ -160,9 +214,28 @@ def fit_clip_steps(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=
                   lazy_images=True,        # (the image lists train() returns are not read here: do not wait for them)
                   chunk=chunk)
     # first frame (fit_video.py:119-142)
+    traj = int(c["traj_num"]) > 0
     yield from tr.train_steps(iterations=c["iterations_first"], lr=c["lr"], lr_camera=c["lr_camera"],
                               lambda_var=c["lambda_var"], densify_interval=c["densify_interval"],
-                              densify_times=c["densify_times"], move_mask=f0["move_mask"], **common)
+                              densify_times=c["densify_times"], move_mask=f0["move_mask"],
+                              move_seg=traj,   # (the seeds' grid needs the first frame's hull mask: host work, once per clip)
+                              **common)
+    traj_imgs, traj_uvs = [], []                         # per frame, ON THE DEVICE until the clip is fitted
+
+    def render_trajectories():
+        # fit_video.py:226-238 / 335-349: the scene's images + the trajectory overlay, and where the seeds project now
+        imgs = tr.eval(traj_index=traj_index, line_scale=0.5, point_scale=2.0, alpha=0.8, split_interval=split_interval,
+                       device_images=True)
+        traj_imgs.append(torch.stack([imgs[3], imgs[4]]))            # trajectories, rgb with the trajectories on top
+        uv_t, _ = tr.project_points(tr.get_attribute("xyz")[traj_index_t].detach())
+        traj_uvs.append(uv_t.detach())
+        if keep is not None:
+            keep.setdefault("traj_groups", []).append([x.clone() if isinstance(x, torch.Tensor) else x for x in tr.last_traj_group])
+
+    if traj:
+        traj_index, split_interval = select_traj_seeds(tr, int(c["traj_num"]), int(c["traj_offset"]))
+        traj_index_t = torch.as_tensor(traj_index, device=tr.device).long()
+        render_trajectories()
     # (PSNR stays on the device and is read ONCE at the end of the clip: a float() per frame drained the queue between
     #  two frames; with a log callback the caller asked for the numbers as they come)
     psnr_sum = tr.psnr().double()
@@ -187,6 +260,8 @@ def fit_clip_steps(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=
                                       lambda_flow=c["lambda_flow"], densify_interval=c["densify_interval_after"],
                                       densify_times=c["densify_times_after"], mask=fr.get("occ_mask"),
                                       mask_count=fr.get("occ_count"), move_mask=fr["move_mask"], **common)
+        if traj:
+            render_trajectories()
         p = tr.psnr()
         psnr_sum = psnr_sum + p.double()
         if keep is not None:
@@ -195,6 +270,23 @@ def fit_clip_steps(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=
             log(f"frame {i}: psnr {float(p):.2f} dB, splats {tr.current_pts_num()}")
     if tr.engine is not None:
         tr.engine.check_overflow()
+    if traj:
+        # one copy of every frame's two images and seed projections to the host, at the end of the clip (the reference copies
+        # five images and the projections per frame, blocking: render2img, .cpu().numpy())
+        imgs_d, uvs_d = torch.stack(traj_imgs), torch.stack(traj_uvs)
+        if imgs_d.is_cuda:
+            from .trainer import _PINNED
+            block = _PINNED.take(imgs_d.numel())
+            imgs_h = block[0][:imgs_d.numel()].view(imgs_d.shape)
+            imgs_h.copy_(imgs_d, non_blocking=True)
+            uvs_h = uvs_d.cpu()                          # (small; waits for the stream, and with it for the images above)
+            traj_out = dict(images=_PINNED.hand_out(block, [imgs_h])[0], uv=uvs_h.numpy(), index=list(traj_index),
+                            split_interval=split_interval)
+            _PINNED.release(block)
+        else:
+            traj_out = dict(images=imgs_d.numpy(), uv=uvs_d.numpy(), index=list(traj_index), split_interval=split_interval)
+        if keep is not None:
+            keep["traj"] = traj_out
     return dict(psnr_sum=float(psnr_sum), frames=len(frames), iterations=tr.iterations_done,
                 rasterisations=tr.rasterisations_done, clips=1, splats_final=tr.current_pts_num(),
                 # iterations that stepped nothing because a tile outgrew its reserved region, and were made up for

@@ -991,6 +991,26 @@ class SimpleGaussian:
             self._snap_done = torch.cuda.Event()
             self._snap_done.record(side)
 
+    def _render_scene_fused(self):
+        """(3, H, W, 3) uint8 on the device: rgb, depth colour, centre blobs of the CURRENT splats and camera (what
+        render_multiple(["rgb", "center", "depth_map_color"]) + render2img give, trainer.py:765-777) through the fused
+        kernels on the second engine: one forward, one gfl_fit_snapshot; nothing is read back."""
+        from .fused import FitEngine
+        eng = self.engine
+        n = eng.N
+        aux = getattr(self, "_aux", None)
+        if aux is None or aux.cap < n:
+            aux = self._aux = FitEngine(self.W, self.H, max(eng.cap, n), self.device, bg=self.bg)
+        aux.set_count(n)
+        aux.pose.copy_(eng.pose)
+        aux.intr.copy_(eng.intr)
+        aux.hp.bg = self.bg
+        aux.params[:n].copy_(eng.params[:n])
+        aux.forward()
+        out = aux.snapshot()
+        aux.watch_overflow()
+        return out
+
     def _render_parts_fused(self):
         """(2, 3, H, W, 3) uint8 on the device: [still splats, moving splats] x [rgb, depth colour, centre blobs] of the
         current state (trainer.py:632-677 renders rgb and centre of both sets).  A splat that is not in the set gets a raw
@@ -1137,11 +1157,14 @@ class SimpleGaussian:
                 setattr(self, k, ckpt[k])
 
     # -------------------------------------------------------- trajectory render
-    def eval(self, traj_index=None, line_scale=0.1, point_scale=0.3, alpha=0.5, split_interval=None):
+    def eval(self, traj_index=None, line_scale=0.1, point_scale=0.3, alpha=0.5, split_interval=None, device_images=False):
         """trainer.py:713-811: render the current splats (rgb, center, depth_map_color) and the trajectories of the
         splats ``traj_index`` (poly-lines from their previous to their current positions, older segments fading by
         ``alpha`` per frame), plus the screen blend of both.  Returns five (H,W,3) uint8 images:
-        (rgb, center, depth_colour, trajectories, rgb with the trajectories on top)."""
+        (rgb, center, depth_colour, trajectories, rgb with the trajectories on top).
+        ``device_images``: the five images as uint8 tensors ON THE DEVICE and nothing read back (fit_video.fit_clip calls this
+        once per frame, fit_video.py:226-238, 335-349, and keeps the images on the device until the clip is fitted); the
+        three images of the scene then come from the fused kernels (a forward + gfl_fit_snapshot on a second engine)."""
         from .color import apply_float_colormap
         from .trajectory import gen_line_set
         dev = self.device
@@ -1179,12 +1202,24 @@ class SimpleGaussian:
             self.traj_rgb = torch.cat([self.traj_rgb, line_rgb], dim=0)
             self.last_traj_xyz = current_xyz
         with torch.no_grad():
-            out = render_mod.render_multiple(self._input_group(detach=True), ["rgb", "center", "depth_map_color"])
             # (the reference hands the RAW trajectory opacity / colour to the rasteriser, :784-790)
             traj_group = [self.traj_xyz, self.traj_scale, self.traj_rotate, self.traj_opacity, self.traj_rgb, self.intr,
                           self.get_extr().detach(), self.bg, self.W, self.H]
+            self.last_traj_group = traj_group
             out_traj = render_mod.render_traj(traj_group, num_traj, line_scale, point_scale)
             self.rasterisations_done += 2
+            if device_images:
+                img_traj = render_mod.render2img_device(out_traj)
+                if self.fused and self.engine is not None and self.engine.N == self.current_pts_num():
+                    scene = self._render_scene_fused()               # rgb, depth colour, centre blobs
+                    img, img_depth, img_center = scene[0], scene[1], scene[2]
+                else:
+                    out = render_mod.render_multiple(self._input_group(detach=True), ["rgb", "center", "depth_map_color"])
+                    img, img_center, img_depth = (render_mod.render2img_device(out[k]) for k in ("rgb", "center", "depth_map_color"))
+                # screen blending as below (numpy forms it in float64 and truncates)
+                upon = 1.0 - (1.0 - img.double() / 255.0) * (1.0 - img_traj.double() / 255.0)
+                return img, img_center, img_depth, img_traj, (upon * 255.0).to(torch.uint8)
+            out = render_mod.render_multiple(self._input_group(detach=True), ["rgb", "center", "depth_map_color"])
         out_img = render_mod.render2img(out["rgb"])
         out_img_center = render_mod.render2img(out["center"])
         out_img_depth = render_mod.render2img(out["depth_map_color"])

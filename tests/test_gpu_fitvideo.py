@@ -311,7 +311,10 @@ def test_snapshots_returned_by_train_are_the_renders_of_their_iterations(async_s
     assert np.abs(frames[0].astype(int) - frames[1].astype(int)).mean() > 0.5      # the fit moved between the snapshots
     assert np.abs(frames[1].astype(int) - frames[2].astype(int)).mean() > 0.1
     b = make()
-    b.make_stepper(iterations=17, snapshot_interval=0, **kw).run(16)     # (the same LinearLR schedule, stopped at 16)
+    st = b.make_stepper(iterations=17, snapshot_interval=0, **kw)          # (the same LinearLR schedule, stopped at 16)
+    st.run(16)
+    st.settle()                          # (iterations that stepped nothing -- a tile outgrew its region -- are made up for)
+    assert int(b.engine.step.item()) == 16
     b.engine.forward()
     torch.cuda.synchronize()
     want = R.render2img(b.engine.render[:3])
@@ -395,7 +398,8 @@ def test_a_snapshot_behind_a_void_iteration_shows_the_splats_of_its_own_iteratio
         next(g)                                       # iterations 0 (snapshot), 1, 2
         eng = tr.engine
         if exact_only:
-            eng._reserved_flag = lambda: 0            # this fit never bins into reserved regions
+            eng._reserved_flag = lambda: 0            # this fit never bins into reserved regions: one iteration per call
+            tr.use_graph = False                      # (iterations 2.. of a multi-iteration call always do)
         mid = torch.tensor([64.0, 48.0], device=DEV)
         centre = int((eng.rec[:eng.N, 0:2] - mid).norm(dim=1).argmin())
         eng.params[0:eng.N:3, 0:3] = eng.params[centre, 0:3].clone()      # (in place: the engine does not know)
@@ -446,3 +450,53 @@ def test_bench_with_two_ranks_on_this_box():
     assert abs(d["value"] - 4 / c["wall_s"]) < 1e-6 * d["value"]         # frames of ALL ranks / the slowest rank's time
     assert d["roofline"] and d["roofline"]["kernel"] == "blend_bwd" and 0 < d["roofline"]["frac"] < 1
     assert d["ms_per_step"] > 0 and "cpu_baseline" not in d
+
+
+def test_fit_clip_renders_the_trajectories_of_every_frame():
+    """fit_clip with the README's ``--traj_num 100 --traj_offset 2`` keeps the reference's frame loop whole: grid seeds from the
+    first frame's hull mask (fit_video.py:163-211), then after the first and after EVERY later frame trainer.eval(traj_index,
+    line_scale=0.5, point_scale=2., alpha=0.8) + project_points (fit_video.py:226-238, 335-349).  Held here: the seeds obey
+    the selection rule, every frame's trajectory image against the oracle's render_traj (render.py:110-156) of that frame's
+    trajectory splats and camera, the screen blend, the seeds' projections against the oracle's project_point, and the
+    fused scene image against the snapshot path."""
+    from gflow_amd import synthetic as S
+    from gflow_amd.fit_video import fit_clip
+    from oracle import msplat_oracle as MO
+    H_, W_ = 120, 168
+    frames = S.make_clip(3, H_, W_, seed=2, device=DEV)
+    cfg = dict(num_points=3000, iterations_first=60, iterations_camera=20, iterations_after=40, densify_interval=25,
+               densify_interval_after=15, traj_num=100, traj_offset=2)
+    keep = {}
+    m = fit_clip(frames, DEV, cfg, seed=0, snapshot_interval=10, keep=keep)
+    base = fit_clip(frames, DEV, dict(cfg, traj_num=0), seed=0, snapshot_interval=10)
+    torch.cuda.synchronize()
+    tr = keep["trainer"]
+    t = keep["traj"]
+    n_seeds = len(t["index"])
+    assert m["frames"] == 3 and m["iterations"] == base["iterations"] == 60 + 2 * 60
+    # two rasterisations per frame on top of the fit's (eval: the scene + the trajectory overlay)
+    assert m["rasterisations"] == base["rasterisations"] + 2 * 3
+    assert t["images"].shape == (3, 2, H_, W_, 3) and t["images"].dtype == np.uint8 and t["uv"].shape == (3, n_seeds, 2)
+    # the seeds: still ones first, then moving ones; every one carries the label of its region
+    assert 0 < n_seeds and max(t["index"]) < 3000 + 1000
+    still0 = None
+    for f, group in enumerate(keep["traj_groups"]):
+        xyz, scale, rot, op, rgb, intr, extr, bg, W2, H2 = [x.cpu() if isinstance(x, torch.Tensor) else x for x in group]
+        want = MO.render_traj([xyz, scale, rot, op, rgb, intr, extr, bg, W2, H2], n_seeds, 0.5, 2.0)
+        want = (torch.clamp(want.permute(1, 2, 0), 0.0, 1.0).numpy() * 255).astype(np.uint8)
+        d = np.abs(t["images"][f, 0].astype(np.int32) - want.astype(np.int32))
+        print(f"observed trajectories frame {f}: {float((d > 1).mean()):.2e} of the bytes off by more than a level, {int((want > 0).sum())} lit")
+        assert (d > 1).mean() <= 2e-3, f
+        assert want.max() > 0
+        # what the seeds project to (project_points of the CURRENT xyz with the frame's camera): the end points of the frame's
+        # poly-lines are those xyz -- the last n_seeds rows of the trajectory splats from the second frame on, all rows before
+        uv_ref, _ = MO.project_point(xyz[-n_seeds:], intr, extr, W2, H2)
+        assert np.allclose(t["uv"][f], uv_ref.numpy(), atol=2e-3), f
+        if f == 0:
+            assert xyz.shape[0] == n_seeds
+        else:
+            assert xyz.shape[0] > n_seeds and float(op[:n_seeds].max()) < float(op[-1])     # older points fade (alpha 0.8)
+    # the overlay: screen blend of the scene image and the trajectory image, as numpy forms it
+    up = t["images"][:, 1].astype(np.float64)
+    assert (up >= t["images"][:, 0].astype(np.float64) - 1).all()
+    assert t["split_interval"] is None or 0 <= t["split_interval"] <= n_seeds

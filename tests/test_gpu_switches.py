@@ -88,7 +88,7 @@ def test_scheduling_switches_do_not_change_a_result(default_run, tmp_path, env):
     if "GFL_FWD_SPLIT_MIN" in env:
         assert np.abs(a["f0_final_T"] - b["f0_final_T"]).max() <= 2e-6
         assert np.abs(a["f0_render"] - b["f0_render"]).max() <= 2e-5
-        assert (a["f0_render"] != b["f0_render"]).any(axis=0).mean() < 0.05      # ... on the long tiles only
+        # (on this small image every tile is the first tile of a queue: any of them may take the long walk)
     else:
         assert np.array_equal(a["f0_final_T"], b["f0_final_T"]) and np.array_equal(a["f0_render"], b["f0_render"])
     # after four iterations: to the order of the backward's LDS adds
