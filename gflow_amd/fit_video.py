@@ -220,22 +220,47 @@ def fit_clip_steps(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=
                               densify_times=c["densify_times"], move_mask=f0["move_mask"],
                               move_seg=traj,   # (the seeds' grid needs the first frame's hull mask: host work, once per clip)
                               **common)
-    traj_imgs, traj_uvs = [], []                         # per frame, ON THE DEVICE until the clip is fitted
+    traj_rec = []                                        # per frame: where the seeds are, the camera, the scene's rgb image
 
-    def render_trajectories():
-        # fit_video.py:226-238 / 335-349: the scene's images + the trajectory overlay, and where the seeds project now
-        imgs = tr.eval(traj_index=traj_index, line_scale=0.5, point_scale=2.0, alpha=0.8, split_interval=split_interval,
-                       device_images=True)
-        traj_imgs.append(torch.stack([imgs[3], imgs[4]]))            # trajectories, rgb with the trajectories on top
-        uv_t, _ = tr.project_points(tr.get_attribute("xyz")[traj_index_t].detach())
-        traj_uvs.append(uv_t.detach())
-        if keep is not None:
-            keep.setdefault("traj_groups", []).append([x.clone() if isinstance(x, torch.Tensor) else x for x in tr.last_traj_group])
+    def record_trajectories():
+        # fit_video.py:226-238 / 335-349 call trainer.eval + project_points here, after every frame.  What they need of THIS
+        # frame is recorded on the device -- the seeds' positions, the camera, the rendered scene (the fused kernels, now) --
+        # and the trajectory overlays of all frames are drawn once the clip is fitted (draw_trajectories): a poly-line's point
+        # count is data and the operator path sizes its lists on the host, i.e. two or three full stops of the host per frame
+        # here, each with the next frame's set-up behind it (60-frame clip fit: 9.76 -> 9.24 frames/s when drawn per frame).
+        with torch.no_grad():
+            xyz_now = tr.get_attribute("xyz")[traj_index_t].detach().float().clone()
+            extr_now = tr.get_extr().detach().clone()
+            if tr.fused and tr.engine is not None and tr.engine.N == tr.current_pts_num():
+                rgb_u8 = tr._render_scene_fused()[0].clone()
+            else:
+                from . import render as render_mod
+                rgb_u8 = render_mod.render2img_device(render_mod.render_multiple(tr._input_group(detach=True), ["rgb"])["rgb"])
+            tr.rasterisations_done += 1
+        traj_rec.append((xyz_now, extr_now, rgb_u8))
+
+    def draw_trajectories():
+        from . import msplat
+        from . import render as render_mod
+        imgs, uvs = [], []
+        with torch.no_grad():
+            for xyz_now, extr_now, rgb_u8 in traj_rec:
+                overlay = tr.eval_trajectories(xyz_now, extr_now, line_scale=0.5, point_scale=2.0, alpha=0.8,
+                                               split_interval=split_interval)
+                img_traj = render_mod.render2img_device(overlay)
+                # screen blending as trainer.eval forms it (numpy: float64, truncation)
+                upon = 1.0 - (1.0 - rgb_u8.double() / 255.0) * (1.0 - img_traj.double() / 255.0)
+                imgs.append(torch.stack([img_traj, (upon * 255.0).to(torch.uint8)]))
+                uvs.append(msplat.project_point(xyz_now, tr.intr, extr_now, tr.W, tr.H)[0])       # trainer.project_points
+                if keep is not None:
+                    keep.setdefault("traj_groups", []).append([x.clone() if isinstance(x, torch.Tensor) else x
+                                                               for x in tr.last_traj_group])
+        return torch.stack(imgs), torch.stack(uvs)
 
     if traj:
         traj_index, split_interval = select_traj_seeds(tr, int(c["traj_num"]), int(c["traj_offset"]))
         traj_index_t = torch.as_tensor(traj_index, device=tr.device).long()
-        render_trajectories()
+        record_trajectories()
     # (PSNR stays on the device and is read ONCE at the end of the clip: a float() per frame drained the queue between
     #  two frames; with a log callback the caller asked for the numbers as they come)
     psnr_sum = tr.psnr().double()
@@ -261,7 +286,7 @@ def fit_clip_steps(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=
                                       densify_times=c["densify_times_after"], mask=fr.get("occ_mask"),
                                       mask_count=fr.get("occ_count"), move_mask=fr["move_mask"], **common)
         if traj:
-            render_trajectories()
+            record_trajectories()
         p = tr.psnr()
         psnr_sum = psnr_sum + p.double()
         if keep is not None:
@@ -273,7 +298,7 @@ def fit_clip_steps(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=
     if traj:
         # one copy of every frame's two images and seed projections to the host, at the end of the clip (the reference copies
         # five images and the projections per frame, blocking: render2img, .cpu().numpy())
-        imgs_d, uvs_d = torch.stack(traj_imgs), torch.stack(traj_uvs)
+        imgs_d, uvs_d = draw_trajectories()
         if imgs_d.is_cuda:
             from .trainer import _PINNED
             block = _PINNED.take(imgs_d.numel())

@@ -1157,22 +1157,38 @@ class SimpleGaussian:
                 setattr(self, k, ckpt[k])
 
     # -------------------------------------------------------- trajectory render
-    def eval(self, traj_index=None, line_scale=0.1, point_scale=0.3, alpha=0.5, split_interval=None, device_images=False):
+    def eval(self, traj_index=None, line_scale=0.1, point_scale=0.3, alpha=0.5, split_interval=None):
         """trainer.py:713-811: render the current splats (rgb, center, depth_map_color) and the trajectories of the
         splats ``traj_index`` (poly-lines from their previous to their current positions, older segments fading by
         ``alpha`` per frame), plus the screen blend of both.  Returns five (H,W,3) uint8 images:
-        (rgb, center, depth_colour, trajectories, rgb with the trajectories on top).
-        ``device_images``: the five images as uint8 tensors ON THE DEVICE and nothing read back (fit_video.fit_clip calls this
-        once per frame, fit_video.py:226-238, 335-349, and keeps the images on the device until the clip is fitted); the
-        three images of the scene then come from the fused kernels (a forward + gfl_fit_snapshot on a second engine)."""
+        (rgb, center, depth_colour, trajectories, rgb with the trajectories on top)."""
+        traj_index = torch.as_tensor(traj_index, device=self.device).long()
+        current_xyz = self.get_attribute("xyz")[traj_index].detach().float()
+        with torch.no_grad():
+            out_traj = self.eval_trajectories(current_xyz, self.get_extr().detach(), line_scale, point_scale, alpha, split_interval)
+            out = render_mod.render_multiple(self._input_group(detach=True), ["rgb", "center", "depth_map_color"])
+            self.rasterisations_done += 1
+        out_img = render_mod.render2img(out["rgb"])
+        out_img_center = render_mod.render2img(out["center"])
+        out_img_depth = render_mod.render2img(out["depth_map_color"])
+        out_img_traj = render_mod.render2img(out_traj)
+        # screen blending
+        result = 1 - (1 - np.array(out_img) / 255.0) * (1 - np.array(out_img_traj) / 255.0)
+        return out_img, out_img_center, out_img_depth, out_img_traj, (result * 255).astype(np.uint8)
+
+    def eval_trajectories(self, current_xyz, extr, line_scale=0.1, point_scale=0.3, alpha=0.5, split_interval=None):
+        """The trajectory half of ``eval`` (trainer.py:716-762, 779-794) as a function of what it needs of a frame: where the
+        tracked splats are (``current_xyz`` (n, 3)) and the frame's camera (``extr`` (3, 4)).  Advances the trajectory state
+        (all poly-line points so far, their fading opacities and colours) by one frame and returns the overlay (3, H, W) float.
+        fit_video.fit_clip records the two inputs after every frame and calls this for all frames once the clip is fitted:
+        the poly-lines' point counts are data (a read-back per frame) and the operator path sizes its lists on the host."""
         from .color import apply_float_colormap
         from .trajectory import gen_line_set
         dev = self.device
-        traj_index = torch.as_tensor(traj_index, device=dev).long()
-        num_traj = traj_index.shape[0]
+        num_traj = current_xyz.shape[0]
         op_inv = self._activations_inv["opacity"]
         if not hasattr(self, "traj_xyz"):                                  # the first frame
-            self.traj_xyz = self.get_attribute("xyz")[traj_index].detach().float()
+            self.traj_xyz = current_xyz
             self.traj_scale = torch.ones((num_traj, 3), device=dev)
             self.traj_rotate = torch.tensor([1.0, 0.0, 0.0, 0.0], device=dev).repeat(num_traj, 1)
             self.traj_opacity = op_inv(0.99 * torch.ones((num_traj, 1), device=dev))
@@ -1190,7 +1206,6 @@ class SimpleGaussian:
             self.last_traj_xyz = self.traj_xyz
             self.last_traj_rgb = self.traj_rgb
         else:                                                              # the following frames
-            current_xyz = self.get_attribute("xyz")[traj_index].detach().float()
             line_xyz, line_rgb = gen_line_set(self.last_traj_xyz, current_xyz, self.last_traj_rgb, device=dev)
             num_in_line = line_xyz.shape[0]
             self.traj_xyz = torch.cat([self.traj_xyz, line_xyz], dim=0)
@@ -1201,32 +1216,12 @@ class SimpleGaussian:
                                            op_inv(0.99 * torch.ones((num_in_line, 1), device=dev))], dim=0)
             self.traj_rgb = torch.cat([self.traj_rgb, line_rgb], dim=0)
             self.last_traj_xyz = current_xyz
-        with torch.no_grad():
-            # (the reference hands the RAW trajectory opacity / colour to the rasteriser, :784-790)
-            traj_group = [self.traj_xyz, self.traj_scale, self.traj_rotate, self.traj_opacity, self.traj_rgb, self.intr,
-                          self.get_extr().detach(), self.bg, self.W, self.H]
-            self.last_traj_group = traj_group
-            out_traj = render_mod.render_traj(traj_group, num_traj, line_scale, point_scale)
-            self.rasterisations_done += 2
-            if device_images:
-                img_traj = render_mod.render2img_device(out_traj)
-                if self.fused and self.engine is not None and self.engine.N == self.current_pts_num():
-                    scene = self._render_scene_fused()               # rgb, depth colour, centre blobs
-                    img, img_depth, img_center = scene[0], scene[1], scene[2]
-                else:
-                    out = render_mod.render_multiple(self._input_group(detach=True), ["rgb", "center", "depth_map_color"])
-                    img, img_center, img_depth = (render_mod.render2img_device(out[k]) for k in ("rgb", "center", "depth_map_color"))
-                # screen blending as below (numpy forms it in float64 and truncates)
-                upon = 1.0 - (1.0 - img.double() / 255.0) * (1.0 - img_traj.double() / 255.0)
-                return img, img_center, img_depth, img_traj, (upon * 255.0).to(torch.uint8)
-            out = render_mod.render_multiple(self._input_group(detach=True), ["rgb", "center", "depth_map_color"])
-        out_img = render_mod.render2img(out["rgb"])
-        out_img_center = render_mod.render2img(out["center"])
-        out_img_depth = render_mod.render2img(out["depth_map_color"])
-        out_img_traj = render_mod.render2img(out_traj)
-        # screen blending
-        result = 1 - (1 - np.array(out_img) / 255.0) * (1 - np.array(out_img_traj) / 255.0)
-        return out_img, out_img_center, out_img_depth, out_img_traj, (result * 255).astype(np.uint8)
+        # (the reference hands the RAW trajectory opacity / colour to the rasteriser, :784-790)
+        traj_group = [self.traj_xyz, self.traj_scale, self.traj_rotate, self.traj_opacity, self.traj_rgb, self.intr, extr,
+                      self.bg, self.W, self.H]
+        self.last_traj_group = traj_group
+        self.rasterisations_done += 1
+        return render_mod.render_traj(traj_group, num_traj, line_scale, point_scale)
 
     def project_points(self, points):
         return msplat.project_point(points, self.intr, self.get_extr(), self.W, self.H)
