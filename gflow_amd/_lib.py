@@ -74,6 +74,7 @@ SIGNATURES = {
     "gfl_selftest_reduce10": (c_int, [_P, _P, _P, _P]),
     "gfl_selftest_cov2d": (c_int, [_P, _P, c_int, _P, _P, _P]),
     "gfl_selftest_block_mask": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "gfl_concave_hull": (c_int, [_P, c_int, ctypes.c_double, ctypes.c_double, _P, c_int]),
     "gfl_abi_sizes": (c_int, [_P, _P]),
     "gfl_profile_enable": (c_int, [ctypes.c_uint]),
     "gfl_profile_read": (c_int, [_P, _P, c_int]),

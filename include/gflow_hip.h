@@ -428,6 +428,15 @@ int gfl_selftest_cov2d(const float* m, const float* cov, int n, float* out_valu,
  * visible pixel by brute force with the kernels' own alpha test.  The mask must contain the truth. */
 int gfl_selftest_block_mask(const float* rec, int n, int x0, int y0, int box, int32_t* mask, int32_t* truth, gfl_stream_t stream);
 
+/* ---- moving-region hull (HOST function: plain pointers, no device work) ----------------------------------
+ * The ring of the concave hull of n 2-D points (concaveman's algorithm, what the `concave_hull` package behind
+ * gflow/utils/concave_hull.py:73-92 implements; gflow/trainer.py:604-609 masks the moving region with it).
+ * points_xy[n][2]: sorted by x then y, no duplicates (numpy.unique(axis=0)); concavity 2, length_threshold 0 are the
+ * package's defaults.  Writes up to cap_vertices ring vertices (not closed) to ring_xy and returns their number, or a
+ * negative gfl_status (GFL_ERR_WORKSPACE: cap_vertices too small; 2 n + 8 always suffices). */
+int gfl_concave_hull(const double* points_xy, int n, double concavity, double length_threshold, double* ring_xy,
+                     int cap_vertices);
+
 /* sizeof(gfl_fit_state), sizeof(gfl_fit_hyper): lets an FFI binding verify its struct mirrors */
 int gfl_abi_sizes(int* sizeof_fit_state, int* sizeof_fit_hyper);
 

@@ -428,6 +428,9 @@ def test_a_snapshot_behind_a_void_iteration_shows_the_splats_of_its_own_iteratio
         print(f"observed snapshot {k}: {float((d > 1).mean()):.2e} of the bytes differ by more than one level, max {int(d.max())}")
         # (the two fits' rows differ in the last bits -- unordered LDS adds in the backward --, a byte now and then by a level)
         assert (d > 1).mean() < 1e-3 and d.mean() < 0.05, k
+    bad_a, bad_b = ~torch.isfinite(rows_a), ~torch.isfinite(rows_b)
+    print(f"observed non-finite row entries: {int(bad_a.sum())} / {int(bad_b.sum())}, by column {bad_a.sum(0).tolist()}")
+    assert not bool(bad_a.any()) and not bool(bad_b.any())
     rel = ((rows_a - rows_b).norm() / rows_b.norm()).item()
     print(f"observed rows after eleven iterations: relative difference {rel:.2e}")
     assert rel < 1e-3, rel

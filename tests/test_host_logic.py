@@ -56,6 +56,30 @@ def test_device_sampler_draws_from_the_same_distribution():
     np.testing.assert_allclose(scales.numpy() * (1.0 / want.flatten()[flat]).sum() / 100.0, 1.0 / want.flatten()[flat], rtol=1e-6)
 
 
+def test_native_concave_hull_is_the_numpy_statement_of_the_algorithm():
+    """gfl_concave_hull (csrc/gfl_hull.hip, host C++) against hull.concave_hull_py, the numpy statement it was written from:
+    the same ring, vertex for vertex, on uniform clouds, clustered clouds, an L shape, a ring, collinear and tiny inputs."""
+    import time
+    from gflow_amd.hull import concave_hull, concave_hull_py
+    rng = np.random.default_rng(4)
+    cases = [rng.uniform(0, 100, (n, 2)) for n in (4, 5, 17, 300, 2000)]
+    blob = np.concatenate([rng.normal((30, 40), 6, (800, 2)), rng.normal((70, 45), 3, (400, 2)), rng.uniform(0, 100, (50, 2))])
+    cases.append(blob)
+    ell = rng.uniform(0, 100, (3000, 2))
+    cases.append(ell[~((ell[:, 0] > 40) & (ell[:, 1] > 40))])
+    ang = rng.uniform(0, 2 * np.pi, 1500)
+    cases.append(np.stack([np.cos(ang), np.sin(ang)], 1) * rng.uniform(30, 40, (1500, 1)) + 50)
+    cases.append(np.stack([np.arange(10.0), 2 * np.arange(10.0)], 1))                      # collinear
+    cases.append(np.round(rng.uniform(0, 20, (500, 2))))                                   # integer pixels: duplicates, ties
+    cases += [np.zeros((0, 2)), np.array([[1.0, 2.0]]), np.array([[0.0, 0.0], [1.0, 0.0], [0.0, 1.0]])]
+    t_py = t_c = 0.0
+    for pts in cases:
+        t0 = time.perf_counter(); a = concave_hull(pts); t1 = time.perf_counter(); b = concave_hull_py(pts); t2 = time.perf_counter()
+        t_c += t1 - t0; t_py += t2 - t1
+        assert a.shape == b.shape and np.array_equal(a, b), (len(pts), a.shape, b.shape)
+    assert t_c < t_py
+
+
 def test_concave_hull_properties():
     """gflow_amd/hull.py -- the moving-region mask of trainer.py:604-609.  The ring cannot be pinned to the reference's
     ``concave_hull`` package (absent), so it is held to what a concave hull must satisfy: it keeps (nearly) every point
