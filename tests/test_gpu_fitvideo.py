@@ -430,7 +430,10 @@ def test_a_snapshot_behind_a_void_iteration_shows_the_splats_of_its_own_iteratio
         assert (d > 1).mean() < 1e-3 and d.mean() < 0.05, k
     bad_a, bad_b = ~torch.isfinite(rows_a), ~torch.isfinite(rows_b)
     print(f"observed non-finite row entries: {int(bad_a.sum())} / {int(bad_b.sum())}, by column {bad_a.sum(0).tolist()}")
-    assert not bool(bad_a.any()) and not bool(bad_b.any())
+    # (raw colours of saturated pixels are +inf in the reference too: logit(clamp(1.0, 1e-15, 1 - 1e-15)) in float32,
+    #  trainer.py:229-232 -- sigmoid gives 1, its derivative 0, Adam leaves them alone)
+    assert torch.equal(bad_a, bad_b) and not bool(bad_a[:, :11].any())
+    rows_a, rows_b = torch.where(bad_a, 0.0, rows_a), torch.where(bad_b, 0.0, rows_b)
     rel = ((rows_a - rows_b).norm() / rows_b.norm()).item()
     print(f"observed rows after eleven iterations: relative difference {rel:.2e}")
     assert rel < 1e-3, rel
