@@ -503,11 +503,41 @@ class FitEngine:
         self.pairs_grown = getattr(self, "pairs_grown", 0) + 1
         return max(skipped, 0)
 
+    def grow_pairs(self):
+        """Twice the room for (splat, tile) pairs, before they run out (the caller has drained the stream)."""
+        self._K_grown = True
+        self._alloc_pairs(2 * self.K_cap)
+        with _GRAPH_LOCK:
+            self._graphs.clear()
+        self._graph_key = None
+        self.pairs_grown = getattr(self, "pairs_grown", 0) + 1
+
     def _overflow_message(self, code):
         if code == 2:
             return ("FitEngine: an iteration was told that the previous one had run its preprocess / reserved its tile regions, "
                     "and it had not")
         return f"FitEngine: more than K_cap={self.K_cap} splat-tile pairs; raise K_cap"
+
+    def watch_pending(self):
+        """Non-blocking: the four overflow words and the pair count as they are once everything queued so far has run, copied
+        to page-locked memory behind that work.  ``read_pending`` waits for exactly that copy -- not for work queued after
+        this call: the trainer queues one more iteration first, so the device is busy while the host looks."""
+        if getattr(self, "_pend_host", None) is None:
+            self._pend_host = torch.zeros(8, dtype=torch.int32, pin_memory=True)
+        self._pend_host[0:4].copy_(self.overflow, non_blocking=True)
+        self._pend_host[4:5].copy_(self.tile_offsets[self.T:self.T + 1], non_blocking=True)
+        self._pend_event = torch.cuda.Event()
+        self._pend_event.record()
+
+    def read_pending(self):
+        """(code, iterations that stepped nothing, pair count) of the last ``watch_pending``; None without one."""
+        ev = getattr(self, "_pend_event", None)
+        if ev is None:
+            return None
+        ev.synchronize()
+        self._pend_event = None
+        v = self._pend_host.tolist()
+        return v[0], v[1], v[4]
 
     def watch_overflow(self):
         """The same check without stopping the host: the flag is copied to pinned memory behind the work queued so

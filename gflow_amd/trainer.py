@@ -656,21 +656,45 @@ class SimpleGaussian:
                     last()
 
         st.settle = settle
+        st.unchecked = 0                 # iterations on reserved regions since the last look at the overflow words
+
+        def account():
+            """run()'s watch, read: iterations that stepped nothing are run now, on the exact path (they cannot be void
+            again); pair lists that overflowed or are more than half full (a looked-at iteration must not be the one that
+            overflows them) go the blocking way -- grown, made up for."""
+            got = eng.read_pending()
+            if got is None:
+                return
+            code, skipped, pairs = got
+            if code != 0 or 2 * pairs > eng.K_cap:
+                if code == 0:
+                    torch.cuda.current_stream().synchronize()
+                    eng.grow_pairs()
+                settle()
+                return
+            if skipped > 0:
+                eng.overflow[1:2].zero_()
+                eng.regions_outgrown = getattr(eng, "regions_outgrown", 0) + skipped
+                for _ in range(skipped):
+                    eng.iteration(use_graph=False, reserved=False)
 
         def one_iteration():
             iteration = st.iteration
             n_rendered = eng.N                       # rows this iteration projects (densification appends afterwards)
             snap = bool(snapshot_interval) and iteration % snapshot_interval == 0
             # Somebody LOOKS at this iteration's forward (snapshot, log entry, the error map of a densification).  An iteration
-            # can step nothing (settle, above) -- and its forward is then a render of truncated lists, and the ones before
-            # it may be waiting to be made up for, i.e. the splats are k optimiser steps behind the reference's at this
-            # index.  So such an iteration (a) bins on the exact path, where no tile can outgrow a region, and (b) is
-            # followed by ONE look at the two words: if k iterations have to be made up for (5 in the 27 050 of a 60-frame
-            # clip, all in the first steps of the first frame), k - 1 plain ones run and then this one AGAIN -- snapshot
-            # slot, loss sums and error map are overwritten by the forward of the splats after exactly ``iteration`` steps,
-            # as in the reference (trainer.py:573-582).  The look stops the host, not the device: the snapshot's side
-            # stream (or the other clips on the device) has ~130 us of composites to run meanwhile.
+            # can step nothing (settle, above) -- its forward is then a render of truncated lists, and while it waits to be made
+            # up for, the splats are a step behind the reference's at every later index (5 such iterations in the 27 050 of a
+            # 60-frame clip, all in the first steps of the first frame).  So (a) a looked-at iteration bins on the exact path,
+            # where no tile can outgrow a region, and so does the plain iteration in front of it; (b) BEFORE it is launched,
+            # the iterations up to the one before that are accounted for (run(): watch_pending behind them, one more iteration
+            # queued, then the look -- the host waits for work that is already done while the device runs that iteration; a
+            # blocking look behind every looked-at iteration cost a clip fit 2 %, tools/ab_trainer_flag.py) and made up for on
+            # the exact path.  The forward the host then looks at is the forward of the splats after exactly ``iteration``
+            # optimiser steps, as in the reference (trainer.py:573-582).
             looked_at = not is_plain(iteration)
+            if looked_at and self.exact_snapshots:
+                account()
             if tentative:
                 self.rasterisations_done += 1                # the reference's extra render of the moving set
             if snap:
@@ -722,8 +746,12 @@ class SimpleGaussian:
                         st.snap_stream = self._snap_stream
 
             launch()
-            if looked_at and self.exact_snapshots:
-                settle(last=launch)
+            if looked_at and self.exact_snapshots == "blocking":
+                settle(last=launch)                  # (the look BEHIND the iteration, and the iteration again: tests, A/B)
+            if looked_at:
+                st.unchecked = 0
+            else:
+                st.unchecked += 1
             self.rasterisations_done += 1
             self.iterations_done += 1
             rec_now = eng.rec                        # (densification may re-allocate the engine's buffers below)
@@ -783,8 +811,21 @@ class SimpleGaussian:
             between two graph launches, tools/graph_gap.py)"""
             end = st.iteration + n
             while st.iteration < end:
+                i = st.iteration
+                if is_plain(i) and not is_plain(i + 1) and self.exact_snapshots:
+                    # the plain iteration in front of a looked-at one: what ran before it is accounted for while IT runs
+                    # (one_iteration: account) -- on the exact path, so that nothing is left unaccounted for
+                    if st.unchecked:
+                        eng.watch_pending()
+                    n_rendered = eng.N
+                    eng.iteration(use_graph=self.use_graph, reserved=False)
+                    self.rasterisations_done += 2 if tentative else 1
+                    self.iterations_done += 1
+                    st.uv, st.depth, st.last_render = eng.rec[:n_rendered, 0:2], eng.rec[:n_rendered, 9:10], eng.render
+                    st.iteration += 1
+                    continue
                 k = 0
-                while k < 4 and st.iteration + k < end and is_plain(st.iteration + k):
+                while (k < 4 and i + k < end and is_plain(i + k) and (is_plain(i + k + 1) or not self.exact_snapshots)):
                     k += 1
                 if k < 2 or not self.use_graph:
                     one_iteration()
@@ -796,6 +837,7 @@ class SimpleGaussian:
                 self.iterations_done += b
                 st.uv, st.depth, st.last_render = eng.rec[:n_rendered, 0:2], eng.rec[:n_rendered, 9:10], eng.render
                 st.iteration += b
+                st.unchecked += b
 
         st.fn = one_iteration
         st.fn_batch = run
