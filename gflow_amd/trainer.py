@@ -664,6 +664,9 @@ class SimpleGaussian:
             overflows them) go the blocking way -- grown, made up for."""
             got = eng.read_pending()
             if got is None:
+                # (iterations run one at a time, st() instead of st.run(n): nothing was queued in between -- the blocking look)
+                if st.unchecked:
+                    settle()
                 return
             code, skipped, pairs = got
             if code != 0 or 2 * pairs > eng.K_cap:
@@ -817,6 +820,7 @@ class SimpleGaussian:
                     # (one_iteration: account) -- on the exact path, so that nothing is left unaccounted for
                     if st.unchecked:
                         eng.watch_pending()
+                        st.unchecked = 0
                     n_rendered = eng.N
                     eng.iteration(use_graph=self.use_graph, reserved=False)
                     self.rasterisations_done += 2 if tentative else 1
