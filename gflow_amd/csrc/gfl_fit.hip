@@ -203,7 +203,7 @@ static NextSched next_sched_reserving(const gfl_fit_state* st, const FitWs& w, i
 static int fit_check(const gfl_fit_state* st, const gfl_fit_hyper* hp) {
     if (!st || !hp) return GFL_ERR_INVALID;
     if (st->N < 0 || st->N > st->cap || st->W <= 0 || st->H <= 0 || st->K_cap < 0) return GFL_ERR_INVALID;
-    if (!st->params || !st->rec || !st->d_rec || !st->pose || !st->intr || !st->extr || !st->render || !st->final_T ||
+    if (!st->params || !st->rec || !st->pose || !st->intr || !st->extr || !st->render || !st->final_T ||
         !st->n_contrib || !st->tile_offsets || !st->ids || !st->tile_range || !st->overflow || !st->workspace)
         return GFL_ERR_INVALID;
     if (st->workspace_bytes < gfl_fit_workspace_bytes(st->cap, st->K_cap, st->W, st->H)) return GFL_ERR_WORKSPACE;

@@ -190,6 +190,37 @@ constexpr int FBL = GFL_FWD_LONG_BATCH;   // ... of the long-tile walk (512: for
 constexpr int FBB = 192;  // backward: 18.6 KB of LDS per workgroup -> 8 workgroups per CU (the tile queues of
                           // gfl_sched.hpp assume that all workgroups of a blend launch are resident)
 
+// "every lane of the workgroup says yes" with ONE barrier and no dependence on the block's shape (HIP's __syncthreads_and reads
+// blockDim / threadIdx.y for a flat thread id: loop-invariant values the forward blend then carried through its tile loop --
+// in scratch, 16 B per lane).  Two LDS counters that only grow, used in turn: a wave cannot reach its add of round r + 2
+// before every wave has read round r's total (the barrier of round r + 1 lies between).  waves = blockDim.x / 64.
+struct WgVote {
+    int32_t* cnt;        // [2] in LDS, zeroed once before the first vote (behind a barrier)
+    int base0, base1, round;
+};
+__device__ __forceinline__ WgVote wg_vote_init(int32_t* lds2) {
+    WgVote v;
+    v.cnt = lds2; v.base0 = 0; v.base1 = 0; v.round = 0;
+    return v;
+}
+__device__ __forceinline__ bool wg_all(WgVote& v, bool pred, int waves) {
+    const int r = v.round & 1;
+    if (__all(pred) && (threadIdx.x & 63) == 0) atomicAdd(&v.cnt[r], 1);
+    __syncthreads();
+    const int now = v.cnt[r];
+    const bool all = now - (r ? v.base1 : v.base0) == waves;
+    if (r) v.base1 = now; else v.base0 = now;
+    ++v.round;
+    return all;
+}
+
+// tile -> (tx, ty) without an integer division: inv_gx = 2^32 / gx rounded up (exact for tile < 2^16, which every tile id
+// in a queue item is)
+__device__ __forceinline__ void tile_xy(int tile, int gx, unsigned inv_gx, int& tx, int& ty) {
+    ty = (int)__umulhi((unsigned)tile, inv_gx);
+    tx = tile - ty * gx;
+}
+
 struct RecLDS {
     float4 p0, p1, p2;    // p2 = (b, depth, cutoff, radius bits)
 };
@@ -322,6 +353,7 @@ void launch_preprocess_bin(const float* params, const PreArgs& a, const uint8_t*
 void launch_colscan(const FitWs& w, int nblk, int T, int32_t* overflow, hipStream_t s);
 void launch_scatter(const gfl_fit_state* st, const FitWs& w, int nblk, int gx, int gy, bool ordered, hipStream_t s);
 // gfl_fit_fwd.hip
+inline unsigned inv_of(int gx) { return (unsigned)((((unsigned long long)1 << 32) + (unsigned)gx - 1) / (unsigned)gx); }
 void launch_blend_fwd(const gfl_fit_state* st, float bg, int gx, int grid, float* out, float* final_T, int32_t* n_contrib,
                       const TileQueue& q, const FitWs& w, int mode, const unsigned* cmap_mm, const float* cmap_lut, int split_min,
                       hipStream_t s);

@@ -81,7 +81,7 @@ __device__ __forceinline__ float row_last(float x) {
 __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(const float* __restrict__ rec,
                                                               const int32_t* __restrict__ ids,
                                                               const int32_t* __restrict__ tile_range, float bg, int W,
-                                                              int H, int gx, float* __restrict__ out,
+                                                              int H, int gx, unsigned inv_gx, float* __restrict__ out,
                                                               float* __restrict__ final_T,
                                                               int32_t* __restrict__ n_contrib, TileQueue queue,
                                                               float* __restrict__ ckpt, int mode,
@@ -99,19 +99,26 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     __shared__ int32_t s_gs[4][FBL / 64 + 1];        // ... and the number of hits in front of every 64-slot group
     __shared__ int32_t s_ticket;
     __shared__ int32_t s_simd[4];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid == 0) {
+    __shared__ int32_t s_vote[2];
+    if (threadIdx.x == 0) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         recs[FBL].p0 = z; recs[FBL].p1 = z; recs[FBL].p2 = z;
+        s_vote[0] = 0; s_vote[1] = 0;
     }
+    WgVote vote = wg_vote_init(s_vote);
     // block plan (gfl_sched.hpp): which 8x8 block of a whole tile this wave walks follows from the SIMD it sits on
     unsigned hw_id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
     const int simd = (hw_id >> 4) & 3;
-    if (lane == 0) s_simd[wave] = simd;
+    if ((threadIdx.x & 63) == 0) s_simd[threadIdx.x >> 6] = simd;
     __syncthreads();
     const bool simd_ok = ((1 << s_simd[0]) | (1 << s_simd[1]) | (1 << s_simd[2]) | (1 << s_simd[3])) == 15;
   for (bool first = true;; first = false) {
+    // (lane-derived values are formed again for every item, from an id the compiler cannot see through: hoisted out of this
+    //  loop they lived across both walks, and the kernel -- at its 96 registers -- kept four of them in scratch)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const TileItem item = next_item(queue, &s_ticket, first, true);
     if (item.tile < 0) {
         if (item.part < 0) break;                    // the queue is empty
@@ -132,7 +139,8 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
         tile = queue.count[owner] > 0 ? (queue.list[(size_t)owner * queue.cap_q] & 0xffff) : -1;
         if (tile < 0) continue;
     }
-    const int tx = tile % gx, ty = tile / gx;
+    int tx, ty;
+    tile_xy(tile, gx, inv_gx, tx, ty);
     const int start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
     const bool first_tile = item.part >= 0;
     const int blk = (first_tile && end - start > split_min) ? item.part : -1;
@@ -189,7 +197,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
 #ifdef GFL_TRACE
             { const long long now = wall_clock64(); tq_walk += now - tq_mark; tq_mark = now; }
 #endif
-            if (__syncthreads_and(alive == 0)) break;
+            if (wg_all(vote, alive == 0, 4)) break;
             {
                 // FBL / 256 entries per lane, their ids and then their records requested together
                 constexpr int PER = FBL / 256;
@@ -373,7 +381,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     const unsigned long long alive0 = __ballot(inside);            // every pixel of the box that is in the image
 
     for (int base = start; base < end; base += FB) {
-        if (__syncthreads_and(Tw == 0.f)) break;
+        if (wg_all(vote, Tw == 0.f, 4)) break;
         const int idx = base + tid;
         if (idx < end) {
             const int g = ids[idx];
@@ -616,7 +624,7 @@ __global__ void __launch_bounds__(256) snapshot_stage_kernel(StageCopy c) {
 void launch_blend_fwd(const gfl_fit_state* st, float bg, int gx, int grid, float* out, float* final_T, int32_t* n_contrib,
                       const TileQueue& q, const FitWs& w, int mode, const unsigned* cmap_mm, const float* cmap_lut, int split_min,
                       hipStream_t s) {
-    fused_blend_fwd_kernel<<<grid, 256, 0, s>>>(st->rec, st->ids, st->tile_range, bg, st->W, st->H, gx, out, final_T, n_contrib, q,
+    fused_blend_fwd_kernel<<<grid, 256, 0, s>>>(st->rec, st->ids, st->tile_range, bg, st->W, st->H, gx, inv_of(gx), out, final_T, n_contrib, q,
                                                 w.ckpt, mode, cmap_mm, cmap_lut, split_min, w.sched_fwd.work, w.sched.first_slot);
 }
 

@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
             d0.z *= 0.5f;
             d1.x *= 0.5f;
         }
-        {
+        if (d_rec) {                                        // (dL/d rec: an output nobody in the fit reads -- written when asked for)
             float4* o4 = reinterpret_cast<float4*>(d_rec + (size_t)i * REC);
             o4[0] = d0; o4[1] = d1; o4[2] = d2;
         }

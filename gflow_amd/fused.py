@@ -146,7 +146,7 @@ class FitEngine:
         self.adam_m = torch.zeros(cap, ROW, **f32)
         self.adam_v = torch.zeros(cap, ROW, **f32)
         self.rec = torch.zeros(cap, REC, **f32)
-        self.d_rec = torch.zeros(cap, REC, **f32)
+        self.d_rec = torch.zeros(cap, REC, **f32) if getattr(self, "want_d_rec", False) else None     # (an optional output)
         if old is not None and n:
             self.params[:n] = old[:n]
         k_min = getattr(self, "K_cap", 0) if getattr(self, "_K_grown", False) else 0      # (never below what an overflow asked for)

@@ -234,7 +234,7 @@ int gfl_step_increment(int32_t* d_step, gfl_stream_t stream);
  *                         r g b | pad pad   (raw, pre-activation values, trainer.py:79-86)
  *   rec   [cap][12]: u v A B | C opacity r g | b depth cutoff radius   (outputs: uv =
  *                    rec[:,0:2], depth = rec[:,9], what render.py:21-49 returns)
- *   d_rec [cap][12]: dL/d(rec[:,0:10])
+ *   d_rec [cap][12] or NULL: dL/d(rec[:,0:10]) of the last backward -- nothing in the iteration reads it; written when given
  * Optional per-splat inputs (NULL = term absent): flow_target[cap][2] + flow_w[cap]
  * (weight = mask/(2 count), trainer.py:511-528), still_target[cap][3] + still_w[cap]
  * (weight = mask/count, trainer.py:505-509), row_flags[cap] (bit0: still splat -- xyz gradient
