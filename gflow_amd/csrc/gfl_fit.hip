@@ -129,11 +129,7 @@ static FitWs carve(const gfl_fit_state* st) {
     w.sched.cap_q = (int)(((size_t)SCHED_MAX_QUEUES * sched_queue_capacity((int)T, 64)) / w.sched.nq);
     w.sched.split_min = 0;
     w.sched.xcd = 1;         // XCD-local bands + LPT in rounds wherever the grid allows it (sched_xcd_usable, next_sched_ok)
-    w.sched.pile_min = 0;
     w.sched_fwd = w.sched;
-    // backward: a first tile with more entries is a pile, its segments go to eight CUs of its XCD (gfl_fit_bwd.hip); needs the
-    // XCD-local queues (a helper is the queue nq / 8, 2 nq / 8 ... further on: the same XCD only if nq / 8 is a multiple of 8)
-    w.sched.pile_min = (w.sched.nq % 64 == 0) ? BWD_PILE_MIN : 0;
     w.sched_fwd.work = (int32_t*)p;
     p += up256(4 * T * sizeof(int32_t));
     w.sched_fwd.list = (int32_t*)p;
@@ -288,7 +284,7 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
     }
     {
         StageScope p(ST_BLEND_FWD, s);
-        const TileQueue q = {w.sched_fwd.list, w.sched_fwd.count, w.sched.counters, w.sched.nq, w.sched.cap_q, 0};
+        const TileQueue q = {w.sched_fwd.list, w.sched_fwd.count, w.sched.counters, w.sched.nq, w.sched.cap_q};
         launch_blend_fwd(st, hp->bg, gx, blend_grid(T, FWD_WG_PER_CU), st->render, st->final_T, st->n_contrib, q, w, 0, nullptr,
                          nullptr, fwd_split_min(), s);
         if (st->foot_flags) {
@@ -342,7 +338,7 @@ int gfl_fit_snapshot(const gfl_fit_state* st, const gfl_fit_hyper* hp, const flo
     if (st->N > 0) launch_rec_depth_range(st->rec, st->N, mm, s);
     for (int mode = 1; mode <= 2; ++mode) {
         // (the forward launch of the iteration used up the engine's own pull counters)
-        const TileQueue q = {w.sched_fwd.list, w.sched_fwd.count, pull + (mode - 1) * SCHED_MAX_QUEUES, w.sched.nq, w.sched.cap_q, 0};
+        const TileQueue q = {w.sched_fwd.list, w.sched_fwd.count, pull + (mode - 1) * SCHED_MAX_QUEUES, w.sched.nq, w.sched.cap_q};
         // (fewer workgroups per CU for these two launches, so that they disturb the fit's own kernels less, was measured in
         //  round 4: one per CU 0.871-0.886 s per 8-frame clip fit against 0.858-0.865 with five, three the same as five)
         launch_blend_fwd(st, hp->bg, gx, blend_grid(T, FWD_WG_PER_CU), mode == 1 ? img_dc : img_c, fT, nc, q, w, mode, mm, lut,
@@ -399,7 +395,7 @@ int gfl_render_bwd(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float
     const FitWs w = carve(st);
     {
         StageScope p(ST_BLEND_BWD, s);
-        const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters + w.sched.nq, w.sched.nq, w.sched.cap_q, w.sched.pile_min};
+        const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters + w.sched.nq, w.sched.nq, w.sched.cap_q};
         launch_blend_bwd(st, hp->bg, gx, blend_grid(T), 10, d_render, q, w, LossTail{}, s);
     }
     {
@@ -447,7 +443,7 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
     }
     {
         StageScope p(ST_BLEND_BWD, s);
-        const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters + w.sched.nq, w.sched.nq, w.sched.cap_q, w.sched.pile_min};
+        const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters + w.sched.nq, w.sched.nq, w.sched.cap_q};
         // sums that nobody reads are not formed: 6 in the camera-only stage, 7 while the colours are frozen (see the kernel)
         const int sums = hp->freeze_all_splats ? 6 : (hp->freeze_rgb ? 7 : 10);
         launch_blend_bwd(st, hp->bg, gx, blend_grid(T), sums, st->d_render, q, w, lt, s);

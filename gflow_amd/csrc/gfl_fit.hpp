@@ -187,10 +187,6 @@ constexpr int FB = 256;   // staged splats per batch (forward)
 #define GFL_FWD_LONG_BATCH 256
 #endif
 constexpr int FBL = GFL_FWD_LONG_BATCH;   // ... of the long-tile walk (512: forward inside a clip fit 56.6 against 52.7 us, round 4)
-#ifndef GFL_BWD_PILE_MIN
-#define GFL_BWD_PILE_MIN 640
-#endif
-constexpr int BWD_PILE_MIN = GFL_BWD_PILE_MIN;   // backward: a queue's first tile with a longer list has its segments walked on eight CUs
 constexpr int FBB = 192;  // backward: 18.6 KB of LDS per workgroup -> 8 workgroups per CU (the tile queues of
                           // gfl_sched.hpp assume that all workgroups of a blend launch are resident)
 

@@ -144,41 +144,10 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
     if (lane == 0) s_simd[wave] = simd;
     __syncthreads();
     const bool simd_ok = ((1 << s_simd[0]) | (1 << s_simd[1]) | (1 << s_simd[2]) | (1 << s_simd[3])) == 15;
-  // Items.  Index 0 .. HEAVY_PARTS-1 of a queue = the segments of its FIRST tile, side by side on this CU -- unless that tile
-  // is a PILE (a list of more than queue.pile_min entries: densification draws pixels with replacement, trainer.py:905, and
-  // leaves a thousand small splats in one tile).  A pile sits in one or two of the tile's 8x8 blocks, i.e. its segments'
-  // busy waves all land on the SIMD(s) the block plan gives those blocks: eight segments side by side on one CU end when
-  // that SIMD has issued the whole pile (CU end 88 us against a mean of 59 on real fits, tools/bwd_trace.py --fit).  So the
-  // segments 1 .. of a pile go to eight CUs of the pile's XCD: index p of queue q first walks segment p of the pile at the
-  // head of queue q + p nq / 8 (if there is one: phase 0), then segment p of its own first tile (unless that is a pile, whose
-  // segments 1 .. are walked elsewhere: phase 1).  The scheduler counts a pile's segments where they run (Sched.pile_min).
-  int idx = 0, phase = 2;
   for (bool first = true;; first = false) {
-    TileItem item;
-    if (phase >= 2) {
-        idx = next_index(queue, &s_ticket, first);
-        phase = idx < HEAVY_PARTS ? 0 : 2;
-    }
-    const int own_q = blockIdx.x % queue.nq;
-    if (phase == 0) {
-        phase = 1;
-        if (idx == 0 || queue.pile_min <= 0) continue;
-        const int owner = (own_q + idx * (queue.nq / HEAVY_PARTS)) % queue.nq;
-        item = item_at(queue, owner, 0, idx);
-        if (item.tile < 0 || tile_range[2 * item.tile + 1] - tile_range[2 * item.tile] <= queue.pile_min) continue;
-    } else if (phase == 1) {
-        phase = 2;
-        item = item_at(queue, own_q, 0, idx);
-        if (item.tile < 0) {
-            if (idx == 0) break;                       // an empty queue
-            continue;
-        }
-        if (idx > 0 && queue.pile_min > 0 && tile_range[2 * item.tile + 1] - tile_range[2 * item.tile] > queue.pile_min) continue;
-    } else {
-        item = item_at(queue, own_q, idx - (HEAVY_PARTS - 1), -1);
-        if (item.tile < 0) break;
-    }
+    const TileItem item = next_item(queue, &s_ticket, first, true);
     const int tile = item.tile;
+    if (tile < 0) break;
     const unsigned plan = item.plan;
     const bool plan_ok = simd_ok && ((1 << (plan & 3)) | (1 << ((plan >> 2) & 3)) | (1 << ((plan >> 4) & 3)) | (1 << ((plan >> 6) & 3))) == 15;
     // (the segments of a heavy first tile turning the plan by one SIMD each was measured slower: tools/experiments/README.md)

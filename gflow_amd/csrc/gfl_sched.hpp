@@ -51,8 +51,6 @@ struct Sched {
     int cap_q;           // capacity of one queue
     int split_min;       // forward schedule: a first tile with a longer list is walked on four CUs; 0: never
     int xcd;             // 1: XCD-local bands + snake deal (schedule_tiles_xcd) instead of the batched LPT
-    int pile_min;        // backward schedule: a first tile with a longer list is a PILE -- its segments 1.. are walked on other
-                         // CUs of its XCD (gfl_fit_bwd.hip), and count there; 0: never
 };
 
 __host__ __device__ inline int sched_queue_capacity(int T, int nq) { return 2 * ((T + nq - 1) / nq) + 8; }
@@ -482,26 +480,6 @@ __device__ void schedule_tiles_xcd(const int32_t* __restrict__ tile_counts, int 
                 ++n_items;
                 load += wt;
             }
-            if (k == 0 && sc.pile_min > 0) {
-                // backward schedule: the segments 1 .. parts-1 of a PILE at the head of a queue are walked by the segment
-                // workgroups of other queues of the same XCD (segment p of queue q's pile by queue q - p NQ / 8: the same
-                // map as the kernel's); every one of them costs its CU a parts-th of the pile
-                if (cnt > j) {
-                    const int own = ord16[b0 + j];
-                    const int n_own = tile_counts[own];
-                    if (n_own > sc.pile_min) load -= w16[own] - w16[own] / heavy_parts(n_own);
-                }
-#pragma unroll
-                for (int b = 1; b < HEAVY_PARTS; ++b) {
-                    const int owner = (q + b * (NQ / 8)) % NQ;
-                    const int ox = owner & 7, oj = owner >> 3;
-                    if (g_base[ox + 1] - g_base[ox] > oj) {
-                        const int ot = ord16[g_base[ox] + oj];
-                        const int n_ot = tile_counts[ot];
-                        if (n_ot > sc.pile_min && heavy_parts(n_ot) > b) load += w16[ot] / heavy_parts(n_ot);
-                    }
-                }
-            }
             if (k == 0 && sc.split_min > 0) {
                 // forward schedule: a long first tile costs its own CU a quarter, the other three quarters go to the queues
                 // that help it (next_item: items 1..3 of queue q walk blocks of the first tile of queue q + p nq/4)
@@ -529,7 +507,6 @@ struct TileQueue {
     int32_t* counter;    // [nq] for this launch
     int nq;
     int cap_q;
-    int pile_min;        // Sched.pile_min of the schedule these queues come from (backward launch; 0 elsewhere)
 };
 
 // Item of a queue.  part: -1 = the whole tile; 0 .. HEAVY_PARTS-1 = that segment of the queue's
@@ -541,26 +518,25 @@ struct TileItem {
     unsigned plan;   // block plan (ITEM_PLAN_*): plan >> (2 * simd) & 3 = the block the wave on that SIMD walks
 };
 
-// the next INDEX into this workgroup's queue: the slot number first (no atomic), later pulls through the queue's counter.
-// Whole workgroup.  Indices 0 .. HEAVY_PARTS-1 of a backward launch are the segments of the queue's first tile, index
-// HEAVY_PARTS-1 + k its k-th item; a forward launch's index k is its k-th item.
-__device__ __forceinline__ int next_index(const TileQueue& q, int32_t* s_ticket, bool first) {
-    if (first) return blockIdx.x / q.nq;
-    __syncthreads();                                 // the previous tile's LDS traffic is complete
-    if (threadIdx.x == 0) *s_ticket = (int)(gridDim.x / q.nq) + atomicAdd(&q.counter[blockIdx.x % q.nq], 1);
-    __syncthreads();
-    return *s_ticket;
-}
-
-// item k of queue `queue` (tile -1: there is none); sets the waves' issue priority to the item's
-__device__ __forceinline__ TileItem item_at(const TileQueue& q, int queue, int k, int part) {
+// next item of this workgroup's queue.  Whole workgroup.  `split`: backward launch.
+__device__ __forceinline__ TileItem next_item(const TileQueue& q, int32_t* s_ticket, bool first, bool split) {
     TileItem it;
-    it.queue = queue;
-    it.part = part;
+    it.queue = blockIdx.x % q.nq;
+    it.part = -1;
     it.tile = -1;
     it.plan = ITEM_PLAN_IDENTITY;
-    if (k >= q.count[queue]) return it;
-    const int item = q.list[(size_t)queue * q.cap_q + k];
+    int idx = blockIdx.x / q.nq;                     // first pull: the slot number, no atomic
+    if (!first) {
+        __syncthreads();                             // the previous tile's LDS traffic is complete
+        if (threadIdx.x == 0) *s_ticket = (int)(gridDim.x / q.nq) + atomicAdd(&q.counter[it.queue], 1);
+        __syncthreads();
+        idx = *s_ticket;
+    }
+    // backward: the first tile of the queue is HEAVY_PARTS items
+    const int k = split ? max(idx - (HEAVY_PARTS - 1), 0) : idx;
+    if (split && idx < HEAVY_PARTS) it.part = idx;   // (also when this queue is empty: the forward pass helps other queues)
+    if (k >= q.count[it.queue]) return it;
+    const int item = q.list[(size_t)it.queue * q.cap_q + k];
     it.tile = item & 0xffff;
     it.plan = ((unsigned)item >> ITEM_PLAN_SHIFT) & 0xffu;
     const int prio = (item >> 28) & 3;
@@ -569,14 +545,6 @@ __device__ __forceinline__ TileItem item_at(const TileQueue& q, int queue, int k
     else if (prio == 1) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
     return it;
-}
-
-// next item of this workgroup's queue.  Whole workgroup.  `split`: the first tile of the queue is HEAVY_PARTS items.
-__device__ __forceinline__ TileItem next_item(const TileQueue& q, int32_t* s_ticket, bool first, bool split) {
-    const int idx = next_index(q, s_ticket, first);
-    const int k = split ? max(idx - (HEAVY_PARTS - 1), 0) : idx;
-    // (part is set also when this queue is empty: the forward pass helps other queues)
-    return item_at(q, blockIdx.x % q.nq, k, (split && idx < HEAVY_PARTS) ? idx : -1);
 }
 
 }  // namespace gfl
