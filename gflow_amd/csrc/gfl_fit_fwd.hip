@@ -78,13 +78,52 @@ __device__ __forceinline__ float row_last(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x10 | (0x0F << 5)));
 }
 
+// Reads of the staged planes INSIDE a walk, while the next batch's global_load_lds pieces are in flight towards the other half
+// of the same array: written as ordinary loads the compiler drains every outstanding LDS-DMA first (s_waitcnt vmcnt(0) in front
+// of the first ds_read of the array: it cannot tell the halves apart) and the prefetch turns into a plain load.  These are the
+// three (or twelve) ds_read_b128 and their wait, spelled out; the planes lie STAGE_PLANE bytes apart.
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int STAGE_PLANE = (FB + 1) * 16;
+__device__ __forceinline__ unsigned lds_offset(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ float4 as_float4(v4f v) { return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void staged_record(const float4* plane0_entry, float4& p0, float4& p1, float4& p2) {
+    v4f a, b, c;
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:%4\n\tds_read_b128 %2, %3 offset:%5\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c)
+                 : "v"(lds_offset(plane0_entry)), "n"(STAGE_PLANE), "n"(2 * STAGE_PLANE)
+                 : "memory");
+    p0 = as_float4(a); p1 = as_float4(b); p2 = as_float4(c);
+}
+__device__ __forceinline__ void staged_records4(const float4* plane0, const int (&j)[4], float4 (&q0)[4], float4 (&q1)[4],
+                                                float4 (&q2)[4]) {
+    v4f a[4], b[4], c[4];
+    const unsigned base = lds_offset(plane0);
+    const unsigned o0 = base + 16u * (unsigned)j[0], o1 = base + 16u * (unsigned)j[1], o2 = base + 16u * (unsigned)j[2],
+                   o3 = base + 16u * (unsigned)j[3];
+    asm volatile("ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:%16\n\tds_read_b128 %2, %12 offset:%17\n\t"
+                 "ds_read_b128 %3, %13\n\tds_read_b128 %4, %13 offset:%16\n\tds_read_b128 %5, %13 offset:%17\n\t"
+                 "ds_read_b128 %6, %14\n\tds_read_b128 %7, %14 offset:%16\n\tds_read_b128 %8, %14 offset:%17\n\t"
+                 "ds_read_b128 %9, %15\n\tds_read_b128 %10, %15 offset:%16\n\tds_read_b128 %11, %15 offset:%17\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(a[0]), "=&v"(b[0]), "=&v"(c[0]), "=&v"(a[1]), "=&v"(b[1]), "=&v"(c[1]), "=&v"(a[2]), "=&v"(b[2]),
+                   "=&v"(c[2]), "=&v"(a[3]), "=&v"(b[3]), "=&v"(c[3])
+                 : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "n"(STAGE_PLANE), "n"(2 * STAGE_PLANE)
+                 : "memory");
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { q0[u] = as_float4(a[u]); q1[u] = as_float4(b[u]); q2[u] = as_float4(c[u]); }
+}
+
+// (mode: a template parameter -- the fit's forward, mode 0, carries none of the snapshot composites' code or constants)
+template <int mode>
 __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(const float* __restrict__ rec,
                                                               const int32_t* __restrict__ ids,
                                                               const int32_t* __restrict__ tile_range, float bg, int W,
                                                               int H, int gx, unsigned inv_gx, float* __restrict__ out,
                                                               float* __restrict__ final_T,
                                                               int32_t* __restrict__ n_contrib, TileQueue queue,
-                                                              float* __restrict__ ckpt, int mode,
+                                                              float* __restrict__ ckpt,
                                                               const unsigned* __restrict__ cmap_mm,
                                                               const float* __restrict__ cmap_lut, int split_min,
                                                               int32_t* __restrict__ tile_work,
@@ -93,7 +132,10 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     // lists with other per-splat values, made while a record is staged: mode 1 = colour := turbo map of the splat's
     // depth (apply_float_colormap(non_zero=True), range in cmap_mm), mode 2 = unit blob at the centre (conic 1 0 1,
     // opacity 1).
-    __shared__ RecLDS recs[FBL + 1];         // recs[FBL]: an all-zero record (opacity 0: never blends)
+    // Staged records, two batches deep, one plane per 16-byte third of a record (p0 = u v A B, p1 = C o r g, p2 = b depth cutoff
+    // radius): global_load_lds writes a wave's 64 pieces side by side.  Entry [FB] of every plane: an all-zero record (opacity
+    // 0: never blends).
+    __shared__ __attribute__((aligned(16))) float4 s_rec[2][3][FB + 1];
     __shared__ unsigned char s_mask[FBL];
     __shared__ unsigned short s_hits[4][FBL];        // long first tiles: a wave's (= a 4x4 quarter's) hit list of the staged batch
     __shared__ int32_t s_gs[4][FBL / 64 + 1];        // ... and the number of hits in front of every 64-slot group
@@ -102,7 +144,8 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     __shared__ int32_t s_vote[2];
     if (threadIdx.x == 0) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        recs[FBL].p0 = z; recs[FBL].p1 = z; recs[FBL].p2 = z;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s_rec[k / 3][k % 3][FB] = z;
         s_vote[0] = 0; s_vote[1] = 0;
     }
     WgVote vote = wg_vote_init(s_vote);
@@ -119,6 +162,35 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    // A batch of 256 list entries is staged WITHOUT registers: a lane requests the three 16-byte thirds of its entry's record
+    // straight into LDS (global_load_lds_dwordx4: wave-uniform LDS base + lane x 16, hence the planes), for the batch AFTER the
+    // one being walked -- and the ids of the batch after that as an ordinary load.  The two dependent round trips per batch
+    // (id, then record: 3-4 us of every batch of a pile's 45 us chain, tools/bwd_trace.py --fwd --fit) then run beside the
+    // walk instead of in front of it.  (Round 4 prefetched the ids alone, into a register that lived across the walk: slower.)
+    auto request_records = [&](int buf, int id) {
+        const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)id * REC);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)r4,
+                                         (__attribute__((address_space(3))) void*)&s_rec[buf][0][64 * wave], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(r4 + 1),
+                                         (__attribute__((address_space(3))) void*)&s_rec[buf][1][64 * wave], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(r4 + 2),
+                                         (__attribute__((address_space(3))) void*)&s_rec[buf][2][64 * wave], 16, 0, 0);
+    };
+    // this lane's entry of the batch in `buf` once it has landed: the snapshot modes' per-splat values, the culling mask
+    auto prepare_entry = [&](int buf, bool have, int x0, int y0, int box) {
+        if (!have) return;
+        float4 p0 = s_rec[buf][0][tid], p1 = s_rec[buf][1][tid], p2 = s_rec[buf][2][tid];
+        if (mode == 1) {
+            const float3 col = cmap_nonzero_lookup(p2.y, cmap_mm, cmap_lut);
+            p1.z = col.x; p1.w = col.y; p2.x = col.z;
+            s_rec[buf][1][tid] = p1; s_rec[buf][2][tid] = p2;
+        } else if (mode == 2) {
+            p0.z = 1.f; p0.w = 0.f; p1.x = 1.f; p1.y = 1.f;
+            p2.z = p2.z < 0.f ? p2.z : alpha_cutoff(1.f, 1.f);
+            s_rec[buf][0][tid] = p0; s_rec[buf][1][tid] = p1; s_rec[buf][2][tid] = p2;
+        }
+        s_mask[tid] = (unsigned char)block_mask(p0, p1, p2.z, x0, y0, box);
+    };
     const TileItem item = next_item(queue, &s_ticket, first, true);
     if (item.tile < 0) {
         if (item.part < 0) break;                    // the queue is empty
@@ -193,37 +265,21 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
         long long tq_stage = 0, tq_walk = 0, tq_mark = wall_clock64();
         int tq_steps = 0;
 #endif
-        for (int base = start; base < end; base += FBL) {
+        int buf = 0;
+        request_records(0, start + tid < end ? ids[start + tid] : 0);
+        int id_next = start + FB + tid < end ? ids[start + FB + tid] : 0;
+        for (int base = start; base < end; base += FBL, buf ^= 1) {
 #ifdef GFL_TRACE
             { const long long now = wall_clock64(); tq_walk += now - tq_mark; tq_mark = now; }
 #endif
-            if (wg_all(vote, alive == 0, 4)) break;
-            {
-                // FBL / 256 entries per lane, their ids and then their records requested together
-                constexpr int PER = FBL / 256;
-                int gidx[PER];
-#pragma unroll
-                for (int e = 0; e < PER; ++e) gidx[e] = base + tid + 256 * e < end ? ids[base + tid + 256 * e] : -1;
-                // (requesting the NEXT batch's ids here, a whole walk ahead, was measured again in round 4: forward inside a
-                //  clip fit 53.7 against 50.7 us without it, same box)
-#pragma unroll 1
-                for (int e = 0; e < PER; ++e) {          // (one record at a time: two in flight spilled the walk's registers)
-                    if (gidx[e] < 0) continue;
-                    const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)gidx[e] * REC);
-                    float4 p0 = r4[0], p1 = r4[1], p2 = r4[2];
-                    if (mode == 1) {
-                        const float3 col = cmap_nonzero_lookup(p2.y, cmap_mm, cmap_lut);
-                        p1.z = col.x; p1.w = col.y; p2.x = col.z;
-                    } else if (mode == 2) {
-                        p0.z = 1.f; p0.w = 0.f; p1.x = 1.f; p1.y = 1.f;
-                        p2.z = p2.z < 0.f ? p2.z : alpha_cutoff(1.f, 1.f);
-                    }
-                    const int sl = tid + 256 * e;
-                    recs[sl].p0 = p0; recs[sl].p1 = p1; recs[sl].p2 = p2;
-                    s_mask[sl] = (unsigned char)block_mask(p0, p1, p2.z, tx * GFL_TILE + (blk & 1) * 8, ty * GFL_TILE + (blk >> 1) * 8, 4);
-                }
-            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the batch (and id_next) have arrived
+            if (wg_all(vote, alive == 0, 4)) break;              // ... everybody's
+            prepare_entry(buf, base + tid < end, tx * GFL_TILE + (blk & 1) * 8, ty * GFL_TILE + (blk >> 1) * 8, 4);
             __syncthreads();
+            if (base + FB < end) {                               // the next batch is on its way while this one is walked
+                request_records(buf ^ 1, id_next);
+                id_next = base + 2 * FB + tid < end ? ids[base + 2 * FB + tid] : 0;
+            }
 #ifdef GFL_TRACE
             { const long long now = wall_clock64(); tq_stage += now - tq_mark; tq_mark = now; }
 #endif
@@ -253,7 +309,9 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                 const int sl = 64 * k + lane;
                 bool hit = sl < cnt && ((s_mask[sl] >> wave) & 1);
                 if (!all_alive && hit) {
-                    const BlockTest t = block_test(recs[sl].p0, recs[sl].p1, recs[sl].p2.z);
+                    float4 r0, r1, r2;
+                    staged_record(&s_rec[buf][0][sl], r0, r1, r2);
+                    const BlockTest t = block_test(r0, r1, r2.z);
                     hit = box_hit(t, bx_lo, bx_hi, by_lo, by_hi);
                 }
                 const unsigned long long bal = __ballot(hit);
@@ -280,7 +338,8 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                     const bool have = h + ls < h_hi;
                     const int j = have ? (int)s_hits[wave][h + ls] : FBL;
                     const int pos1 = base - start + j + 1;
-                    const float4 q0 = recs[j].p0, q1 = recs[j].p1, q2 = recs[j].p2;
+                    float4 q0, q1, q2;
+                    staged_record(&s_rec[buf][0][j], q0, q1, q2);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const float fyq = (float)(qy0 + g);
@@ -380,24 +439,18 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     int last = 0;
     const unsigned long long alive0 = __ballot(inside);            // every pixel of the box that is in the image
 
-    for (int base = start; base < end; base += FB) {
-        if (wg_all(vote, Tw == 0.f, 4)) break;
-        const int idx = base + tid;
-        if (idx < end) {
-            const int g = ids[idx];
-            const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g * REC);
-            float4 p0 = r4[0], p1 = r4[1], p2 = r4[2];
-            if (mode == 1) {
-                const float3 col = cmap_nonzero_lookup(p2.y, cmap_mm, cmap_lut);
-                p1.z = col.x; p1.w = col.y; p2.x = col.z;
-            } else if (mode == 2) {
-                p0.z = 1.f; p0.w = 0.f; p1.x = 1.f; p1.y = 1.f;
-                p2.z = p2.z < 0.f ? p2.z : alpha_cutoff(1.f, 1.f);
-            }
-            recs[tid].p0 = p0; recs[tid].p1 = p1; recs[tid].p2 = p2;
-            s_mask[tid] = (unsigned char)block_mask(p0, p1, p2.z, org_x, org_y);
-        }
+    int buf = 0;
+    request_records(0, start + tid < end ? ids[start + tid] : 0);
+    int id_next = start + FB + tid < end ? ids[start + FB + tid] : 0;
+    for (int base = start; base < end; base += FB, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of the batch (and id_next) have arrived
+        if (wg_all(vote, Tw == 0.f, 4)) break;                   // ... everybody's
+        prepare_entry(buf, base + tid < end, org_x, org_y, 8);
         __syncthreads();
+        if (base + FB < end) {                                   // the next batch is on its way while this one is walked
+            request_records(buf ^ 1, id_next);
+            id_next = base + 2 * FB + tid < end ? ids[base + 2 * FB + tid] : 0;
+        }
         const int cnt = min(FB, end - base);
         if (__all(Tw == 0.f)) continue;      // this wave is finished; keep meeting the barriers
         for (int c0 = 0; c0 < cnt; c0 += 64) {
@@ -425,7 +478,9 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                     const int xl = __builtin_ctz(cols), xh = 31 - __builtin_clz(cols);
                     const int yl = (int)__builtin_ctzll(alive) >> 3, yh = (63 - (int)__builtin_clzll(alive)) >> 3;
                     if (hit) {
-                        const BlockTest t = block_test(recs[slot].p0, recs[slot].p1, recs[slot].p2.z);
+                        float4 r0, r1, r2;
+                        staged_record(&s_rec[buf][0][slot], r0, r1, r2);
+                        const BlockTest t = block_test(r0, r1, r2.z);
                         hit = box_hit(t, (float)(px0w + xl), (float)(px0w + xh), (float)(py0w + yl), (float)(py0w + yh));
                     }
                 }
@@ -452,8 +507,8 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                 for (int u = 0; u < FWD_UNITS; ++u) trace_units += j[u] != FBL ? 1 : 0;
 #endif
                 float4 q0[FWD_UNITS], q1[FWD_UNITS], q2[FWD_UNITS];
-#pragma unroll
-                for (int u = 0; u < FWD_UNITS; ++u) { q0[u] = recs[j[u]].p0; q1[u] = recs[j[u]].p1; q2[u] = recs[j[u]].p2; }
+                static_assert(FWD_UNITS == 4, "staged_records4 reads four records");
+                staged_records4(&s_rec[buf][0][0], j, q0, q1, q2);
                 float al[FWD_UNITS];
                 bool val[FWD_UNITS];
 #pragma unroll
@@ -624,8 +679,9 @@ __global__ void __launch_bounds__(256) snapshot_stage_kernel(StageCopy c) {
 void launch_blend_fwd(const gfl_fit_state* st, float bg, int gx, int grid, float* out, float* final_T, int32_t* n_contrib,
                       const TileQueue& q, const FitWs& w, int mode, const unsigned* cmap_mm, const float* cmap_lut, int split_min,
                       hipStream_t s) {
-    fused_blend_fwd_kernel<<<grid, 256, 0, s>>>(st->rec, st->ids, st->tile_range, bg, st->W, st->H, gx, inv_of(gx), out, final_T, n_contrib, q,
-                                                w.ckpt, mode, cmap_mm, cmap_lut, split_min, w.sched_fwd.work, w.sched.first_slot);
+    auto kern = mode == 0 ? fused_blend_fwd_kernel<0> : (mode == 1 ? fused_blend_fwd_kernel<1> : fused_blend_fwd_kernel<2>);
+    kern<<<grid, 256, 0, s>>>(st->rec, st->ids, st->tile_range, bg, st->W, st->H, gx, inv_of(gx), out, final_T, n_contrib, q, w.ckpt,
+                              cmap_mm, cmap_lut, split_min, w.sched_fwd.work, w.sched.first_slot);
 }
 
 void launch_footprint(const gfl_fit_state* st, int gx, int T, hipStream_t s) {
