@@ -183,8 +183,10 @@ constexpr int FWD_SPLIT_MIN = 448;     // forward: a queue's first tile is walke
                                        // (round 4 sweep, sixteen-splat steps: bench-scene forward 47.0 / 40.8 / 39.7 / 39.7 us and 4-frame clip
                                        //  fit 0.483 / 0.485 / 0.490 / 0.523 s at 256 / 448 / 640 / never)
 constexpr int FB = 256;   // staged splats per batch (forward)
-constexpr int FBL = FB;   // ... of the long-tile walk (512 measured slower in round 4: 56.6 against 52.7 us inside a clip fit); the two
-                          // walks share the double-buffered staging planes
+#ifndef GFL_FWD_LONG_BATCH
+#define GFL_FWD_LONG_BATCH 256
+#endif
+constexpr int FBL = GFL_FWD_LONG_BATCH;   // ... of the long-tile walk (512: forward inside a clip fit 56.6 against 52.7 us, round 4)
 constexpr int FBB = 192;  // backward: 18.6 KB of LDS per workgroup -> 8 workgroups per CU (the tile queues of
                           // gfl_sched.hpp assume that all workgroups of a blend launch are resident)
 

@@ -483,21 +483,14 @@ __device__ void schedule_tiles_xcd(const int32_t* __restrict__ tile_counts, int 
             if (k == 0 && sc.split_min > 0) {
                 // forward schedule: a long first tile costs its own CU a quarter, the other three quarters go to the queues
                 // that help it (next_item: items 1..3 of queue q walk blocks of the first tile of queue q + p nq/4)
-                // (block p's share of the tile's work by the last forward's count, frac4: a pile sits in ONE of the four blocks,
-                //  and a quarter each put the CU that walks it at 2 090 units against a mean of 1 364 on a real fit, round 5)
-                auto share = [&](int tile, int blk) {
-                    const int w = w16[tile];
-                    if (!frac4 || tile >= SCHED_PLAN_TILES) return w >> 2;
-                    return (int)(((frac4[tile] >> (8 * blk)) & 255u) * (unsigned)w) / 255;
-                };
-                if (cnt > j && tile_counts[ord16[b0 + j]] > sc.split_min) load -= w16[ord16[b0 + j]] - share(ord16[b0 + j], 0);
+                if (cnt > j && tile_counts[ord16[b0 + j]] > sc.split_min) load -= w16[ord16[b0 + j]] - (w16[ord16[b0 + j]] >> 2);
 #pragma unroll
                 for (int b = 1; b < 4; ++b) {
                     const int owner = (q + b * (NQ / 4)) % NQ;
                     const int ox = owner & 7, oj = owner >> 3;
                     if (g_base[ox + 1] - g_base[ox] > oj) {
                         const int ot = ord16[g_base[ox] + oj];
-                        if (tile_counts[ot] > sc.split_min) load += share(ot, b);
+                        if (tile_counts[ot] > sc.split_min) load += w16[ot] >> 2;
                     }
                 }
             }
