@@ -529,6 +529,11 @@ class FitEngine:
         self._pend_event = torch.cuda.Event()
         self._pend_event.record()
 
+    def pending_ready(self):
+        """False while a ``watch_pending`` copy has not landed yet (``read_pending`` would wait)."""
+        ev = getattr(self, "_pend_event", None)
+        return ev is None or ev.query()
+
     def read_pending(self):
         """(code, iterations that stepped nothing, pair count) of the last ``watch_pending``; None without one."""
         ev = getattr(self, "_pend_event", None)

@@ -657,6 +657,7 @@ class SimpleGaussian:
 
         st.settle = settle
         st.unchecked = 0                 # iterations on reserved regions since the last look at the overflow words
+        st.yielding = False              # run() returns early rather than wait for a look (train_steps with ``chunk``)
 
         def account():
             """run()'s watch, read: iterations that stepped nothing are run now, on the exact path (they cannot be void
@@ -815,6 +816,8 @@ class SimpleGaussian:
             end = st.iteration + n
             while st.iteration < end:
                 i = st.iteration
+                if st.yielding and not is_plain(i) and self.exact_snapshots and not eng.pending_ready():
+                    return                           # (the caller comes back: train_steps)
                 if is_plain(i) and not is_plain(i + 1) and self.exact_snapshots:
                     # the plain iteration in front of a looked-at one: what ran before it is accounted for while IT runs
                     # (one_iteration: account) -- on the exact path, so that nothing is left unaccounted for
@@ -872,11 +875,11 @@ class SimpleGaussian:
         W, H, dev = self.W, self.H, self.device
         st = self.make_stepper(iterations=iterations, snapshot_interval=snapshot_interval, **kw)
         if chunk:
-            done = 0
-            while done < iterations:
-                n = min(int(chunk), iterations - done)
-                st.run(n)
-                done += n
+            # (several fits taking turns on one device from ONE host thread: a fit that would have to WAIT for its look at the
+            #  overflow words hands the turn on instead -- run() returns early -- so that the others' queues do not run dry)
+            st.yielding = True
+            while st.iteration < iterations:
+                st.run(min(int(chunk), iterations - st.iteration))
                 yield
         else:
             st.run(iterations)

@@ -36,7 +36,7 @@ for q, tiles in enumerate(queues):
     for t in tiles.tolist():
         band[t // gx, t % gx] = q % 8
 assert int((band < 0).sum()) == 0
-pad = torch.nn.functional.pad(band, (1, 1, 1, 1), mode="replicate")
+pad = torch.nn.functional.pad(band[None, None].float(), (1, 1, 1, 1), mode="replicate")[0, 0].long()
 same = torch.ones(gy, gx, dtype=torch.bool)
 for dy in (0, 1, 2):
     for dx in (0, 1, 2):
