@@ -303,7 +303,10 @@ __global__ void __launch_bounds__(SORT_THREADS, 8) bin_tile_sort_kernel(const in
             m += c;
         }
         const int n_lower = half == 0 ? m : n - m;
-        if (m <= SORT_XB * SORT_THREADS && n - m <= SORT_XB * SORT_THREADS) {
+        // (a split list has at most 2048 keys: with SORT_XB * SORT_THREADS = 2048 slots in the exchange buffer -- the shipped 512
+        //  lanes -- either half always fits and the fallback below does not exist in the binary; a 256-lane build keeps it)
+        constexpr bool HALVES_ALWAYS_FIT = SORT_XB * SORT_THREADS >= 2048;
+        if (HALVES_ALWAYS_FIT || (m <= SORT_XB * SORT_THREADS && n - m <= SORT_XB * SORT_THREADS)) {
 #pragma unroll
             for (int e = 0; e < EP; ++e) {
                 const unsigned long long bal = __ballot(keep[e]);
@@ -324,8 +327,8 @@ __global__ void __launch_bounds__(SORT_THREADS, 8) bin_tile_sort_kernel(const in
             SORT_TRACE(3);
             return;
         }
-        // (a pivot so lopsided that one half does not fit the buffer -- sampled medians do not do that, but it must be
-        //  right if they do --: the first workgroup sorts the whole list the ordinary way)
+        // (narrower builds only: a pivot so lopsided that one half does not fit the buffer -- sampled medians do not do that,
+        //  but it must be right if they do --: the first workgroup sorts the whole list the ordinary way)
         if (half == 1) return;
         __syncthreads();
     }
