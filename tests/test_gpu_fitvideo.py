@@ -516,3 +516,42 @@ def test_fit_clip_renders_the_trajectories_of_every_frame():
     up = t["images"][:, 1].astype(np.float64)
     assert (up >= t["images"][:, 0].astype(np.float64) - 1).all()
     assert t["split_interval"] is None or 0 <= t["split_interval"] <= n_seeds
+
+
+def test_concurrent_fits_draw_their_trajectories_too():
+    """fit_clips_concurrent with the trajectory work switched on: every clip records its frames and draws them at its own end,
+    the others keep their turns (a fit that would wait for its look at the overflow words hands the turn on: run() returns
+    early) -- the same counts as the fits one after another."""
+    from gflow_amd.fit_video import fit_clip, fit_clips_concurrent
+    cfg = dict(SMALL, traj_num=100, traj_offset=2)
+    clips = [_clip(seed=s) for s in (21, 22)]
+    alone = [fit_clip(c, DEV, cfg, seed=i, snapshot_interval=10) for i, c in enumerate(clips)]
+    together = fit_clips_concurrent(clips, DEV, cfg, seeds=[0, 1], snapshot_interval=10, chunk=7)
+    torch.cuda.synchronize()
+    for a, b in zip(alone, together):
+        assert b["iterations"] == a["iterations"] and b["rasterisations"] == a["rasterisations"]
+        assert abs(a["psnr_sum"] - b["psnr_sum"]) / 3 < 0.7, (a, b)
+
+
+def test_host_writes_invalidate_the_reserved_regions():
+    """FitEngine bins into the regions the last iteration reserved only while the splats are those it reserved them for: a new
+    row count, new rows, a restored state or an explicit invalidate_regions() (the trainer: a new pose at every stage) send the
+    next iteration down the exact path -- and the one after that back onto the regions."""
+    from tests.test_gpu_fused import POSE, _engine, _raw_from_scene, _targets
+    from tests.scenes import random_scene
+    s = random_scene(1500, 168, 120, seed=5, sigma_px=2.5, tilt=False)
+    raw = _raw_from_scene(s)
+    img, dep = _targets(s["H"], s["W"], 5)
+    eng = _engine(raw, s, img, dep, pose=POSE, lambda_rgb=1.0, lr=1e-3, lr_camera=0.0, total_iters=50)
+    if not eng.lib.gfl_fit_reserved_supported(__import__("ctypes").byref(eng.state()), __import__("ctypes").byref(eng.hp)):
+        pytest.skip("reserved tile regions are switched off (GFL_RESERVED=0)")
+    assert eng._reserved_flag() == 0
+    eng.iteration()
+    assert eng._reserved_flag() == eng.GFL_ITER_RESERVED
+    for act in (eng.invalidate_regions, lambda: eng.set_count(eng.N), lambda: eng.restore_state(eng.save_state())):
+        act()
+        assert eng._reserved_flag() == 0
+        eng.iteration()
+        assert eng._reserved_flag() == eng.GFL_ITER_RESERVED
+    eng.check_overflow()
+    assert int(eng.step.item()) == 4

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of one environment switch on ONE box on the clip fit (4 frames x 6 fits, min / median) and on bench.py's step
-#   gpurun -- bash tools/ab_clip.sh GFL_BWD_ROTATE 1 0 [repeats]
+#   gpurun -- bash tools/ab_clip.sh GFL_RESERVED 1 0 [repeats]
 VAR=$1; A=$2; B=$3; R=${4:-2}
 for r in $(seq 1 $R); do
   for v in $A $B; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of one environment switch on ONE box, alternating: bench.py's step (pinned window) with VAR=A and VAR=B, R times each.
-#   gpurun -- bash tools/ab_env.sh GFL_NEXT_PRE 1 0 [repeats] [extra bench flags]
+#   gpurun -- bash tools/ab_env.sh GFL_RESERVED 1 0 [repeats] [extra bench flags]
 VAR=$1; A=$2; B=$3; R=${4:-3}; shift 4
 for r in $(seq 1 $R); do
   for v in $A $B; do

@@ -1,5 +1,5 @@
 """Stage times (library's HIP events) of the camera-only iterations of a clip's second frame.
-    gpurun -- python tools/camera_stage_time.py        (try GFL_BWD_GEOM_ONLY=0)"""
+    gpurun -- python tools/camera_stage_time.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
