@@ -73,15 +73,6 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // MODE 2: write gt_stats, nothing else.
 // KEEP: an occlusion mask is given (a second template parameter instead of a pointer test per load: the staging loads
 // below have to be straight-line code to be issued together).
-// Round 5: PERSISTENT workgroups (gridDim.x = a multiple of 8, a few per CU) that walk their XCD's contiguous range of items
-// and request the NEXT item's staged pixels into registers while the current one is filtered: the kernel's duration used to
-// be made of one staging round trip per workgroup with nothing behind it (VALU 35 % busy at 2.4 rounds of workgroups per CU).
-struct StatsRegs {
-    float xs[4], ys[4];
-    int kb[4];
-    float mu2_own, e22_own;
-};
-
 template <int MODE, bool KEEP>
 __global__ void __launch_bounds__(256) ssim_stats_kernel(const float* __restrict__ render,
                                                          const float* __restrict__ gt_rgb,
@@ -102,179 +93,156 @@ __global__ void __launch_bounds__(256) ssim_stats_kernel(const float* __restrict
     __shared__ __attribute__((aligned(16))) v2f h_a[SI][ST];
     __shared__ __attribute__((aligned(16))) v2f h_b[MODE == 0 ? SI : 1][ST];
     __shared__ __attribute__((aligned(16))) float h_xy[MODE == 2 ? 1 : SI][ST];
-    __shared__ float red[4];
+    const int lb = __builtin_amdgcn_readfirstlane(xcd_logical_block(blockIdx.x, gx * gy * 3));
+    const int c = lb % 3, tile = lb / 3;
+    const int bx = tile % gx, by = tile / gx;
+    const int x0 = bx * ST - SR, y0 = by * ST - SR;
     const int tid = threadIdx.x;
     const unsigned plane_b = (unsigned)H * (unsigned)W * 4u;       // bytes of a plane (the launcher checks 36 HW < 2^32)
-    constexpr int NS = 4;
-    const int sq = tid & 31, srg = tid >> 5;
-    // this workgroup's items: XCD x = blockIdx.x % 8 owns the logical blocks [first, first + cnt) (xcd_logical_block); its
-    // workgroups take them in turn
-    const int nb = gx * gy * 3;
-    const int xcd = blockIdx.x & 7, q8 = nb >> 3, r8 = nb & 7;
-    const int first = xcd * q8 + min(xcd, r8), cnt = q8 + (xcd < r8 ? 1 : 0);
-    const int stride = (int)gridDim.x >> 3;
-
-    // Staging loads of one item.  A lane owns ONE staged column (32 lanes across, 26 in use) and every eighth row: four
-    // passes whose addresses differ by a constant, with 32-bit byte offsets from uniform bases.  ALL of a lane's loads are
-    // issued before the first is used and nothing below branches: written as a loop with a load, a test and a store per
-    // pass, the compiler waited for memory in every pass.  Addresses outside the image are clamped to pixel 0 and the
-    // value replaced.  MODE 1: the cached statistics of this lane's own pixel are requested with them.
-    auto request = [&](int it, StatsRegs& g) {
-        const int lb = first + it;
-        const int c = lb % 3, tile = lb / 3;
-        const int bx = tile % gx, by = tile / gx;
-        const int x0 = bx * ST - SR, y0 = by * ST - SR;
-        g.mu2_own = 0.f; g.e22_own = 0.f;
-        if (MODE == 1) {
-            const int opx = bx * ST + (tid & 15), opy = by * ST + (tid >> 4);
-            if (opx < W && opy < H) {
-                const unsigned ob = (pixel_index(opy, W, opx)) * 4u + 2u * c * plane_b;
-                g.mu2_own = ld_f32(gt_stats, ob);
-                g.e22_own = ld_f32(gt_stats, ob + plane_b);
-            }
-        }
-        const int sx = x0 + sq;
-        const bool in_x = sq < SI && sx >= 0 && sx < W;
-        const unsigned c_plane_b = (unsigned)c * plane_b;
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            const int y = y0 + srg + 8 * j;
-            const bool in = in_x && (srg + 8 * j) < SI && (unsigned)y < (unsigned)H;
-            const unsigned pix = in ? pixel_index(y, W, sx) : 0u;
-            const unsigned pix4 = pix << 2;
-            g.xs[j] = MODE == 2 ? 0.f : ld_f32(render, pix4 + c_plane_b);
-            g.ys[j] = ld_f32(gt_rgb, pix4 + (pix4 << 1) + 4u * c);
-            g.kb[j] = KEEP ? (int)keep[pix] : 1;
-        }
-    };
-
-    StatsRegs cur;
-    int it = (int)blockIdx.x >> 3;
-    if (it < cnt) request(it, cur);
-    for (; it < cnt; it += stride) {
-        const int lb = __builtin_amdgcn_readfirstlane(first + it);
-        const int c = lb % 3, tile = lb / 3;
-        const int bx = tile % gx, by = tile / gx;
-        const int x0 = bx * ST - SR, y0 = by * ST - SR;
-        {
-            const int sx = x0 + sq;
-            const bool in_x = sq < SI && sx >= 0 && sx < W;
-#pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                const int y = y0 + srg + 8 * j;
-                const bool k = in_x && (srg + 8 * j) < SI && (unsigned)y < (unsigned)H && cur.kb[j] != 0;
-                const float xv = k ? cur.xs[j] : 0.f, yv = k ? cur.ys[j] : 0.f;
-                const int r = min(srg + 8 * j, SI);          // rows past the end -> the spare row (columns >= 26: padding)
-                if (MODE == 0) {
-                    s_a[r][sq] = (v2f){xv, yv};
-                    s_b[r][sq] = (v2f){xv * xv, yv * yv};
-                } else if (MODE == 1) {
-                    s_a[r][sq] = (v2f){xv, xv * xv};
-                } else {
-                    s_a[r][sq] = (v2f){yv, yv * yv};
-                }
-                if (MODE != 2) s_x_y[r][sq] = xv * yv;
-            }
-        }
-        const float mu2_own = cur.mu2_own, e22_own = cur.e22_own;
-        __syncthreads();
-        // the next item's pixels: in flight while this one is filtered
-        if (it + stride < cnt) request(it + stride, cur);
-        // row pass: a lane produces TWO adjacent outputs of a row from twelve staged pixels read once (six 16-byte reads of
-        // pairs, six 8-byte reads of xy) -- 26 x 8 = 208 lanes, one pass, a quarter of the LDS reads of one output per lane
-        if (tid < SI * 8) {
-            const int r = tid >> 3, q = (tid & 7) * 2;
-            v2f A[12], B[12];
-            float X[12];
-#pragma unroll
-            for (int k = 0; k < 12; k += 2) {
-                const float4 t = *reinterpret_cast<const float4*>(&s_a[r][q + k]);
-                A[k] = (v2f){t.x, t.y};
-                A[k + 1] = (v2f){t.z, t.w};
-                if (MODE == 0) {
-                    const float4 u = *reinterpret_cast<const float4*>(&s_b[r][q + k]);
-                    B[k] = (v2f){u.x, u.y};
-                    B[k + 1] = (v2f){u.z, u.w};
-                }
-                if (MODE != 2) {
-                    const float2 u = *reinterpret_cast<const float2*>(&s_x_y[r][q + k]);
-                    X[k] = u.x;
-                    X[k + 1] = u.y;
-                }
-            }
-            v2f a_a[2] = {{0.f, 0.f}, {0.f, 0.f}}, a_b[2] = {{0.f, 0.f}, {0.f, 0.f}};
-            float a_xy[2] = {0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < SW; ++k) {
-                const float w = win.w[k];
-                const v2f w2 = {w, w};
-#pragma unroll
-                for (int o = 0; o < 2; ++o) {
-                    a_a[o] = __builtin_elementwise_fma(w2, A[o + k], a_a[o]);
-                    if (MODE == 0) a_b[o] = __builtin_elementwise_fma(w2, B[o + k], a_b[o]);
-                    if (MODE != 2) a_xy[o] = fmaf(w, X[o + k], a_xy[o]);
-                }
-            }
-            *reinterpret_cast<float4*>(&h_a[r][q]) = make_float4(a_a[0].x, a_a[0].y, a_a[1].x, a_a[1].y);
-            if (MODE == 0) *reinterpret_cast<float4*>(&h_b[r][q]) = make_float4(a_b[0].x, a_b[0].y, a_b[1].x, a_b[1].y);
-            if (MODE != 2) *reinterpret_cast<float2*>(&h_xy[r][q]) = make_float2(a_xy[0], a_xy[1]);
-        }
-        __syncthreads();
-        const int lx = tid & 15, ly = tid >> 4;
-        const int px = bx * ST + lx, py = by * ST + ly;
-        float sval = 0.f;
-        if (px < W && py < H) {
-            v2f fa = {0.f, 0.f}, fb = {0.f, 0.f};
-            float e12 = 0.f;
-#pragma unroll
-            for (int k = 0; k < SW; ++k) {
-                const float w = win.w[k];
-                const v2f w2 = {w, w};
-                fa = __builtin_elementwise_fma(w2, h_a[ly + k][lx], fa);
-                if (MODE == 0) fb = __builtin_elementwise_fma(w2, h_b[ly + k][lx], fb);
-                if (MODE != 2) e12 = fmaf(w, h_xy[ly + k][lx], e12);
-            }
-            const unsigned pb = (pixel_index(py, W, px)) * 4u;
-            if (MODE == 2) {
-                st_f32(gt_stats, pb + 2u * c * plane_b, fa.x);                    // mu2
-                st_f32(gt_stats, pb + (2u * c + 1u) * plane_b, fa.y);             // E[y^2]
-            } else {
-                float mu1, mu2, e11, e22;
-                if (MODE == 0) {
-                    mu1 = fa.x; mu2 = fa.y; e11 = fb.x; e22 = fb.y;
-                } else {
-                    mu1 = fa.x; e11 = fa.y;
-                    mu2 = mu2_own;
-                    e22 = e22_own;
-                }
-                const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
-                const float s1 = e11 - mu1s, s2 = e22 - mu2s, s12 = e12 - mu12;
-                const float A1 = 2.f * mu12 + SSIM_C1, A2 = 2.f * s12 + SSIM_C2;
-                const float B1 = mu1s + mu2s + SSIM_C1, B2 = s1 + s2 + SSIM_C2;
-                // two hardware reciprocals (1 ulp) instead of three IEEE divisions (~10 VALU instructions each): B1 >= C1,
-                // B2 ~ C2 + variances, nowhere near the denormals
-                const float r1 = __builtin_amdgcn_rcpf(B1), r2 = __builtin_amdgcn_rcpf(B2);
-                const float inv = r1 * r2;
-                sval = A1 * A2 * inv;
-                const float d_e11 = -sval * r2;
-                const float d_e12 = 2.f * A1 * inv;
-                const float d_mu1 = 2.f * mu2 * (A2 - A1) * inv - 2.f * mu1 * sval * (r1 - r2);
-                const unsigned mb = pb + 3u * c * plane_b;       // dmaps[c][3][H][W]
-                st_f32(dmaps, mb, scale * d_mu1);
-                st_f32(dmaps, mb + plane_b, scale * d_e11);
-                st_f32(dmaps, mb + 2u * plane_b, scale * d_e12);
-            }
-        }
-        if (MODE != 2) {
-            const int bid = c * gx * gy + tile;
-            const float s = wave_sum_to_lane63(sval);
-            if ((tid & 63) == 63) red[tid >> 6] = s;
-            __syncthreads();
-            if (tid == 0) partial[bid] = red[0] + red[1] + red[2] + red[3];
-        } else {
-            __syncthreads();                         // (the column pass has read h_* before the next item's row pass writes them)
+    // MODE 1: the cached statistics of this lane's own pixel, requested before anything else (read where they are
+    // used, after the column pass, the two loads were a full memory round trip at the end of the workgroup's life)
+    float mu2_own = 0.f, e22_own = 0.f;
+    if (MODE == 1) {
+        const int opx = bx * ST + (tid & 15), opy = by * ST + (tid >> 4);
+        if (opx < W && opy < H) {
+            const unsigned ob = (pixel_index(opy, W, opx)) * 4u + 2u * c * plane_b;
+            mu2_own = ld_f32(gt_stats, ob);
+            e22_own = ld_f32(gt_stats, ob + plane_b);
         }
     }
+    // Staging.  A lane owns ONE staged column (32 lanes across, 26 in use) and every eighth row: four passes whose
+    // addresses differ by a constant, with 32-bit byte offsets from uniform bases.  ALL of a lane's loads are issued
+    // before the first is used and nothing below branches: written as a loop with a load, a test and a store per pass,
+    // the compiler waited for memory in every pass -- six dependent round trips in the life of a workgroup, which is what
+    // this kernel's duration was made of.  Addresses outside the image are clamped to pixel 0 and the value replaced.
+    constexpr int NS = 4;
+    const int sq = tid & 31, srg = tid >> 5;
+    const int sx = x0 + sq;
+    const bool in_x = sq < SI && sx >= 0 && sx < W;
+    const unsigned c_plane_b = (unsigned)c * plane_b;
+    float xs[NS], ys[NS];
+    int kb[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int y = y0 + srg + 8 * j;
+        const bool in = in_x && (srg + 8 * j) < SI && (unsigned)y < (unsigned)H;
+        const unsigned pix = in ? pixel_index(y, W, sx) : 0u;
+        const unsigned pix4 = pix << 2;
+        xs[j] = MODE == 2 ? 0.f : ld_f32(render, pix4 + c_plane_b);
+        ys[j] = ld_f32(gt_rgb, pix4 + (pix4 << 1) + 4u * c);
+        kb[j] = KEEP ? (int)keep[pix] : 1;
+    }
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int y = y0 + srg + 8 * j;
+        const bool k = in_x && (srg + 8 * j) < SI && (unsigned)y < (unsigned)H && kb[j] != 0;
+        const float xv = k ? xs[j] : 0.f, yv = k ? ys[j] : 0.f;
+        const int r = min(srg + 8 * j, SI);              // rows past the end -> the spare row (columns >= 26: padding)
+        if (MODE == 0) {
+            s_a[r][sq] = (v2f){xv, yv};
+            s_b[r][sq] = (v2f){xv * xv, yv * yv};
+        } else if (MODE == 1) {
+            s_a[r][sq] = (v2f){xv, xv * xv};
+        } else {
+            s_a[r][sq] = (v2f){yv, yv * yv};
+        }
+        if (MODE != 2) s_x_y[r][sq] = xv * yv;
+    }
+    __syncthreads();
+    // row pass: a lane produces TWO adjacent outputs of a row from twelve staged pixels read once (six 16-byte reads of
+    // pairs, six 8-byte reads of xy) -- 26 x 8 = 208 lanes, one pass, a quarter of the LDS reads of one output per lane
+    if (tid < SI * 8) {
+        const int r = tid >> 3, q = (tid & 7) * 2;
+        v2f A[12], B[12];
+        float X[12];
+#pragma unroll
+        for (int k = 0; k < 12; k += 2) {
+            const float4 t = *reinterpret_cast<const float4*>(&s_a[r][q + k]);
+            A[k] = (v2f){t.x, t.y};
+            A[k + 1] = (v2f){t.z, t.w};
+            if (MODE == 0) {
+                const float4 u = *reinterpret_cast<const float4*>(&s_b[r][q + k]);
+                B[k] = (v2f){u.x, u.y};
+                B[k + 1] = (v2f){u.z, u.w};
+            }
+            if (MODE != 2) {
+                const float2 u = *reinterpret_cast<const float2*>(&s_x_y[r][q + k]);
+                X[k] = u.x;
+                X[k + 1] = u.y;
+            }
+        }
+        v2f a_a[2] = {{0.f, 0.f}, {0.f, 0.f}}, a_b[2] = {{0.f, 0.f}, {0.f, 0.f}};
+        float a_xy[2] = {0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < SW; ++k) {
+            const float w = win.w[k];
+            const v2f w2 = {w, w};
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                a_a[o] = __builtin_elementwise_fma(w2, A[o + k], a_a[o]);
+                if (MODE == 0) a_b[o] = __builtin_elementwise_fma(w2, B[o + k], a_b[o]);
+                if (MODE != 2) a_xy[o] = fmaf(w, X[o + k], a_xy[o]);
+            }
+        }
+        *reinterpret_cast<float4*>(&h_a[r][q]) = make_float4(a_a[0].x, a_a[0].y, a_a[1].x, a_a[1].y);
+        if (MODE == 0) *reinterpret_cast<float4*>(&h_b[r][q]) = make_float4(a_b[0].x, a_b[0].y, a_b[1].x, a_b[1].y);
+        if (MODE != 2) *reinterpret_cast<float2*>(&h_xy[r][q]) = make_float2(a_xy[0], a_xy[1]);
+    }
+    __syncthreads();
+    const int lx = tid & 15, ly = tid >> 4;
+    const int px = bx * ST + lx, py = by * ST + ly;
+    float sval = 0.f;
+    if (px < W && py < H) {
+        v2f fa = {0.f, 0.f}, fb = {0.f, 0.f};
+        float e12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < SW; ++k) {
+            const float w = win.w[k];
+            const v2f w2 = {w, w};
+            fa = __builtin_elementwise_fma(w2, h_a[ly + k][lx], fa);
+            if (MODE == 0) fb = __builtin_elementwise_fma(w2, h_b[ly + k][lx], fb);
+            if (MODE != 2) e12 = fmaf(w, h_xy[ly + k][lx], e12);
+        }
+        const unsigned pb = (pixel_index(py, W, px)) * 4u;
+        if (MODE == 2) {
+            st_f32(gt_stats, pb + 2u * c * plane_b, fa.x);                    // mu2
+            st_f32(gt_stats, pb + (2u * c + 1u) * plane_b, fa.y);             // E[y^2]
+            return;
+        }
+        float mu1, mu2, e11, e22;
+        if (MODE == 0) {
+            mu1 = fa.x; mu2 = fa.y; e11 = fb.x; e22 = fb.y;
+        } else {
+            mu1 = fa.x; e11 = fa.y;
+            mu2 = mu2_own;
+            e22 = e22_own;
+        }
+        const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
+        const float s1 = e11 - mu1s, s2 = e22 - mu2s, s12 = e12 - mu12;
+        const float A1 = 2.f * mu12 + SSIM_C1, A2 = 2.f * s12 + SSIM_C2;
+        const float B1 = mu1s + mu2s + SSIM_C1, B2 = s1 + s2 + SSIM_C2;
+        // two hardware reciprocals (1 ulp) instead of three IEEE divisions (~10 VALU instructions each): B1 >= C1,
+        // B2 ~ C2 + variances, nowhere near the denormals
+        const float r1 = __builtin_amdgcn_rcpf(B1), r2 = __builtin_amdgcn_rcpf(B2);
+        const float inv = r1 * r2;
+        sval = A1 * A2 * inv;
+        const float d_e11 = -sval * r2;
+        const float d_e12 = 2.f * A1 * inv;
+        const float d_mu1 = 2.f * mu2 * (A2 - A1) * inv - 2.f * mu1 * sval * (r1 - r2);
+        const unsigned mb = pb + 3u * c * plane_b;       // dmaps[c][3][H][W]
+        st_f32(dmaps, mb, scale * d_mu1);
+        st_f32(dmaps, mb + plane_b, scale * d_e11);
+        st_f32(dmaps, mb + 2u * plane_b, scale * d_e12);
+    }
+    if (MODE == 2) return;
+    float v[1] = {sval};
+    const int bid = c * gx * gy + tile;
+    // block_reduce_store indexes by blockIdx.x only -> reduce by hand here
+    __shared__ float red[4];
+    const float s = wave_sum_to_lane63(v[0]);
+    if ((tid & 63) == 63) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) partial[bid] = red[0] + red[1] + red[2] + red[3];
 }
 
 // grid gx*gy*4 blocks in XCD order, the four blocks of a tile adjacent: 0..2 -> gradient of one
@@ -497,25 +465,6 @@ size_t gfl_loss_workspace_bytes(int W, int H) {
            align_up256(gx * gy * 4 * sizeof(float));
 }
 
-// workgroups of the persistent statistics launch: GFL_STATS_WG_PER_CU per CU (a multiple of 8 in all: one XCD's share each),
-// never more than there are items
-#ifndef GFL_STATS_WG_PER_CU
-#define GFL_STATS_WG_PER_CU 4
-#endif
-static int stats_grid(int items) {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            cus <= 0)
-            cus = 256;
-    }
-    int g = GFL_STATS_WG_PER_CU * cus;
-    if (g > items) g = items;
-    g = (g + 7) / 8 * 8;
-    return g;
-}
-
 static int loss_launch(const float* render, const float* gt_rgb, const float* gt_depth, const uint8_t* keep,
                        const float* depth_ab, float lambda_rgb, float lambda_depth, int W, int H, float* d_render,
                        float* err_px, float* sums, void* workspace, size_t workspace_bytes, gfl_stream_t stream,
@@ -538,7 +487,7 @@ static int loss_launch(const float* render, const float* gt_rgb, const float* gt
     float* st = const_cast<float*>(gt_stats);
     auto stats = gt_stats ? (keep ? ssim_stats_kernel<1, true> : ssim_stats_kernel<1, false>)
                           : (keep ? ssim_stats_kernel<0, true> : ssim_stats_kernel<0, false>);
-    stats<<<stats_grid(gx * gy * 3), 256, 0, s>>>(render, gt_rgb, keep, W, H, gx, gy, win, s_scale, dmaps, p_ssim, st);
+    stats<<<gx * gy * 3, 256, 0, s>>>(render, gt_rgb, keep, W, H, gx, gy, win, s_scale, dmaps, p_ssim, st);
     auto grad = keep ? loss_grad_kernel<true> : loss_grad_kernel<false>;
     grad<<<gx * gy * 4, 256, 0, s>>>(render, gt_rgb, gt_depth, keep, depth_ab, dmaps, W, H, gx, gy, win,
                                      lambda_rgb * 2.f / (3.f * hw), lambda_depth / hw, d_render, err_px, p_grad);
@@ -571,8 +520,8 @@ int gfl_loss_prepare_gt(const float* gt_rgb, const uint8_t* keep, int W, int H, 
     const int gx = (W + ST - 1) / ST, gy = (H + ST - 1) / ST;
     static const Win win = make_window();
     auto stats = keep ? ssim_stats_kernel<2, true> : ssim_stats_kernel<2, false>;
-    stats<<<stats_grid(gx * gy * 3), 256, 0, (hipStream_t)stream>>>(nullptr, gt_rgb, keep, W, H, gx, gy, win, 0.f, nullptr, nullptr,
-                                                                    gt_stats);
+    stats<<<gx * gy * 3, 256, 0, (hipStream_t)stream>>>(nullptr, gt_rgb, keep, W, H, gx, gy, win, 0.f, nullptr, nullptr,
+                                                        gt_stats);
     return check_launch();
 }
 
