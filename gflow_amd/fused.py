@@ -115,9 +115,12 @@ class FitEngine:
         self.d_render = torch.zeros(4, H_, W_, **f32)
         self.err_px = torch.zeros(H_, W_, **f32)
         self.sums = torch.zeros(8, **f32)
-        self.tile_offsets = torch.zeros(self.T + 1, **i32)
+        # (one allocation: the pair count tile_offsets[T] and the four overflow words lie side by side -- watch_pending copies
+        #  the five of them to the host in ONE copy)
+        self._offsets_and_flags = torch.zeros(self.T + 1 + 4, **i32)
+        self.tile_offsets = self._offsets_and_flags[:self.T + 1]
         self.tile_range = torch.zeros(self.T, 2, **i32)
-        self.overflow = torch.zeros(4, **i32)         # [0]: sticky flag, [1]: iterations that stepped nothing, [2], [3]: this one is void (gflow_hip.h)
+        self.overflow = self._offsets_and_flags[self.T + 1:]    # [0]: sticky flag, [1]: iterations that stepped nothing, [2], [3]: this one is void (gflow_hip.h)
         self.gt_rgb = self.gt_depth = self.keep = None
         self.move_mask = self.foot_flags = None
         self.flow_target = self.flow_w = self.still_target = self.still_w = self.row_flags = None
@@ -524,8 +527,7 @@ class FitEngine:
         this call: the trainer queues one more iteration first, so the device is busy while the host looks."""
         if getattr(self, "_pend_host", None) is None:
             self._pend_host = torch.zeros(8, dtype=torch.int32, pin_memory=True)
-        self._pend_host[0:4].copy_(self.overflow, non_blocking=True)
-        self._pend_host[4:5].copy_(self.tile_offsets[self.T:self.T + 1], non_blocking=True)
+        self._pend_host[0:5].copy_(self._offsets_and_flags[self.T:self.T + 5], non_blocking=True)      # K, then the four words
         self._pend_event = torch.cuda.Event()
         self._pend_event.record()
 
@@ -542,7 +544,7 @@ class FitEngine:
         ev.synchronize()
         self._pend_event = None
         v = self._pend_host.tolist()
-        return v[0], v[1], v[4]
+        return v[1], v[2], v[0]
 
     def watch_overflow(self):
         """The same check without stopping the host: the flag is copied to pinned memory behind the work queued so
