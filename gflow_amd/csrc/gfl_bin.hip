@@ -251,7 +251,7 @@ int gfl_tile_sort_with_slots(const int32_t* tile_offsets, int W, int H, int K_ca
 
 int gfl_tile_sort_ordered(const int32_t* order, int W, int H, int K_cap, void* keys, int32_t* ids, int32_t* tile_range,
                           const float* rec, int32_t* slot_inv, int32_t* slot_pool, gfl_stream_t stream) {
-    if (W <= 0 || H <= 0 || K_cap < 0 || !order || !keys || !tile_range || (K_cap > 0 && !ids) || !rec || !slot_inv)
+    if (W <= 0 || H <= 0 || K_cap < 0 || !order || !keys || !tile_range || (K_cap > 0 && !ids) || (slot_inv && !rec))
         return GFL_ERR_INVALID;
     const int gx = (W + GFL_TILE - 1) / GFL_TILE, gy = (H + GFL_TILE - 1) / GFL_TILE;
     bin_tile_sort_kernel<<<SORT_MAX_SPLIT + gx * gy, SORT_THREADS, 0, (hipStream_t)stream>>>(
@@ -264,7 +264,7 @@ int gfl_tile_sort_reserved(const int32_t* order, const int32_t* fill, int32_t* t
                            int K_cap, void* keys, int32_t* ids, int32_t* tile_range, const float* rec, int32_t* slot_inv,
                            int32_t* slot_pool, gfl_stream_t stream) {
     if (W <= 0 || H <= 0 || K_cap < 0 || !order || !fill || !tile_counts || !keys || !tile_range || (K_cap > 0 && !ids) ||
-        !rec || !slot_inv)
+        (slot_inv && !rec))
         return GFL_ERR_INVALID;
     const int gx = (W + GFL_TILE - 1) / GFL_TILE, gy = (H + GFL_TILE - 1) / GFL_TILE;
     bin_tile_sort_kernel<<<SORT_MAX_SPLIT + gx * gy, SORT_THREADS, 0, (hipStream_t)stream>>>(

@@ -70,9 +70,9 @@ size_t gfl_fit_workspace_bytes(int cap, int K_cap, int W, int H) {
            + up256((size_t)K_cap * sizeof(unsigned long long))                      // keys
            + up256((size_t)reduce_rows(cap > 0 ? cap : 1) * 12 * sizeof(float))    // extr partials
            + up256(T * sizeof(int32_t))                                             // tile totals
-           + up256((size_t)K_cap * PG * sizeof(float))                             // per-pair gradient rows
-           + up256((size_t)(cap > 0 ? cap : 1) * SLOT_MAX * sizeof(int32_t))        // slot -> list position
-           + 256 + up256((size_t)K_cap * sizeof(int32_t))                          // counters + slot pool
+           + up256(((size_t)(cap > 0 ? cap : 1) * SLOT_MAX + (size_t)K_cap) * PG * sizeof(float))   // pair rows: SLOT_MAX per splat + the wide splats' runs
+           + up256((size_t)(cap > 0 ? cap : 1) * sizeof(int32_t))                   // a wide splat's run
+           + 256                                                                    // counters
            + up256(4 * T * sizeof(int32_t))                                         // scheduler: work feedback per 8x8 block
            + up256((size_t)SCHED_MAX_QUEUES * sched_queue_capacity((int)T, 64) * sizeof(int32_t))   // queue items
            + 2 * up256(2 * SCHED_MAX_QUEUES * sizeof(int32_t))                      // queue lengths, pull counters
@@ -102,17 +102,17 @@ static FitWs carve(const gfl_fit_state* st) {
     w.tile_counts = (int32_t*)p;
     p += up256(T * sizeof(int32_t));
     w.pair_grad = (float*)p;
-    p += up256((size_t)st->K_cap * PG * sizeof(float));
-    w.slot_inv = (int32_t*)p;
-    p += up256((size_t)(st->cap > 0 ? st->cap : 1) * SLOT_MAX * sizeof(int32_t));
+    w.wide_base = (long long)(st->cap > 0 ? st->cap : 1) * SLOT_MAX;
+    p += up256(((size_t)(st->cap > 0 ? st->cap : 1) * SLOT_MAX + (size_t)st->K_cap) * PG * sizeof(float));
+    w.wide_off = (int32_t*)p;
+    p += up256((size_t)(st->cap > 0 ? st->cap : 1) * sizeof(int32_t));
     w.pool_counter = (int32_t*)p;
+    w.stamp = w.pool_counter + 56;
     w.sched_valid = w.pool_counter + 16;
     w.regions_valid = w.pool_counter + 32;
     w.extent = w.pool_counter + 40;
     w.extent_next = w.pool_counter + 48;
     p += 256;
-    w.slot_pool = (int32_t*)p;
-    p += up256((size_t)st->K_cap * sizeof(int32_t));
     w.sched.work = (int32_t*)p;
     p += up256(4 * T * sizeof(int32_t));
     w.sched.list = (int32_t*)p;
@@ -219,8 +219,8 @@ static PreArgs pre_args(const gfl_fit_state* st, const gfl_fit_hyper* hp, const 
     a.N = st->N; a.W = st->W; a.H = st->H;
     a.nearest = hp->nearest; a.extent = hp->extent;
     a.gx = gx; a.gy = gy;
-    a.rec = st->rec; a.slot_inv = w.slot_inv; a.hist_g = w.hist; a.extr_out = st->extr; a.overflow = st->overflow;
-    a.slot_pool = w.slot_pool; a.pool_counter = w.pool_counter; a.pool_cap = st->K_cap;
+    a.rec = st->rec; a.wide_off = w.wide_off; a.hist_g = w.hist; a.extr_out = st->extr; a.overflow = st->overflow;
+    a.pool_counter = w.pool_counter; a.pool_cap = st->K_cap;
     a.op_mode = op_mode;
     a.scale_rows_mode = (!op_mode && hp->lambda_scale != 0.f) ? (hp->freeze_all_splats ? 2 : 1) : 0;
     a.scale_cnt = w.scale_cnt;
@@ -252,7 +252,7 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
         {
             StageScope p(ST_TILE_SORT, s);
             rc = gfl_tile_sort_reserved((const int32_t*)w.sort_order_next, w.fill, w.tile_counts, st->overflow + 2, st->W, st->H,
-                                        st->K_cap, w.keys, st->ids, st->tile_range, st->rec, w.slot_inv, w.slot_pool, stream);
+                                        st->K_cap, w.keys, st->ids, st->tile_range, nullptr, nullptr, nullptr, stream);
         }
         if (rc) return rc;
     } else {
@@ -275,10 +275,9 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
             StageScope p(ST_TILE_SORT, s);
             if (ordered)
                 rc = gfl_tile_sort_ordered((const int32_t*)w.sort_order, st->W, st->H, st->K_cap, w.keys, st->ids, st->tile_range,
-                                           st->rec, w.slot_inv, w.slot_pool, stream);
+                                           nullptr, nullptr, nullptr, stream);
             else
-                rc = gfl_tile_sort_with_slots(st->tile_offsets, st->W, st->H, st->K_cap, w.keys, st->ids, st->tile_range, st->rec,
-                                              w.slot_inv, w.slot_pool, stream);
+                rc = gfl_tile_sort_only(st->tile_offsets, gx * gy, st->K_cap, w.keys, st->ids, st->tile_range, stream);
         }
         if (rc) return rc;
     }
@@ -396,7 +395,7 @@ int gfl_render_bwd(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float
     {
         StageScope p(ST_BLEND_BWD, s);
         const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters + w.sched.nq, w.sched.nq, w.sched.cap_q};
-        launch_blend_bwd(st, hp->bg, gx, blend_grid(T), 10, d_render, q, w, LossTail{}, s);
+        launch_blend_bwd(st, hp->bg, gx, gy, blend_grid(T), 10, d_render, q, w, LossTail{}, s);
     }
     {
         StageScope p(ST_PRE_BWD_ADAM, s);
@@ -446,7 +445,7 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
         const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters + w.sched.nq, w.sched.nq, w.sched.cap_q};
         // sums that nobody reads are not formed: 6 in the camera-only stage, 7 while the colours are frozen (see the kernel)
         const int sums = hp->freeze_all_splats ? 6 : (hp->freeze_rgb ? 7 : 10);
-        launch_blend_bwd(st, hp->bg, gx, blend_grid(T), sums, st->d_render, q, w, lt, s);
+        launch_blend_bwd(st, hp->bg, gx, gy, blend_grid(T), sums, st->d_render, q, w, lt, s);
     }
     const int rows = reduce_rows(st->N > 0 ? st->N : 1);
     RegCfg rcfg;

@@ -147,8 +147,8 @@ struct PreArgs {
     int N, W, H;
     float nearest, extent;
     int gx, gy;
-    float* rec; int32_t* slot_inv; int32_t* hist_g; float* extr_out; int32_t* overflow;
-    int32_t* slot_pool; int32_t* pool_counter; int pool_cap; int op_mode;
+    float* rec; int32_t* wide_off; int32_t* hist_g; float* extr_out; int32_t* overflow;
+    int32_t* pool_counter; int pool_cap; int op_mode;
     int scale_rows_mode; int32_t* scale_cnt;
 };
 
@@ -314,9 +314,15 @@ struct FitWs {
     float* partial;
     int32_t* tile_counts;
     float* pair_grad;
-    int32_t* slot_inv;
-    int32_t* slot_pool;
-    int32_t* pool_counter;   // entries of the slot pool handed out by this iteration's preprocess
+    // pair rows (round 5): the backward blend writes the gradient row of the pair (splat g, tile) at a place the per-splat
+    // launch finds WITHOUT a table -- row g * SLOT_MAX + (the tile's index inside g's tile rectangle); splats covering more than
+    // SLOT_MAX tiles (a handful per frame) get a run of the rows behind those, at wide_base + wide_off[g].  A row carries the
+    // STAMP of the forward it belongs to in its eleventh float: rows of older iterations, and of pairs nobody walked (behind the
+    // tile's deepest contributor, culled by the exact disc test), are simply not this iteration's.
+    int32_t* wide_off;       // [cap] offset of a wide splat's run (written by the preprocess for wide splats only)
+    long long wide_base;     // first row of the runs = cap * SLOT_MAX
+    int32_t* stamp;          // the current forward's number (the forward blend's launch advances it)
+    int32_t* pool_counter;   // rows of the runs handed out by this iteration's preprocess
     int32_t* sched_valid;    // != 0: the tile queues in the workspace were built at the end of the last iteration
     Sched sched;             // tile queues of the backward blend; sched.work persists between calls
     Sched sched_fwd;         // ... and of the forward blend (its own work feedback)
@@ -362,7 +368,7 @@ void launch_rec_depth_range(const float* rec, int N, unsigned* mm, hipStream_t s
 void launch_snapshot_u8(const float* a, const float* b, const float* c, int P, uint8_t* out, hipStream_t s);
 void launch_snapshot_stage(const StageCopy& c, hipStream_t s);
 // gfl_fit_bwd.hip
-void launch_blend_bwd(const gfl_fit_state* st, float bg, int gx, int grid, int sums, const float* d_out, const TileQueue& q,
+void launch_blend_bwd(const gfl_fit_state* st, float bg, int gx, int gy, int grid, int sums, const float* d_out, const TileQueue& q,
                       const FitWs& w, const LossTail& lt, hipStream_t s);
 // gfl_fit_splat.hip
 void launch_splat_bwd_adam(const gfl_fit_state* st, const FitWs& w, int gx, int gy, const RegCfg& rc, const AdamCfg& ac,

@@ -32,7 +32,6 @@ __device__ __forceinline__ void preprocess_block(const PreArgs& a, const float4 
     }
     float u = 0.f, v = 0.f, cutoff = 0.f;
     int wx0 = 0, wy0 = 0, wnx = 0, wnt = 0;      // rectangle of a "wide" splat (walked by the wave below)
-    int woff = -1;                               // its offset in the slot pool (more than SLOT_MAX tiles)
     bool in_scale_rows = false;
     Splat s = {};
     Proj p = {};
@@ -53,7 +52,7 @@ __device__ __forceinline__ void preprocess_block(const PreArgs& a, const float4 
     if (EWA_MFMA) e = ewa_fwd_mfma(c, p.vis, p.px, p.py, p.pz, cov, W, H);       // (the whole wave: no divergence here)
     if (i < N) {
         float depth = 0.f, A = 0.f, B = 0.f, C = 0.f;
-        int rad = 0, nt_slots = 0;
+        int rad = 0;
         if (p.vis) {
             u = p.u; v = p.v; depth = p.pz;
             if (!EWA_MFMA) e = ewa_fwd(c, p.px, p.py, p.pz, cov, W, H);
@@ -64,7 +63,6 @@ __device__ __forceinline__ void preprocess_block(const PreArgs& a, const float4 
                 const int nt = (x1 - x0) * (y1 - y0);
                 if (nt > 0) {
                     rad = r;
-                    nt_slots = min(nt, SLOT_MAX);
                     A = e.c / e.det; B = -e.b / e.det; C = e.a / e.det;
                     cutoff = alpha_cutoff(s.o, e.lam);
                     if (nt > WIDE_TILES) {
@@ -83,22 +81,11 @@ __device__ __forceinline__ void preprocess_block(const PreArgs& a, const float4 
         r4[2] = make_float4(s.c[2], depth, cutoff, __int_as_float(rad));
         if (BINNED) { po->u = u; po->v = v; po->cutoff = cutoff; po->depth = depth; po->rad = rad; }
         in_scale_rows = a.scale_rows_mode && scale_row(u, v, W, H, own_flags, a.scale_rows_mode);
-        int4* iv = reinterpret_cast<int4*>(a.slot_inv + (size_t)i * SLOT_MAX);
-        const int4 none = make_int4(-1, -1, -1, -1);
-        // only the slots of the splat's own tile rectangle are ever read (gather of the backward)
-#pragma unroll
-        for (int q = 0; q < SLOT_MAX / 4; ++q)
-            if (4 * q < nt_slots) iv[q] = none;
         if (wnt > SLOT_MAX) {
-            // too many tiles for the slot row: reserve wnt entries of the pool; the row's first
-            // entry carries the pool offset as -2 - offset
+            // too many tiles for the splat's own SLOT_MAX pair rows: a run of wnt rows behind them (FitWs.wide_off)
             const int off = atomicAdd(a.pool_counter, wnt);
-            if (off + wnt <= a.pool_cap) {
-                woff = off;
-                a.slot_inv[(size_t)i * SLOT_MAX] = -2 - off;
-            } else {
-                *a.overflow = 1;
-            }
+            a.wide_off[i] = off + wnt <= a.pool_cap ? off : -1;      // (-1: no rows -- and the lists' overflow flag: they must grow)
+            if (off + wnt > a.pool_cap) *a.overflow = 1;
         }
     }
     if (PHASES) GFL_PHASE(0, 4);
@@ -111,11 +98,9 @@ __device__ __forceinline__ void preprocess_block(const PreArgs& a, const float4 
             todo &= todo - 1;
             const float su = __shfl(u, src), sv = __shfl(v, src), sc = __shfl(cutoff, src);
             const int sx0 = __shfl(wx0, src), sy0 = __shfl(wy0, src), snx = __shfl(wnx, src), snt = __shfl(wnt, src);
-            const int soff = __shfl(woff, src);
             for (int q = lane; q < snt; q += 64) {
                 const int tx = sx0 + q % snx, ty = sy0 + q / snx;
                 if (tile_hit2(su, sv, sc, tx, ty)) atomicAdd(&hist[ty * gx + tx], 1);
-                if (soff >= 0) a.slot_pool[soff + q] = -1;
             }
         }
     }

@@ -117,15 +117,23 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
                                                               float* __restrict__ pair_grad, TileQueue queue,
                                                               int32_t* __restrict__ tile_work,
                                                               const float* __restrict__ ckpt,
-                                                              const float* __restrict__ render, LossTail ltail) {
+                                                              const float* __restrict__ render, LossTail ltail, int gy,
+                                                              const int32_t* __restrict__ wide_off, long long wide_base,
+                                                              const int32_t* __restrict__ stamp_ptr) {
     // (see LossTail.  The workgroup that holds the LAST pre-assigned slot of queue 0 does it before its first item: ~3 us
     //  that the seven other workgroups of its queue absorb.  A workgroup of its own behind the others only started when one
     //  of them -- all persistent -- had finished: +1 us at the end of the launch.)
     if (ltail.enabled && blockIdx.x == gridDim.x - queue.nq) loss_tail(ltail);
-    // No global atomics: the four waves of the tile combine their per-splat sums in LDS and the
-    // tile writes ONE 48-byte row per (splat, tile) pair at the pair's list position with plain,
-    // coalesced stores.  The per-splat kernel gathers its rows afterwards (deterministic).
+    // No global atomics: the four waves of the tile combine their per-splat sums in LDS and the tile writes ONE 48-byte row per
+    // (splat, tile) pair with plain stores -- round 5: not at the pair's list position (the per-splat launch then needed a table
+    // of positions, written by the tile sort from a gather of the records, and gathered rows scattered over 12.7 MB: 41 MB of
+    // traffic) but at row g * SLOT_MAX + (the tile's index in the splat's own tile rectangle), which the
+    // per-splat launch computes for itself and reads as ONE contiguous run per splat.  The scattered side of the exchange is
+    // now the stores of this kernel, which is bound by instruction issue and does not wait for them.  A row carries the number
+    // of the forward it belongs to (FitWs.stamp) in its eleventh float: pairs nobody walks -- behind the tile's deepest
+    // contributor -- need no zero row.
     __shared__ RecLDS recs[FBB];
+    __shared__ int32_t s_gid[FBB];
     __shared__ float acc[FBB][REC];
     __shared__ unsigned char s_mask[FBB];
     __shared__ int32_t s_max_last;
@@ -203,13 +211,7 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
     const int lo = item.part > 0 ? item.part * seg : 0;
     const int hi = last_part ? depth_n : min((item.part + 1) * seg, depth_n);
 
-    // pairs behind the deepest contributor of the tile get a zero row
-    if (last_part)
-        for (int p = depth_n + tid; p < total; p += 256) {
-            float4* o = reinterpret_cast<float4*>(pair_grad + (size_t)(start + p) * PG);
-            o[0] = zero4; o[1] = zero4; o[2] = zero4;
-        }
-
+    const int stamp = *stamp_ptr;
     for (int r0 = 0; r0 < hi - lo; r0 += FBB) {
         const int pos_t = tid < FBB ? hi - 1 - r0 - tid : -1;          // slot tid <-> list position pos_t
         __syncthreads();
@@ -218,6 +220,7 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
             const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g * REC);
             const float4 p0 = r4[0], p1 = r4[1], p2 = r4[2];
             recs[tid].p0 = p0; recs[tid].p1 = p1; recs[tid].p2 = p2;
+            s_gid[tid] = g;
             s_mask[tid] = (unsigned char)block_mask(p0, p1, p2.z, tx * GFL_TILE, ty * GFL_TILE);
         }
         if (tid < FBB) {
@@ -279,9 +282,24 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
         }
         __syncthreads();
         if (pos_t >= lo) {
-            const float4* a4 = reinterpret_cast<const float4*>(&acc[tid][0]);
-            float4* o = reinterpret_cast<float4*>(pair_grad + (size_t)(start + pos_t) * PG);
-            o[0] = a4[0]; o[1] = a4[1]; o[2] = a4[2];
+            // the pair's row: the tile's index inside the splat's tile rectangle (tile_rect of the staged u, v, radius: what the
+            // binning walked and the per-splat launch will walk)
+            const int g = s_gid[tid];
+            const float4 p0 = recs[tid].p0;
+            int x0, x1, y0, y1;
+            tile_rect(p0.x, p0.y, __float_as_int(recs[tid].p2.w), gx, gy, x0, x1, y0, y1);
+            const int nx = x1 - x0, j = (ty - y0) * nx + (tx - x0);
+            long long row = (long long)g * SLOT_MAX + j;
+            if (nx * (y1 - y0) > SLOT_MAX) {
+                const int off = wide_off[g];
+                row = off >= 0 ? wide_base + off + j : -1;
+            }
+            if (row >= 0) {
+                const float4* a4 = reinterpret_cast<const float4*>(&acc[tid][0]);
+                float4* o = reinterpret_cast<float4*>(pair_grad + (size_t)row * PG);
+                o[0] = a4[0]; o[1] = a4[1];
+                o[2] = make_float4(a4[2].x, a4[2].y, __int_as_float(stamp), 0.f);
+            }
         }
     }
     // work feedback for the next iteration's schedule, per 8x8 block (gfl_sched.hpp)
@@ -304,11 +322,11 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
 }
 
 // ---- launcher (gfl_fit.hpp).  sums: 10 / 7 / 6 (see the kernel)
-void launch_blend_bwd(const gfl_fit_state* st, float bg, int gx, int grid, int sums, const float* d_out, const TileQueue& q,
+void launch_blend_bwd(const gfl_fit_state* st, float bg, int gx, int gy, int grid, int sums, const float* d_out, const TileQueue& q,
                       const FitWs& w, const LossTail& lt, hipStream_t s) {
     auto kern = sums == 6 ? fused_blend_bwd_kernel<6> : (sums == 7 ? fused_blend_bwd_kernel<7> : fused_blend_bwd_kernel<10>);
     kern<<<grid, 256, 0, s>>>(st->rec, st->ids, st->tile_range, bg, st->W, st->H, gx, st->final_T, st->n_contrib, d_out, w.pair_grad,
-                              q, w.sched.work, w.ckpt, st->render, lt);
+                              q, w.sched.work, w.ckpt, st->render, lt, gy, w.wide_off, w.wide_base, w.stamp);
 }
 
 #ifdef GFL_TRACE

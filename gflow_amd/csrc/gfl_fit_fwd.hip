@@ -90,7 +90,11 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                                                               const unsigned* __restrict__ cmap_mm,
                                                               const float* __restrict__ cmap_lut, int split_min,
                                                               int32_t* __restrict__ tile_work,
-                                                              const int32_t* __restrict__ first_slot) {
+                                                              const int32_t* __restrict__ first_slot,
+                                                              int32_t* __restrict__ stamp) {
+    // the number of this forward: the backward blend stamps its pair rows with it, the per-splat launch takes only rows that
+    // carry it (FitWs.stamp; nobody reads it before this launch has ended)
+    if (mode == 0 && stamp && blockIdx.x == 0 && threadIdx.x == 0) *stamp += 1;
     // mode 0: the records as they are.  The two snapshot-only images of render.py:76-106 are composites of the SAME
     // lists with other per-splat values, made while a record is staged: mode 1 = colour := turbo map of the splat's
     // depth (apply_float_colormap(non_zero=True), range in cmap_mm), mode 2 = unit blob at the centre (conic 1 0 1,
@@ -633,7 +637,7 @@ void launch_blend_fwd(const gfl_fit_state* st, float bg, int gx, int grid, float
                       hipStream_t s) {
     auto kern = mode == 0 ? fused_blend_fwd_kernel<0> : (mode == 1 ? fused_blend_fwd_kernel<1> : fused_blend_fwd_kernel<2>);
     kern<<<grid, 256, 0, s>>>(st->rec, st->ids, st->tile_range, bg, st->W, st->H, gx, inv_of(gx), out, final_T, n_contrib, q, w.ckpt,
-                              cmap_mm, cmap_lut, split_min, w.sched_fwd.work, w.sched.first_slot);
+                              cmap_mm, cmap_lut, split_min, w.sched_fwd.work, w.sched.first_slot, mode == 0 ? w.stamp : nullptr);
 }
 
 void launch_footprint(const gfl_fit_state* st, int gx, int T, hipStream_t s) {

@@ -14,8 +14,8 @@ template <bool OP>
 __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel(
     float* __restrict__ params, float* __restrict__ adam_m, float* __restrict__ adam_v, const float* __restrict__ intr,
     const float* pose, const float* __restrict__ rec, float* __restrict__ d_rec,
-    const float* __restrict__ pair_grad, const int32_t* __restrict__ slot_pool,
-    const int32_t* __restrict__ tile_range, const int32_t* __restrict__ slot_inv, int gx, int gy, int N, int W, int H,
+    const float* __restrict__ pair_grad, const int32_t* __restrict__ wide_off, long long wide_base,
+    const int32_t* __restrict__ stamp_ptr, int gx, int gy, int N, int W, int H,
     const float* __restrict__ flow_target, const float* __restrict__ flow_w, const float* __restrict__ still_target,
     const float* __restrict__ still_w, const uint8_t* __restrict__ row_flags, RegCfg rc, AdamCfg ac,
     const int32_t* d_step, float* partial, const float* __restrict__ d_uv_in,
@@ -74,6 +74,8 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
     // the parameter row and both Adam moments are requested before the gather so that their
     // latency overlaps it (the launch has about one wave per SIMD: nothing else would hide it)
     float4 prow_v[4] = {}, mrow_v[4], vrow_v[4];
+    float4 f0[4], f1[4], f2[4];
+    const int stamp = *stamp_ptr;
     float rec_C = 0.f;
     unsigned own_flags = 0;
     float own_flow_w = 0.f, own_still_w = 0.f, own_still_t[3] = {0.f, 0.f, 0.f};    // (OP: own_flow_w = dL/d depth,
@@ -93,6 +95,12 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
         const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)i * REC);
         rp0 = r4[0]; rp2 = r4[2];
         rec_C = rec[(size_t)i * REC + 4];
+        {
+            // the splat's first four pair rows, before anybody knows how many it has (their place depends on i alone)
+            const float4* g4 = reinterpret_cast<const float4*>(pair_grad + (size_t)i * SLOT_MAX * PG);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { f0[j] = g4[3 * j]; f1[j] = g4[3 * j + 1]; f2[j] = g4[3 * j + 2]; }
+        }
         // the per-row side inputs of the regularisers too: read where they are used, deep inside the chain rule, each
         // was a round trip of its own (joint stages: chain rule 3.5 us against 2.3 without them, tools/phase_trace.py)
         if (!OP) {
@@ -121,28 +129,23 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
                 tile_rect(rp0.x, rp0.y, rad, gx, gy, x0, x1, y0, y1);
                 const int nt = (x1 - x0) * (y1 - y0);
                 if (nt <= SLOT_MAX) {
-                    // The launch has about one wave per SIMD, so nothing hides a dependent load:
-                    // the whole slot row is fetched first (up to eight 16-byte loads in flight),
-                    // then the gradient rows four at a time (twelve loads in flight), summed in
-                    // tile order.  One slot and one row per trip took 2 x nt round trips to L2.
-                    const int4* sl4 = reinterpret_cast<const int4*>(slot_inv + (size_t)i * SLOT_MAX);
-                    int4 s4[SLOT_MAX / 4];
-#pragma unroll
-                    for (int k = 0; k < SLOT_MAX / 4; ++k) s4[k] = (4 * k < nt) ? sl4[k] : make_int4(-1, -1, -1, -1);
+                    // The splat's pair rows are rows i * SLOT_MAX .. + nt of pair_grad, in the order of its tile rectangle
+                    // (the backward blend put them there); the first four were requested at the top with everything else --
+                    // nine splats in ten have no more --, the others follow four at a time (twelve loads in flight), summed in
+                    // tile order.  A row counts if it carries this forward's stamp.
+                    const float4* g4 = reinterpret_cast<const float4*>(pair_grad + (size_t)i * SLOT_MAX * PG);
 #pragma unroll
                     for (int k = 0; k < SLOT_MAX / 4; ++k) {
                         if (4 * k >= nt) break;
-                        const int pos[4] = {s4[k].x, s4[k].y, s4[k].z, s4[k].w};
                         float4 r0[4], r1[4], r2[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const bool ok = 4 * k + j < nt && pos[j] >= 0;
-                            const float4* g4 = reinterpret_cast<const float4*>(pair_grad + (size_t)(ok ? pos[j] : 0) * PG);
-                            r0[j] = g4[0]; r1[j] = g4[1]; r2[j] = g4[2];
+                            if (k == 0) { r0[j] = f0[j]; r1[j] = f1[j]; r2[j] = f2[j]; }
+                            else { r0[j] = g4[3 * (4 * k + j)]; r1[j] = g4[3 * (4 * k + j) + 1]; r2[j] = g4[3 * (4 * k + j) + 2]; }
                         }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            if (4 * k + j < nt && pos[j] >= 0) {
+                            if (4 * k + j < nt && __float_as_int(r2[j].z) == stamp) {
                                 d0.x += r0[j].x; d0.y += r0[j].y; d0.z += r0[j].z; d0.w += r0[j].w;
                                 d1.x += r1[j].x; d1.y += r1[j].y; d1.z += r1[j].z; d1.w += r1[j].w;
                                 d2.x += r2[j].x; d2.y += r2[j].y;
@@ -160,8 +163,8 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GFL_PHASE(3, 2);
 #endif
-    // ---- wave-cooperative gather for the few splats with more than SLOT_MAX tiles: their list
-    // positions sit in the slot pool (offset encoded in the first slot); rows are wave-summed
+    // ---- wave-cooperative gather for the few splats with more than SLOT_MAX tiles: their rows are a run behind the others
+    // (wide_off), wave-summed
     {
         const int lane = threadIdx.x & 63;
         unsigned long long todo = __ballot(big);
@@ -170,15 +173,14 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
             todo &= todo - 1;
             const int si = __shfl(i, src);
             const int nt = __shfl(big_nt, src);
-            const int code = slot_inv[(size_t)si * SLOT_MAX];
+            const int off = wide_off[si];
             float a[10];
 #pragma unroll
             for (int k = 0; k < 10; ++k) a[k] = 0.f;
-            for (int q = lane; q < nt && code <= -2; q += 64) {
-                const int lo = slot_pool[-2 - code + q];
-                if (lo >= 0) {
-                    const float4* g4 = reinterpret_cast<const float4*>(pair_grad + (size_t)lo * PG);
-                    const float4 q0 = g4[0], q1 = g4[1], q2 = g4[2];
+            for (int q = lane; q < nt && off >= 0; q += 64) {
+                const float4* g4 = reinterpret_cast<const float4*>(pair_grad + (size_t)(wide_base + off + q) * PG);
+                const float4 q0 = g4[0], q1 = g4[1], q2 = g4[2];
+                if (__float_as_int(q2.z) == stamp) {
                     a[0] += q0.x; a[1] += q0.y; a[2] += q0.z; a[3] += q0.w; a[4] += q1.x; a[5] += q1.y; a[6] += q1.z;
                     a[7] += q1.w; a[8] += q2.x; a[9] += q2.y;
                 }
@@ -459,8 +461,8 @@ __global__ void __launch_bounds__(1024) fused_camera_adam_kernel(
 void launch_splat_bwd_adam(const gfl_fit_state* st, const FitWs& w, int gx, int gy, const RegCfg& rc, const AdamCfg& ac,
                            const NextSched& ns, int extra, size_t lds, hipStream_t s) {
     fused_preprocess_bwd_adam_kernel<false><<<ns.rows + extra, REDUCE_BLOCK, lds, s>>>(
-        st->params, st->adam_m, st->adam_v, st->intr, st->pose, st->rec, st->d_rec, w.pair_grad, w.slot_pool, st->tile_range,
-        w.slot_inv, gx, gy, st->N, st->W, st->H, st->flow_target, st->flow_w, st->still_target, st->still_w, st->row_flags, rc, ac,
+        st->params, st->adam_m, st->adam_v, st->intr, st->pose, st->rec, st->d_rec, w.pair_grad, w.wide_off, w.wide_base, w.stamp,
+        gx, gy, st->N, st->W, st->H, st->flow_target, st->flow_w, st->still_target, st->still_w, st->row_flags, rc, ac,
         st->step, w.partial, nullptr, nullptr, nullptr, w.scale_cnt, ns, st->overflow);
 }
 
@@ -468,7 +470,7 @@ void launch_splat_bwd_adam(const gfl_fit_state* st, const FitWs& w, int gx, int 
 void launch_splat_bwd_op(const gfl_fit_state* st, const FitWs& w, int gx, int gy, const NextSched& ns, int extra, size_t lds,
                          const float* d_uv, const float* d_depth, float* d_params, float* d_extr, hipStream_t s) {
     fused_preprocess_bwd_adam_kernel<true><<<ns.rows + extra, REDUCE_BLOCK, lds, s>>>(
-        st->params, nullptr, nullptr, st->intr, st->extr, st->rec, st->d_rec, w.pair_grad, w.slot_pool, st->tile_range, w.slot_inv,
+        st->params, nullptr, nullptr, st->intr, st->extr, st->rec, st->d_rec, w.pair_grad, w.wide_off, w.wide_base, w.stamp,
         gx, gy, st->N, st->W, st->H, nullptr, nullptr, nullptr, nullptr, nullptr, RegCfg{}, AdamCfg{}, nullptr, w.partial, d_uv,
         d_depth, d_params, nullptr, ns, nullptr);
     fold_partials_kernel<12><<<1, 256, 0, s>>>(w.partial, ns.rows, d_extr);
