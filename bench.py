@@ -288,6 +288,9 @@ def main():
     ap.add_argument("--no-coresident", action="store_true",
                     help="skip the secondary table of 1 / 2 / 3 clip fits sharing this GPU (clips_per_gpu)")
     ap.add_argument("--coresident-frames", type=int, default=8, help="frames per clip of that secondary table")
+    ap.add_argument("--collective", action="store_true",
+                    help="initialise the process group and run the barriers and the two metric all-reduces even when the "
+                         "world is ONE rank (under torchrun): the RCCL path of an N > 1 run on a one-GPU box")
     ap.add_argument("--snapshot-interval", type=int, default=10,
                     help="snapshots of the clip fit (the reference keeps three images every 10th iteration, "
                          "trainer.py:573-582); 0 = none")
@@ -311,7 +314,7 @@ def main():
     dev = torch.device("cuda", local_rank % n_dev)
     dist = None
     backend = None
-    if world > 1:
+    if world > 1 or (args.collective and "WORLD_SIZE" in os.environ):
         import torch.distributed as dist
         backend = "gloo" if shared else "nccl"
         if shared:

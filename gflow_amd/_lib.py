@@ -20,7 +20,7 @@ _lib = None
 
 c_void_p, c_int, c_float, c_size_t, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_int64
 
-MIN_VERSION = 300          # GFL_VERSION of the include/gflow_hip.h this binding mirrors (overflow[4], sort-order trailer)
+MIN_VERSION = 301          # GFL_VERSION of the include/gflow_hip.h this binding mirrors (overflow[4], sort-order trailer)
 
 # name -> (restype, argtypes); mirrors include/gflow_hip.h one to one
 _P = c_void_p
@@ -66,6 +66,7 @@ SIGNATURES = {
     "gfl_fit_snapshot_stage": (c_int, [_P, _P, _P]),
     "gfl_fit_snapshot_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gfl_fit_snapshot": (c_int, [_P, _P, _P, _P, _P, c_size_t, _P]),
+    "gfl_fit_iteration_snapshot": (c_int, [_P, _P, _P, _P, _P]),
     "gfl_render_fwd": (c_int, [_P, _P, _P]),
     "gfl_render_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "gfl_fit_prepare_targets": (c_int, [_P, _P]),

@@ -108,6 +108,7 @@ static FitWs carve(const gfl_fit_state* st) {
     p += up256((size_t)(st->cap > 0 ? st->cap : 1) * sizeof(int32_t));
     w.pool_counter = (int32_t*)p;
     w.stamp = w.pool_counter + 56;
+    w.snap_mm = (unsigned*)(w.pool_counter + 58);
     w.sched_valid = w.pool_counter + 16;
     w.regions_valid = w.pool_counter + 32;
     w.extent = w.pool_counter + 40;
@@ -228,7 +229,9 @@ static PreArgs pre_args(const gfl_fit_state* st, const gfl_fit_hyper* hp, const 
 }
 
 // reserved: the tile regions the previous iteration's last launch reserved are used (one launch instead of three).
-static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream, int op_mode, int reserved = 0) {
+// snap_lut / snap_u8 (gfl_fit_iteration_snapshot): this forward also leaves the three snapshot images, as uint8.
+static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_stream_t stream, int op_mode, int reserved = 0,
+                            const float* snap_lut = nullptr, uint8_t* snap_u8 = nullptr) {
     int rc = fit_check(st, hp);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
@@ -284,8 +287,18 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
     {
         StageScope p(ST_BLEND_FWD, s);
         const TileQueue q = {w.sched_fwd.list, w.sched_fwd.count, w.sched.counters, w.sched.nq, w.sched.cap_q};
-        launch_blend_fwd(st, hp->bg, gx, blend_grid(T, FWD_WG_PER_CU), st->render, st->final_T, st->n_contrib, q, w, 0, nullptr,
-                         nullptr, fwd_split_min(), s);
+        if (snap_u8) {
+            // the range of the splats' depths (the turbo map's normalisation), then the forward that composes rgb and
+            // depth_map_color in one walk, then "center" over the same lists
+            rc = check(hipMemsetAsync(w.snap_mm, 0, 2 * sizeof(unsigned), s));
+            if (rc) return rc;
+            if (st->N > 0) launch_rec_depth_range(st->rec, st->N, w.snap_mm, s);
+            launch_blend_fwd(st, hp->bg, gx, blend_grid(T, FWD_WG_PER_CU), st->render, st->final_T, st->n_contrib, q, w, 2,
+                             w.snap_mm, snap_lut, fwd_split_min(), s, snap_u8);
+            launch_center_blend(st, hp->bg, gx, T, nullptr, snap_u8 + (size_t)2 * st->W * st->H * 3, s);
+        } else
+            launch_blend_fwd(st, hp->bg, gx, blend_grid(T, FWD_WG_PER_CU), st->render, st->final_T, st->n_contrib, q, w, 0,
+                             nullptr, nullptr, fwd_split_min(), s);
         if (st->foot_flags) {
             // keep is in/out here: the footprint of this iteration's flagged splats is cleared from it, so it
             // carries the running union over the iterations of the stage exactly like the reference, which
@@ -335,14 +348,14 @@ int gfl_fit_snapshot(const gfl_fit_state* st, const gfl_fit_hyper* hp, const flo
     rc = check(hipMemsetAsync(workspace, 0, head_bytes, s));
     if (rc) return rc;
     if (st->N > 0) launch_rec_depth_range(st->rec, st->N, mm, s);
-    for (int mode = 1; mode <= 2; ++mode) {
-        // (the forward launch of the iteration used up the engine's own pull counters)
-        const TileQueue q = {w.sched_fwd.list, w.sched_fwd.count, pull + (mode - 1) * SCHED_MAX_QUEUES, w.sched.nq, w.sched.cap_q};
-        // (fewer workgroups per CU for these two launches, so that they disturb the fit's own kernels less, was measured in
+    {
+        // depth_map_color: the blend kernel over the forward's queues (the iteration's own launch used up the engine's pull counters)
+        const TileQueue q = {w.sched_fwd.list, w.sched_fwd.count, pull, w.sched.nq, w.sched.cap_q};
+        // (fewer workgroups per CU for this launch, so that it disturbs the fit's own kernels less, was measured in
         //  round 4: one per CU 0.871-0.886 s per 8-frame clip fit against 0.858-0.865 with five, three the same as five)
-        launch_blend_fwd(st, hp->bg, gx, blend_grid(T, FWD_WG_PER_CU), mode == 1 ? img_dc : img_c, fT, nc, q, w, mode, mm, lut,
-                         fwd_split_min(), s);
+        launch_blend_fwd(st, hp->bg, gx, blend_grid(T, FWD_WG_PER_CU), img_dc, fT, nc, q, w, 1, mm, lut, fwd_split_min(), s);
     }
+    launch_center_blend(st, hp->bg, gx, T, img_c, nullptr, s);       // center: a kernel of its own (gfl_fit_fwd.hip)
     launch_snapshot_u8(st->render, img_dc, img_c, P, out_u8, s);
     return check_launch();
 }
@@ -486,6 +499,14 @@ int gfl_fit_iterations(const gfl_fit_state* st, const gfl_fit_hyper* hp, int cou
         if (rc) return rc;
     }
     return GFL_OK;
+}
+
+int gfl_fit_iteration_snapshot(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float* lut, uint8_t* out_u8,
+                               gfl_stream_t stream) {
+    if (!lut || !out_u8) return GFL_ERR_INVALID;
+    int rc = fit_forward_impl(st, hp, stream, 0, 0, lut, out_u8);
+    if (rc) return rc;
+    return gfl_fit_backward_step(st, hp, stream);
 }
 
 int gfl_fit_reserved_supported(const gfl_fit_state* st, const gfl_fit_hyper* hp) {

@@ -322,6 +322,7 @@ struct FitWs {
     int32_t* wide_off;       // [cap] offset of a wide splat's run (written by the preprocess for wide splats only)
     long long wide_base;     // first row of the runs = cap * SLOT_MAX
     int32_t* stamp;          // the current forward's number (the forward blend's launch advances it)
+    unsigned* snap_mm;       // a snapshot iteration's depth range (two words, cmap_nonzero_lookup)
     int32_t* pool_counter;   // rows of the runs handed out by this iteration's preprocess
     int32_t* sched_valid;    // != 0: the tile queues in the workspace were built at the end of the last iteration
     Sched sched;             // tile queues of the backward blend; sched.work persists between calls
@@ -362,8 +363,9 @@ void launch_scatter(const gfl_fit_state* st, const FitWs& w, int nblk, int gx, i
 inline unsigned inv_of(int gx) { return (unsigned)((((unsigned long long)1 << 32) + (unsigned)gx - 1) / (unsigned)gx); }
 void launch_blend_fwd(const gfl_fit_state* st, float bg, int gx, int grid, float* out, float* final_T, int32_t* n_contrib,
                       const TileQueue& q, const FitWs& w, int mode, const unsigned* cmap_mm, const float* cmap_lut, int split_min,
-                      hipStream_t s);
+                      hipStream_t s, uint8_t* snap_u8 = nullptr);
 void launch_footprint(const gfl_fit_state* st, int gx, int T, hipStream_t s);
+void launch_center_blend(const gfl_fit_state* st, float bg, int gx, int T, float* out, uint8_t* out_u8, hipStream_t s);
 void launch_rec_depth_range(const float* rec, int N, unsigned* mm, hipStream_t s);
 void launch_snapshot_u8(const float* a, const float* b, const float* c, int P, uint8_t* out, hipStream_t s);
 void launch_snapshot_stage(const StageCopy& c, hipStream_t s);

@@ -1,6 +1,6 @@
 // Fused fit iteration, stage 2: front-to-back compositing (C = 4: rgb + depth) over the sorted per-tile lists, the
-// moving-splat footprint of the camera-only stage, and the snapshot's helper kernels (the two extra composites of a snapshot
-// are this file's blend kernel in modes 1 / 2).
+// moving-splat footprint of the camera-only stage, and the snapshot's kernels (its depth_map_color image is this file's blend
+// kernel in mode 1, its center image a kernel of its own).
 #include "gfl_fit.hpp"
 
 namespace gfl {
@@ -78,9 +78,21 @@ __device__ __forceinline__ float row_last(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x10 | (0x0F << 5)));
 }
 
+// a float image value as render2img stores it (render.py:158-166): clamp to [0, 1], x 255, truncate
+__device__ __forceinline__ uint8_t img_u8(float v) {
+    const float x = fminf(fmaxf(v, 0.f), 1.f) * 255.f;
+    return (uint8_t)(x != x ? 0.f : x);
+}
+
 // (mode: a template parameter -- the fit's forward, mode 0, carries none of the snapshot composites' code or constants)
+// mode 0: the fit's forward.  mode 1: the depth_map_color composite alone (gfl_fit_snapshot: a snapshot of a forward that has
+// already run).  mode 2: the forward of a SNAPSHOT iteration (gfl_fit_iteration_snapshot) -- the fit's forward, and in the same
+// walk the depth_map_color composite: the same alphas, transmittances and stop rule, three more sums per pixel with the turbo
+// colour of the splat's depth as the colour (render.py:76-91 blends the same lists a second time); both images leave as uint8
+// (snap_u8: [image][H][W][3], images 0 and 1), the render's float planes as always.  Round 5, until then: a second blend launch
+// on a side stream, 53 us every tenth iteration for the 4 us the three sums cost here.
 template <int mode>
-__global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(const float* __restrict__ rec,
+__global__ void __launch_bounds__(256, mode == 2 ? FWD_WG_PER_CU - 1 : FWD_WG_PER_CU) fused_blend_fwd_kernel(const float* __restrict__ rec,
                                                               const int32_t* __restrict__ ids,
                                                               const int32_t* __restrict__ tile_range, float bg, int W,
                                                               int H, int gx, unsigned inv_gx, float* __restrict__ out,
@@ -91,15 +103,17 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                                                               const float* __restrict__ cmap_lut, int split_min,
                                                               int32_t* __restrict__ tile_work,
                                                               const int32_t* __restrict__ first_slot,
-                                                              int32_t* __restrict__ stamp) {
+                                                              int32_t* __restrict__ stamp, uint8_t* __restrict__ snap_u8) {
+    constexpr bool FIT = mode != 1;          // the fit's own forward: stamp, work feedback
+    constexpr bool DC = mode == 2;           // ... which also composes depth_map_color
     // the number of this forward: the backward blend stamps its pair rows with it, the per-splat launch takes only rows that
     // carry it (FitWs.stamp; nobody reads it before this launch has ended)
-    if (mode == 0 && stamp && blockIdx.x == 0 && threadIdx.x == 0) *stamp += 1;
-    // mode 0: the records as they are.  The two snapshot-only images of render.py:76-106 are composites of the SAME
-    // lists with other per-splat values, made while a record is staged: mode 1 = colour := turbo map of the splat's
-    // depth (apply_float_colormap(non_zero=True), range in cmap_mm), mode 2 = unit blob at the centre (conic 1 0 1,
-    // opacity 1).
+    if (FIT && stamp && blockIdx.x == 0 && threadIdx.x == 0) *stamp += 1;
+    // mode 0: the records as they are.  mode 1: the depth_map_color image of render.py:76-91, a composite of the SAME lists
+    // with colour := turbo map of the splat's depth (apply_float_colormap(non_zero=True), range in cmap_mm), substituted while
+    // a record is staged.  (The third snapshot image, "center", has a kernel of its own below.)
     __shared__ RecLDS recs[FBL + 1];         // recs[FBL]: an all-zero record (opacity 0: never blends)
+    __shared__ float4 s_dc[DC ? FBL + 1 : 1];       // mode 2: the turbo colour of every staged splat's depth ([FBL]: zero)
     __shared__ unsigned char s_mask[FBL];
     __shared__ unsigned short s_hits[4][FBL];        // long first tiles: a wave's (= a 4x4 quarter's) hit list of the staged batch
     __shared__ int32_t s_gs[4][FBL / 64 + 1];        // ... and the number of hits in front of every 64-slot group
@@ -109,6 +123,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     if (threadIdx.x == 0) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         recs[FBL].p0 = z; recs[FBL].p1 = z; recs[FBL].p2 = z;
+        if (DC) s_dc[FBL] = z;
         s_vote[0] = 0; s_vote[1] = 0;
     }
     WgVote vote = wg_vote_init(s_vote);
@@ -175,11 +190,13 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
         const int qx0 = tx * GFL_TILE + (blk & 1) * 8 + (wave & 1) * 4, qy0 = ty * GFL_TILE + (blk >> 1) * 8 + (wave >> 1) * 4;
         const float fxq = (float)(qx0 + lr);
         float Tq[4], c0q[4], c1q[4], c2q[4], c3q[4];
+        float d0q[4], d1q[4], d2q[4];                // (mode 2: depth_map_color)
         int lastq[4];
         unsigned alive = 0;                          // bit g: pixel (column lr, row g) is in the image and has not stopped
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             Tq[g] = 1.f; c0q[g] = 0.f; c1q[g] = 0.f; c2q[g] = 0.f; c3q[g] = 0.f; lastq[g] = 0;
+            d0q[g] = 0.f; d1q[g] = 0.f; d2q[g] = 0.f;
             if (qx0 + lr < W && qy0 + g < H) alive |= 1u << g;
         }
         // (checkpoint layout of the backward pass: [boundary][T C0 C1 C2 C3][256 pixels of the tile, block-major])
@@ -225,11 +242,12 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                     if (mode == 1) {
                         const float3 col = cmap_nonzero_lookup(p2.y, cmap_mm, cmap_lut);
                         p1.z = col.x; p1.w = col.y; p2.x = col.z;
-                    } else if (mode == 2) {
-                        p0.z = 1.f; p0.w = 0.f; p1.x = 1.f; p1.y = 1.f;
-                        p2.z = p2.z < 0.f ? p2.z : alpha_cutoff(1.f, 1.f);
                     }
                     const int sl = tid + 256 * e;
+                    if (DC) {
+                        const float3 col = cmap_nonzero_lookup(p2.y, cmap_mm, cmap_lut);
+                        s_dc[sl] = make_float4(col.x, col.y, col.z, 0.f);
+                    }
                     recs[sl].p0 = p0; recs[sl].p1 = p1; recs[sl].p2 = p2;
                     s_mask[sl] = (unsigned char)block_mask(p0, p1, p2.z, tx * GFL_TILE + (blk & 1) * 8, ty * GFL_TILE + (blk >> 1) * 8, 4);
                 }
@@ -292,6 +310,8 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                     const int j = have ? (int)s_hits[wave][h + ls] : FBL;
                     const int pos1 = base - start + j + 1;
                     const float4 q0 = recs[j].p0, q1 = recs[j].p1, q2 = recs[j].p2;
+                    float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (DC) dq = s_dc[j];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const float fyq = (float)(qy0 + g);
@@ -325,6 +345,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                         const float w = (stopped || !live) ? 0.f : a * q;
                         c0q[g] = fmaf(q1.z, w, c0q[g]); c1q[g] = fmaf(q1.w, w, c1q[g]);
                         c2q[g] = fmaf(q2.x, w, c2q[g]); c3q[g] = fmaf(q2.y, w, c3q[g]);
+                        if (DC) { d0q[g] = fmaf(dq.x, w, d0q[g]); d1q[g] = fmaf(dq.y, w, d1q[g]); d2q[g] = fmaf(dq.z, w, d2q[g]); }
                         lastq[g] = max(lastq[g], (val && live && !stopped) ? pos1 : 0);
                         const float r15 = row_last(r);
                         if ((alive >> g) & 1u) Tq[g] = r15;                        // (rows that stopped keep t_new)
@@ -347,20 +368,29 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
         for (int g = 0; g < 4; ++g) {
             const float s0 = row_sum16(c0q[g]), s1 = row_sum16(c1q[g]), s2 = row_sum16(c2q[g]), s3 = row_sum16(c3q[g]);
             const int lastp = row_max16(lastq[g]);
+            float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+            if (DC) { e0 = row_sum16(d0q[g]); e1 = row_sum16(d1q[g]); e2 = row_sum16(d2q[g]); }
             if (ls == 0 && qx0 + lr < W && qy0 + g < H) {
                 const size_t pix = (size_t)(qy0 + g) * W + (qx0 + lr), plane = (size_t)H * W;
                 const float Tf = Tq[g];
-                out[pix] = fmaf(Tf, bg, s0);
-                out[plane + pix] = fmaf(Tf, bg, s1);
-                out[2 * plane + pix] = fmaf(Tf, bg, s2);
+                const float o0 = fmaf(Tf, bg, s0), o1 = fmaf(Tf, bg, s1), o2 = fmaf(Tf, bg, s2);
+                out[pix] = o0;
+                out[plane + pix] = o1;
+                out[2 * plane + pix] = o2;
                 out[3 * plane + pix] = fmaf(Tf, bg, s3);
                 final_T[pix] = Tf;
                 n_contrib[pix] = lastp;
+                if (DC) {
+                    uint8_t* u0 = snap_u8 + pix * 3;
+                    u0[0] = img_u8(o0); u0[1] = img_u8(o1); u0[2] = img_u8(o2);
+                    uint8_t* u1 = snap_u8 + (plane + pix) * 3;
+                    u1[0] = img_u8(fmaf(Tf, bg, e0)); u1[1] = img_u8(fmaf(Tf, bg, e1)); u1[2] = img_u8(fmaf(Tf, bg, e2));
+                }
             }
         }
-        if (mode == 0 && lane == 0) atomicAdd(&tile_work[4 * tile + blk], units + 1);
+        if (FIT && lane == 0) atomicAdd(&tile_work[4 * tile + blk], units + 1);
 #ifdef GFL_TRACE
-        if (lane == 0 && tile < 4096 && mode == 0) {
+        if (lane == 0 && tile < 4096 && FIT) {
             long long* t2 = g_fwd_trace2 + ((size_t)tile * 16 + blk * 4 + wave) * 4;
             t2[0] = tq_stage; t2[1] = tq_walk + (wall_clock64() - tq_mark); t2[2] = tq_steps; t2[3] = units;
         }
@@ -388,6 +418,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     // everything behind blends with weight 0 without a per-splat "done" flag; T keeps the value
     // the pixel stopped at.  (Lanes outside the image start stopped.)
     float T = 1.f, Tw = inside ? 1.f : 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f;              // (mode 2: depth_map_color)
     int last = 0;
     const unsigned long long alive0 = __ballot(inside);            // every pixel of the box that is in the image
 
@@ -401,9 +432,10 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
             if (mode == 1) {
                 const float3 col = cmap_nonzero_lookup(p2.y, cmap_mm, cmap_lut);
                 p1.z = col.x; p1.w = col.y; p2.x = col.z;
-            } else if (mode == 2) {
-                p0.z = 1.f; p0.w = 0.f; p1.x = 1.f; p1.y = 1.f;
-                p2.z = p2.z < 0.f ? p2.z : alpha_cutoff(1.f, 1.f);
+            }
+            if (DC) {
+                const float3 col = cmap_nonzero_lookup(p2.y, cmap_mm, cmap_lut);
+                s_dc[tid] = make_float4(col.x, col.y, col.z, 0.f);
             }
             recs[tid].p0 = p0; recs[tid].p1 = p1; recs[tid].p2 = p2;
             s_mask[tid] = (unsigned char)block_mask(p0, p1, p2.z, org_x, org_y);
@@ -465,6 +497,9 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                 float4 q0[FWD_UNITS], q1[FWD_UNITS], q2[FWD_UNITS];
 #pragma unroll
                 for (int u = 0; u < FWD_UNITS; ++u) { q0[u] = recs[j[u]].p0; q1[u] = recs[j[u]].p1; q2[u] = recs[j[u]].p2; }
+                float4 dq[FWD_UNITS];
+#pragma unroll
+                for (int u = 0; u < FWD_UNITS; ++u) dq[u] = DC ? s_dc[j[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
                 float al[FWD_UNITS];
                 bool val[FWD_UNITS];
 #pragma unroll
@@ -479,6 +514,7 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
                     const bool stop = test_T < GFL_T_MIN;            // now, or earlier (Tw = 0)
                     const float w = stop ? 0.f : a * Tw;
                     a0 = fmaf(q1[u].z, w, a0); a1 = fmaf(q1[u].w, w, a1); a2 = fmaf(q2[u].x, w, a2); a3 = fmaf(q2[u].y, w, a3);
+                    if (DC) { b0 = fmaf(dq[u].x, w, b0); b1 = fmaf(dq[u].y, w, b1); b2 = fmaf(dq[u].z, w, b2); }
                     T = stop ? T : test_T;
                     Tw = stop ? 0.f : test_T;
                     last = (val[u] && !stop) ? base - start + j[u] + 1 : last;
@@ -489,14 +525,21 @@ __global__ void __launch_bounds__(256, FWD_WG_PER_CU) fused_blend_fwd_kernel(con
     }
     if (inside) {
         const size_t pix = (size_t)py * W + px, plane = (size_t)H * W;
-        out[pix] = fmaf(T, bg, a0);
-        out[plane + pix] = fmaf(T, bg, a1);
-        out[2 * plane + pix] = fmaf(T, bg, a2);
+        const float o0 = fmaf(T, bg, a0), o1 = fmaf(T, bg, a1), o2 = fmaf(T, bg, a2);
+        out[pix] = o0;
+        out[plane + pix] = o1;
+        out[2 * plane + pix] = o2;
         out[3 * plane + pix] = fmaf(T, bg, a3);
         final_T[pix] = T;
         n_contrib[pix] = last;
+        if (DC) {
+            uint8_t* u0 = snap_u8 + pix * 3;
+            u0[0] = img_u8(o0); u0[1] = img_u8(o1); u0[2] = img_u8(o2);
+            uint8_t* u1 = snap_u8 + (plane + pix) * 3;
+            u1[0] = img_u8(fmaf(T, bg, b0)); u1[1] = img_u8(fmaf(T, bg, b1)); u1[2] = img_u8(fmaf(T, bg, b2));
+        }
     }
-    if (mode == 0 && lane == 0) atomicAdd(&tile_work[4 * tile + wb], units + 1);     // per 8x8 block (gfl_sched.hpp: block plan)
+    if (FIT && lane == 0) atomicAdd(&tile_work[4 * tile + wb], units + 1);     // per 8x8 block (gfl_sched.hpp: block plan)
     // the wave stopped before the split position: every pixel's state is frozen, final = checkpoint
     for (; ck_next < parts; ++ck_next) {
         float* c5 = ck + (size_t)(ck_next - 1) * 5 * 256;
@@ -574,6 +617,76 @@ __global__ void __launch_bounds__(256) footprint_kernel(const float* __restrict_
     }
     if (inside && marked) keep[(size_t)py * W + px] = 0;
 }
+// ------------------------------------------------- the "center" image of a snapshot (render.py:98-106)
+// alpha_blending over the SAME sorted lists with conic (1, 0, 1) and opacity 1: a unit blob at every splat's centre, which reaches
+// pixels within sqrt(2 ln 255) = 3.33 of it and nobody else.  Until round 5 this was the blend kernel in a mode of its own -- 57 us
+// on the side stream every tenth iteration, as long as the fit's own forward, although a pixel sees a handful of blobs: that kernel
+// is made for long walks (queues, block plans, checkpoints, the four-CU walk of a pile), and what it costs here is its per-item
+// latency.  This one is the footprint kernel's shape: a workgroup per tile, all tiles resident at once, lanes = pixels, a wave per
+// 8x8 block; the arithmetic of a pixel is the blend kernel's, term for term (splat_alpha2 on the substituted record, one splat at
+// a time in list order).
+__global__ void __launch_bounds__(256) center_blend_kernel(const float* __restrict__ rec, const int32_t* __restrict__ ids,
+                                                           const int32_t* __restrict__ tile_range, float bg, int W, int H, int gx,
+                                                           float* __restrict__ out, uint8_t* __restrict__ out_u8) {
+    __shared__ RecLDS recs[FB];
+    __shared__ unsigned char s_mask[FB];
+    const int tile = blockIdx.x;
+    const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int px = tx * GFL_TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * GFL_TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float fx = (float)px, fy = (float)py;
+    const int start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
+    const float blob_cutoff = alpha_cutoff(1.f, 1.f);
+    float T = 1.f, Tw = inside ? 1.f : 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int base = start; base < end; base += FB) {
+        if (__syncthreads_and(Tw == 0.f)) break;
+        const int idx = base + tid;
+        unsigned char m = 0;
+        if (idx < end) {
+            const int g = ids[idx];
+            const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g * REC);
+            float4 p0 = r4[0], p1 = r4[1], p2 = r4[2];
+            p0.z = 1.f; p0.w = 0.f; p1.x = 1.f; p1.y = 1.f;
+            p2.z = p2.z < 0.f ? p2.z : blob_cutoff;
+            recs[tid].p0 = p0; recs[tid].p1 = p1; recs[tid].p2 = p2;
+            m = (unsigned char)block_mask(p0, p1, p2.z, tx * GFL_TILE, ty * GFL_TILE);
+        }
+        s_mask[tid] = m;
+        __syncthreads();
+        const int cnt = min(FB, end - base);
+        for (int c0 = 0; c0 < cnt && !__all(Tw == 0.f); c0 += 64) {
+            const int slot = c0 + lane;
+            unsigned long long bits = __ballot(slot < cnt && ((s_mask[slot] >> wave) & 1));
+            while (bits) {
+                const int j = c0 + (int)__builtin_ctzll(bits);
+                bits &= bits - 1;
+                const float4 q1 = recs[j].p1;
+                float al, G;
+                const bool val = splat_alpha2(recs[j].p0, q1, fx, fy, al, G);
+                const float a = val ? al : 0.f;
+                const float test_T = Tw * (1.f - a);
+                const bool stop = test_T < GFL_T_MIN;
+                const float w = stop ? 0.f : a * Tw;
+                a0 = fmaf(q1.z, w, a0); a1 = fmaf(q1.w, w, a1); a2 = fmaf(recs[j].p2.x, w, a2);
+                T = stop ? T : test_T;
+                Tw = stop ? 0.f : test_T;
+            }
+        }
+    }
+    if (inside) {
+        const size_t pix = (size_t)py * W + px, plane = (size_t)H * W;
+        const float o0 = fmaf(T, bg, a0), o1 = fmaf(T, bg, a1), o2 = fmaf(T, bg, a2);
+        if (out_u8) {                                    // (a snapshot iteration: straight into the uint8 image)
+            uint8_t* u = out_u8 + pix * 3;
+            u[0] = img_u8(o0); u[1] = img_u8(o1); u[2] = img_u8(o2);
+        } else {
+            out[pix] = o0; out[plane + pix] = o1; out[2 * plane + pix] = o2;
+        }
+    }
+}
+
 // min over the non-zero / max over all depths of the records, as ordered-uint keys (the range of
 // apply_float_colormap(non_zero=True), color.py:28-31; the encoding of cmap_range_kernel of gfl_loss.hip, the minimum
 // COMPLEMENTED so that both words are initialised by the one memset that also clears the snapshot's pull counters)
@@ -607,8 +720,7 @@ __global__ void __launch_bounds__(256) snapshot_u8_kernel(const float* __restric
     for (int k = 0; k < 3; ++k) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            const float x = fminf(fmaxf(src[k][(size_t)ch * P + i], 0.f), 1.f) * 255.f;
-            out[((size_t)k * P + i) * 3 + ch] = (uint8_t)(x != x ? 0.f : x);
+            out[((size_t)k * P + i) * 3 + ch] = img_u8(src[k][(size_t)ch * P + i]);
         }
     }
 }
@@ -634,14 +746,19 @@ __global__ void __launch_bounds__(256) snapshot_stage_kernel(StageCopy c) {
 // ---- launchers (gfl_fit.hpp)
 void launch_blend_fwd(const gfl_fit_state* st, float bg, int gx, int grid, float* out, float* final_T, int32_t* n_contrib,
                       const TileQueue& q, const FitWs& w, int mode, const unsigned* cmap_mm, const float* cmap_lut, int split_min,
-                      hipStream_t s) {
+                      hipStream_t s, uint8_t* snap_u8) {
     auto kern = mode == 0 ? fused_blend_fwd_kernel<0> : (mode == 1 ? fused_blend_fwd_kernel<1> : fused_blend_fwd_kernel<2>);
     kern<<<grid, 256, 0, s>>>(st->rec, st->ids, st->tile_range, bg, st->W, st->H, gx, inv_of(gx), out, final_T, n_contrib, q, w.ckpt,
-                              cmap_mm, cmap_lut, split_min, w.sched_fwd.work, w.sched.first_slot, mode == 0 ? w.stamp : nullptr);
+                              cmap_mm, cmap_lut, split_min, w.sched_fwd.work, w.sched.first_slot, mode != 1 ? w.stamp : nullptr,
+                              snap_u8);
 }
 
 void launch_footprint(const gfl_fit_state* st, int gx, int T, hipStream_t s) {
     footprint_kernel<<<T, 256, 0, s>>>(st->rec, st->ids, st->tile_range, st->foot_flags, st->W, st->H, gx, st->keep);
+}
+
+void launch_center_blend(const gfl_fit_state* st, float bg, int gx, int T, float* out, uint8_t* out_u8, hipStream_t s) {
+    center_blend_kernel<<<T, 256, 0, s>>>(st->rec, st->ids, st->tile_range, bg, st->W, st->H, gx, out, out_u8);
 }
 
 void launch_rec_depth_range(const float* rec, int N, unsigned* mm, hipStream_t s) {

@@ -25,6 +25,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
     extern __shared__ int32_t sched_scratch[];           // T ints + the block plans: the scheduling workgroups' scratch
     if ((int)blockIdx.x >= ns.rows) {
         __shared__ int32_t sched_wsum[BLOCK / 64];
+        GFL_PHASE(3, 0);
         if ((int)blockIdx.x == ns.rows + 2) {
             // ... and a third the next iteration's tile regions, its sort order, and what the column scan of the exact path
             // resets (the slot pool's counter, the blend launches' pull counters: both done with for this iteration)
@@ -34,6 +35,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
                 *ns.pool_counter = 0;
                 *ns.regions_valid = 1;
             }
+            GFL_PHASE(3, 7);
             return;
         }
         // the two workgroups behind the per-splat ones build the NEXT iteration's tile queues (see fused_scatter_kernel)
@@ -42,6 +44,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) fused_preprocess_bwd_adam_kernel
         schedule_tiles_xcd<BLOCK>(ns.tile_counts, ns.T, sc, sched_scratch, sched_wsum, sched_lds,
                                   reinterpret_cast<uint32_t*>(sched_scratch + ns.T));      // (T <= SCHED_PLAN_TILES: next_sched_ok)
         if (threadIdx.x == 0) *ns.valid = 1;
+        GFL_PHASE(3, 7);
         return;
     }
     GFL_PHASE(3, 0);

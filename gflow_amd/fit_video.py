@@ -157,7 +157,8 @@ def select_traj_seeds(tr, traj_num, traj_offset):
     return sp_still.tolist(), None
 
 
-def fit_clip(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, log=None, load_extr=True, keep=None):
+def fit_clip(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, log=None, load_extr=True, keep=None,
+             async_snapshots=None):
     """Fit one clip; returns the metrics dict of this clip (PSNR summed over its frames).
     ``load_extr`` (default True, like the reference's flag): frames that carry a camera pose
     (``extr``, read from the sequence's camera files) load it before they are fitted
@@ -166,7 +167,8 @@ def fit_clip(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, 
     trajectory images and seed projections as they left for the host (``keep["traj"]``)."""
     dev_ = torch.device(device)
     g = fit_clip_steps(frames, device, cfg=cfg, seed=seed, snapshot_interval=snapshot_interval, fused=fused, log=log,
-                       load_extr=load_extr, chunk=None, keep=keep)
+                       load_extr=load_extr, chunk=None, keep=keep,
+                       **({} if async_snapshots is None else {"async_snapshots": async_snapshots}))
 
     def drive():
         try:

@@ -57,6 +57,8 @@ def _declare(lib):
     lib.gfl_fit_iterations.argtypes = [ctypes.POINTER(FitState), ctypes.POINTER(FitHyper), ctypes.c_int, ctypes.c_int, _P]
     lib.gfl_fit_snapshot.restype = ctypes.c_int
     lib.gfl_fit_snapshot.argtypes = [ctypes.POINTER(FitState), ctypes.POINTER(FitHyper), _P, _P, _P, ctypes.c_size_t, _P]
+    lib.gfl_fit_iteration_snapshot.restype = ctypes.c_int
+    lib.gfl_fit_iteration_snapshot.argtypes = [ctypes.POINTER(FitState), ctypes.POINTER(FitHyper), _P, _P, _P]
     lib.gfl_render_bwd.restype = ctypes.c_int
     lib.gfl_render_bwd.argtypes = [ctypes.POINTER(FitState), ctypes.POINTER(FitHyper), _P, _P, _P, _P, _P, _P]
     lib._fit_declared = True
@@ -330,10 +332,10 @@ class FitEngine:
         return self.GFL_ITER_RESERVED if self._reserved_sup[1] else 0
 
     def iteration(self, use_graph=False, count=1, snapshot=False, flags=0, reserved=None):
-        """``count`` full iterations; ``snapshot=True`` (count 1): followed by gfl_fit_snapshot into the engine's own
-        image buffer -- returns that (3, H, W, 3) uint8 tensor, which the NEXT snapshot overwrites -- so that the
-        iteration and the eight launches of the snapshot replay as ONE graph (launched one by one they left ~6 us
-        between each other: 40-50 us per snapshot, every tenth iteration of a clip fit).  ``use_graph=True`` replays a hipGraph of the launches (captured
+        """``count`` full iterations; ``snapshot=True`` (count 1): the iteration's forward also leaves the three snapshot
+        images (gfl_fit_iteration_snapshot: rgb and depth_map_color out of one walk of the lists, center from a small kernel)
+        in the engine's own image buffer -- returns that (3, H, W, 3) uint8 tensor, which the NEXT snapshot overwrites.
+        ``use_graph=True`` replays a hipGraph of the launches (captured
         lazily, re-captured whenever a pointer, a size or a hyper-parameter changed); it is ignored
         while the library's stage profiler is recording events.  Several iterations in ONE graph save the
         2-6 us that pass between two graph launches (tools/graph_gap.py: 0.2094 -> 0.2028, 0.2079 -> 0.2058 ms per
@@ -343,12 +345,10 @@ class FitEngine:
             from .color import lut
             assert count == 1
             if getattr(self, "_snap_out", None) is None:
-                need = self.lib.gfl_fit_snapshot_workspace_bytes(self.cap, self.W, self.H)
-                self._snap_ws = torch.empty(int(need), dtype=torch.uint8, device=self.dev)
                 self._snap_out = torch.empty(3, self.H, self.W, 3, dtype=torch.uint8, device=self.dev)
-            snap_args = (L.ptr(lut("turbo", self.dev)), L.ptr(self._snap_out), L.ptr(self._snap_ws), self._snap_ws.numel())
+            snap_args = (L.ptr(lut("turbo", self.dev)), L.ptr(self._snap_out))
         # (reserved=False: the first iteration of the call takes the exact binning path whatever came before)
-        reserved = 0 if (flags or reserved is False) else self._reserved_flag()
+        reserved = 0 if (flags or reserved is False or snapshot) else self._reserved_flag()      # (a snapshot iteration bins exactly)
         gkey = ("snap", count, reserved) if snapshot else (count, reserved)
         if use_graph and not PROFILE["mask"] and self._launched and not flags:
             key = bytes(self.state()) + bytes(self.hp)
@@ -378,11 +378,12 @@ class FitEngine:
                         with torch.cuda.stream(side):
                             g.capture_begin(capture_error_mode="thread_local")
                             try:
-                                L.check(self.lib.gfl_fit_iterations(ctypes.byref(st), ctypes.byref(hp), count, reserved,
-                                                                    L.stream()), "fit iterations (capture)")
                                 if snapshot:
-                                    L.check(self.lib.gfl_fit_snapshot(ctypes.byref(st), ctypes.byref(hp), *snap_args,
-                                                                      L.stream()), "snapshot (capture)")
+                                    L.check(self.lib.gfl_fit_iteration_snapshot(ctypes.byref(st), ctypes.byref(hp), *snap_args,
+                                                                                L.stream()), "snapshot iteration (capture)")
+                                else:
+                                    L.check(self.lib.gfl_fit_iterations(ctypes.byref(st), ctypes.byref(hp), count, reserved,
+                                                                        L.stream()), "fit iterations (capture)")
                             finally:
                                 g.capture_end()
                         cur.wait_stream(side)
@@ -393,15 +394,15 @@ class FitEngine:
             g.replay()
             self._reserved_N = self.N
             return self._snap_out if snapshot else None
-        L.check(self.lib.gfl_fit_iterations(ctypes.byref(self.state()), ctypes.byref(self.hp), count, int(flags) | reserved,
-                                            L.stream()), "fit iterations")
+        if snapshot:
+            L.check(self.lib.gfl_fit_iteration_snapshot(ctypes.byref(self.state()), ctypes.byref(self.hp), *snap_args, L.stream()),
+                    "snapshot iteration")
+        else:
+            L.check(self.lib.gfl_fit_iterations(ctypes.byref(self.state()), ctypes.byref(self.hp), count, int(flags) | reserved,
+                                                L.stream()), "fit iterations")
         self._reserved_N = self.N
         self._launched = True          # every kernel is loaded now: capture is safe from here on
-        if snapshot:
-            L.check(self.lib.gfl_fit_snapshot(ctypes.byref(self.state()), ctypes.byref(self.hp), *snap_args, L.stream()),
-                    "snapshot")
-            return self._snap_out
-        return None
+        return self._snap_out if snapshot else None
 
     def snapshot(self, out=None):
         """(3, H, W, 3) uint8 on the device: rgb, depth_map_color, center of the last forward (gfl_fit_snapshot).

@@ -87,8 +87,9 @@ typedef enum gfl_status {
 /* 300 (round 5): gfl_fit_state.overflow is int32[4] (was [1] before 200's reserved regions), gfl_tile_sort_ordered reads a
  * trailer of GFL_SORT_ORDER_TRAILER ints behind order[T][4], gfl_fit_iterations' flags are GFL_ITER_RESERVED only
  * (GFL_ITER_PRE_DONE / _PRE_NEXT / _ODD, gfl_fit_next_preprocess_supported and gfl_bwd_rows_on are gone), the fit
- * workspace is smaller (one slot pool).  A binding checks gfl_version() >= GFL_VERSION of the header it was written for. */
-#define GFL_VERSION 300
+ * workspace is smaller (one slot pool).  301: gfl_fit_iteration_snapshot.
+ * A binding checks gfl_version() >= GFL_VERSION of the header it was written for. */
+#define GFL_VERSION 301
 int gfl_version(void);
 /* out[10] = TILE, NEAREST, EXTENT, FOV_CLAMP, LOWPASS, EIG_FLOOR, RADIUS_SIGMA, ALPHA_MIN, ALPHA_MAX, T_MIN of this build */
 int gfl_constants(float* out10);
@@ -358,15 +359,23 @@ int gfl_render_bwd(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float
  * device: rgb of the last forward, the turbo-coloured depth map and the centre blobs (render.py:76-106; both composites
  * of the same lists, the per-splat values are derived while the records are staged), each clamped, scaled by 255 and
  * truncated like render2img (render.py:158-166).  out_u8 [3 images][H][W][3] uint8; lut [256][3] = the turbo table.
- * Call it AFTER the iteration's backward (it reuses the forward's workspace). */
+ * For a forward that has already run (an evaluation render, a staged copy): the lists are walked again for
+ * depth_map_color. */
+size_t gfl_fit_snapshot_workspace_bytes(int N, int W, int H);
+int gfl_fit_snapshot(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float* lut, uint8_t* out_u8, void* workspace,
+                     size_t workspace_bytes, gfl_stream_t stream);
+/* One full iteration (gfl_fit_iteration, exact binning path) whose forward ALSO leaves those three images in out_u8 -- what
+ * trainer.py:573-582 does every 10th iteration with three more renders.  rgb and depth_map_color come out of ONE walk of the
+ * lists (the second composite has the first one's alphas and transmittances: three more sums per pixel), center from a small
+ * kernel over the same lists; nothing is composed twice and nothing waits for the backward.  +~25 us on that iteration
+ * (gfl_fit_snapshot after it: ~130 us).  lut [256][3] = the turbo table; out_u8 [3][H][W][3]. */
+int gfl_fit_iteration_snapshot(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float* lut, uint8_t* out_u8,
+                               gfl_stream_t stream);
 /* Copies from one engine to another (same image size, same row count N, capacities at least as large) everything
  * gfl_fit_snapshot reads of a forward: records, sorted ids, tile ranges, the rgb planes of the render and the forward's
  * tile queues -- one launch, ~9 MB at 480p / 60 000 splats.  The snapshot of iteration i can then be taken from the copy,
  * on another stream, BESIDE iteration i + 1 (gflow_amd/trainer.py: _snapshot_async) instead of between the two. */
 int gfl_fit_snapshot_stage(const gfl_fit_state* src, const gfl_fit_state* dst, gfl_stream_t stream);
-size_t gfl_fit_snapshot_workspace_bytes(int N, int W, int H);
-int gfl_fit_snapshot(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float* lut, uint8_t* out_u8, void* workspace,
-                     size_t workspace_bytes, gfl_stream_t stream);
 /* once per ground-truth image / keep mask: SSIM statistics of the target into the workspace; set
  * st->gt_cached = 1 afterwards (0 is always valid: everything is then recomputed per iteration) */
 int gfl_fit_prepare_targets(const gfl_fit_state* st, gfl_stream_t stream);

@@ -468,6 +468,30 @@ def test_bench_with_two_ranks_on_this_box():
     assert d["ms_per_step"] > 0 and "cpu_baseline" not in d
 
 
+def test_bench_collectives_over_rccl_with_one_rank():
+    """The collective path of an N > 1 run as far as a one-GPU box can take it: ``bench.py --collective`` under
+    torch.distributed.run with ONE rank initialises the ``nccl`` (= RCCL) process group on the device, and the barriers, the
+    MAX and the SUM of the metric line all go through RCCL on HIP tensors -- the calls an 8-GPU run makes, with one rank."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29631", "bench.py", "--gpus", "1", "--collective", "--clip-frames", "2", "--steps", "4", "--warmup", "2",
+           "--no-cpu-baseline", "--no-coresident"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["collective_backend"] == "nccl"
+    c = d["clip_fit"]
+    assert c["frames_per_rank"] == 2 and len(c["rank_wall_s"]) == 1 and c["rank_wall_s"][0] > 0.0
+    assert abs(d["value"] - 2 / c["wall_s"]) < 1e-6 * d["value"]
+    assert d["roofline"] and 0 < d["roofline"]["frac"] < 1
+
+
 def test_fit_clip_renders_the_trajectories_of_every_frame():
     """fit_clip with the README's ``--traj_num 100 --traj_offset 2`` keeps the reference's frame loop whole: grid seeds from the
     first frame's hull mask (fit_video.py:163-211), then after the first and after EVERY later frame trainer.eval(traj_index,

@@ -152,6 +152,31 @@ def test_fullsize_reserved_regions_against_the_exact_path(which):
         assert int((tr[:, 1] - tr[:, 0]).max()) > 1200
 
 
+@pytest.mark.parametrize("which", ["bench_scene", "densified_scene"])
+def test_fullsize_snapshot_iteration_against_the_snapshot_of_its_forward(which):
+    """The snapshot iteration (gfl_fit_iteration_snapshot: rgb and depth_map_color out of one walk, center from its own kernel)
+    at 480x854 / 60 000 splats, on the bench scene and on the scene with a 1 500-splat pile (the long-tile walk: sixteen splats
+    per step, the partial sums of a pixel folded at the end -- the three extra sums too): the three uint8 images against
+    gfl_fit_snapshot of the same forward byte for byte, the render the loss sees against a plain iteration's bit for bit."""
+    frame, raw = _bench_scene() if which == "bench_scene" else _densified_scene()
+    s = dict(W=W, H=H, intr=raw["intr"])
+    hyper = dict(lambda_rgb=1.0, lambda_depth=0.1, lambda_var=10.0, lr=1e-3, lr_camera=0.0, total_iters=500)
+    a = _engine({k: raw[k] for k in NAMES}, s, frame["image"], frame["depth"], **hyper)
+    b = _engine({k: raw[k] for k in NAMES}, s, frame["image"], frame["depth"], **hyper)
+    for it in range(2):
+        got = a.iteration(snapshot=True).clone()
+        b.iteration(reserved=False)
+        want = b.snapshot()
+        torch.cuda.synchronize()
+        assert torch.equal(a.render, b.render) and torch.equal(a.final_T, b.final_T) and torch.equal(a.n_contrib, b.n_contrib)
+        for k, name in enumerate(("rgb", "depth_map_color", "center")):
+            assert torch.equal(got[k], want[k]), f"{which} {name}, iteration {it}: " \
+                f"{(got[k] != want[k]).float().mean().item():.2e} of the bytes differ"
+        assert got[1].float().std() > 10 and got[2].float().std() > 10          # (images, not blanks)
+        from tests.test_gpu_fused import _copy_engine_state
+        _copy_engine_state(a, b)         # (the backward's LDS adds are unordered: the next comparison starts from the same rows)
+
+
 def test_config3_shape_eight_frame_clip_at_480p_60k():
     """configs[2] at full size, shortened to 8 frames: 500 first-frame iterations, then 150 camera-only + 300 joint per
     frame, densification at 149 / 299 and 0 / 99, flow / still terms, hipGraph replay between the events."""

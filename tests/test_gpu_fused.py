@@ -293,6 +293,40 @@ def test_snapshot_images_match_the_oracle(setup):
     assert (eng2.params[:n, :14] - eng3.params[:n, :14]).abs().max().item() < 1e-5
 
 
+def test_snapshot_iteration_leaves_the_images_of_its_own_forward(setup):
+    """gfl_fit_iteration_snapshot (FitEngine.iteration(snapshot=True)): the iteration whose forward composes rgb and
+    depth_map_color in ONE walk and center with a kernel of its own, against the same iteration followed by gfl_fit_snapshot
+    (which walks the lists again, after the backward): the three uint8 images byte for byte -- the second composite has the
+    first one's alphas, transmittances and stop rule, term for term --, the render the loss sees bit for bit, and the rows
+    and loss sums the iteration leaves (the extra sums change nothing the fit sees).  Twice, with and without a hipGraph."""
+    s, raw, img, dep = setup
+    n = raw["xyz"].shape[0]
+    for use_graph in (False, True):
+        a = _engine(raw, s, img, dep, pose=POSE, lr=1e-3, lr_camera=1e-3, lambda_rgb=1.0, lambda_depth=0.1)
+        b = _engine(raw, s, img, dep, pose=POSE, lr=1e-3, lr_camera=1e-3, lambda_rgb=1.0, lambda_depth=0.1)
+        for it in range(3):
+            got = a.iteration(snapshot=True, use_graph=use_graph).clone()
+            b.iteration(reserved=False)
+            want = b.snapshot()
+            for k, name in enumerate(("rgb", "depth_map_color", "center")):
+                assert torch.equal(got[k], want[k]), f"{name}, iteration {it}, graph {use_graph}: " \
+                    f"{(got[k] != want[k]).float().mean().item():.2e} of the bytes differ"
+            assert torch.equal(a.render, b.render) and torch.equal(a.final_T, b.final_T) and torch.equal(a.n_contrib, b.n_contrib)
+            # (the backward's LDS adds are unordered: two runs of the SAME iteration agree to the last bits only)
+            rel = ((a.params[:n] - b.params[:n]).norm() / b.params[:n].norm()).item()
+            assert rel < 1e-6 and torch.allclose(a.sums, b.sums, rtol=1e-5, atol=1e-8), (rel, a.sums, b.sums)
+            _copy_engine_state(a, b)
+    # ... and against the oracle's three images
+    act = FO.activate(raw)
+    eng = _engine(raw, s, img, dep, pose=POSE, lr=0.0, lr_camera=0.0, lambda_rgb=1.0, lambda_depth=0.1)
+    got = eng.iteration(snapshot=True).cpu().numpy()
+    oc = MO.render_multiple([*act, s["intr"], LO.pose_to_extr(POSE), 0.0, s["W"], s["H"]], ["rgb", "depth_map_color", "center"])
+    for k, name in enumerate(("rgb", "depth_map_color", "center")):
+        want = (torch.clamp(oc[name].permute(1, 2, 0), 0.0, 1.0).numpy() * 255).astype(np.uint8)
+        d = np.abs(got[k].astype(np.int32) - want.astype(np.int32))
+        assert (d > 1).mean() < (1e-3 if name == "rgb" else 4e-3), f"{name}: {(d > 1).mean():.2e} of the values off"
+
+
 def test_trainer_fused_and_operator_paths_agree():
     """Short first-frame fit with densification through both trainer paths."""
     from gflow_amd import synthetic as S

@@ -52,6 +52,16 @@ for k, (name, labels) in NAMES.items():
     t = t[live]
     t = t[t[:, 0] > t[:, 0].max() - 20000]        # the last launch only (200 us)
     base = t[:, 0].min()
+    if k == 3:
+        # the scheduling workgroups behind the per-splat ones stamp only their start and their end
+        sched = (t[:, 1] == 0) & (t[:, 7] > 0)
+        names3 = ["backward queues", "forward queues", "regions + sort order"]
+        for b in range(int(sched.sum()) // 4):
+            w = t[sched][4 * b:4 * b + 4]
+            print(f"  scheduling workgroup {b} ({names3[b] if b < 3 else '?'}): start {(w[:, 0].min() - base) / 100.0:.2f} us, "
+                  f"end {(w[:, 7].max() - base) / 100.0:.2f} us")
+        print(f"  launch span with them {(t[:, :8].max() - base) / 100.0:.2f} us")
+        t = t[~sched]
     print(f"== {name}: {len(t)} waves, launch span {(t[:, :len(labels)].max() - base) / 100.0:.2f} us")
     prev = t[:, 0]
     for j, lab in enumerate(labels):
