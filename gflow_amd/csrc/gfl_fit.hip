@@ -348,6 +348,11 @@ int gfl_fit_snapshot(const gfl_fit_state* st, const gfl_fit_hyper* hp, const flo
     rc = check(hipMemsetAsync(workspace, 0, head_bytes, s));
     if (rc) return rc;
     if (st->N > 0) launch_rec_depth_range(st->rec, st->N, mm, s);
+    // center first: a kernel of its own (gfl_fit_fwd.hip), short-lived workgroups.  On a side stream (trainer.py: _snapshot_async)
+    // these launches run beside the NEXT iteration's binning and tile sort, and the persistent workgroups of the blend kernel
+    // below hold every CU's registers for their ~50 us: the tile sort beside them took 44 us instead of 14
+    // (tools/snapshot_gaps.py); behind this kernel they start when that iteration is past its sort.
+    launch_center_blend(st, hp->bg, gx, T, img_c, nullptr, s);
     {
         // depth_map_color: the blend kernel over the forward's queues (the iteration's own launch used up the engine's pull counters)
         const TileQueue q = {w.sched_fwd.list, w.sched_fwd.count, pull, w.sched.nq, w.sched.cap_q};
@@ -355,7 +360,6 @@ int gfl_fit_snapshot(const gfl_fit_state* st, const gfl_fit_hyper* hp, const flo
         //  round 4: one per CU 0.871-0.886 s per 8-frame clip fit against 0.858-0.865 with five, three the same as five)
         launch_blend_fwd(st, hp->bg, gx, blend_grid(T, FWD_WG_PER_CU), img_dc, fT, nc, q, w, 1, mm, lut, fwd_split_min(), s);
     }
-    launch_center_blend(st, hp->bg, gx, T, img_c, nullptr, s);       // center: a kernel of its own (gfl_fit_fwd.hip)
     launch_snapshot_u8(st->render, img_dc, img_c, P, out_u8, s);
     return check_launch();
 }

@@ -7,9 +7,10 @@ from gflow_amd import trainer as TR
 
 n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 snap = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+KW = {"async_snapshots": False} if os.environ.get("PROFILE_SYNC_SNAPSHOTS") == "1" else {}     # (in the snapshot iteration's own forward)
 dev = torch.device("cuda", 0)
 frames = FV.upload_clip(S.make_clip(n_frames, 480, 854, seed=0), dev)
-FV.fit_clip(frames[:2], dev, dict(num_points=60000), seed=0, snapshot_interval=snap)
+FV.fit_clip(frames[:2], dev, dict(num_points=60000), seed=0, snapshot_interval=snap, **KW)
 torch.cuda.synchronize()
 
 log = []
@@ -29,7 +30,7 @@ TR.SimpleGaussian.train = timed("train", orig_train)
 TR.SimpleGaussian.densify_by_pixels = timed("densify", orig_dens)
 TR.SimpleGaussian.make_stepper = timed("make_stepper", orig_make)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-m = FV.fit_clip(frames, dev, dict(num_points=60000), seed=0, snapshot_interval=snap)
+m = FV.fit_clip(frames, dev, dict(num_points=60000), seed=0, snapshot_interval=snap, **KW)
 torch.cuda.synchronize(); total = time.perf_counter() - t0
 print(f"total {total:.3f} s for {m['iterations']} iterations = {m['iterations']/total:.0f} it/s, {n_frames/total:.2f} frames/s")
 agg = {}
