@@ -497,9 +497,11 @@ __global__ void __launch_bounds__(256, mode == 2 ? FWD_WG_PER_CU - 1 : FWD_WG_PE
                 float4 q0[FWD_UNITS], q1[FWD_UNITS], q2[FWD_UNITS];
 #pragma unroll
                 for (int u = 0; u < FWD_UNITS; ++u) { q0[u] = recs[j[u]].p0; q1[u] = recs[j[u]].p1; q2[u] = recs[j[u]].p2; }
-                float4 dq[FWD_UNITS];
+                float4 dq[DC ? FWD_UNITS : 1];
+                if constexpr (DC) {
 #pragma unroll
-                for (int u = 0; u < FWD_UNITS; ++u) dq[u] = DC ? s_dc[j[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int u = 0; u < FWD_UNITS; ++u) dq[u] = s_dc[j[u]];
+                }
                 float al[FWD_UNITS];
                 bool val[FWD_UNITS];
 #pragma unroll
@@ -514,7 +516,7 @@ __global__ void __launch_bounds__(256, mode == 2 ? FWD_WG_PER_CU - 1 : FWD_WG_PE
                     const bool stop = test_T < GFL_T_MIN;            // now, or earlier (Tw = 0)
                     const float w = stop ? 0.f : a * Tw;
                     a0 = fmaf(q1[u].z, w, a0); a1 = fmaf(q1[u].w, w, a1); a2 = fmaf(q2[u].x, w, a2); a3 = fmaf(q2[u].y, w, a3);
-                    if (DC) { b0 = fmaf(dq[u].x, w, b0); b1 = fmaf(dq[u].y, w, b1); b2 = fmaf(dq[u].z, w, b2); }
+                    if constexpr (DC) { b0 = fmaf(dq[u].x, w, b0); b1 = fmaf(dq[u].y, w, b1); b2 = fmaf(dq[u].z, w, b2); }
                     T = stop ? T : test_T;
                     Tw = stop ? 0.f : test_T;
                     last = (val[u] && !stop) ? base - start + j[u] + 1 : last;

@@ -1,4 +1,4 @@
-for v in 256 448 640 896 100000; do
+for v in ${SPLITS:-256 448 640 896 100000}; do
   echo "== split_min $v"
   GFL_FWD_SPLIT_MIN=$v python bench.py --no-clip --no-cpu-baseline --steps 100 --warmup 10 2>/dev/null | python -c "
 import json,sys
