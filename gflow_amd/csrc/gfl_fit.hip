@@ -296,9 +296,16 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
             launch_blend_fwd(st, hp->bg, gx, blend_grid(T, FWD_WG_PER_CU), st->render, st->final_T, st->n_contrib, q, w, 2,
                              w.snap_mm, snap_lut, fwd_split_min(), s, snap_u8);
             launch_center_blend(st, hp->bg, gx, T, nullptr, snap_u8 + (size_t)2 * st->W * st->H * 3, s);
-        } else
-            launch_blend_fwd(st, hp->bg, gx, blend_grid(T, FWD_WG_PER_CU), st->render, st->final_T, st->n_contrib, q, w, 0,
-                             nullptr, nullptr, fwd_split_min(), s);
+        }
+        // (camera-only stage, black background: the footprint's workgroups ride behind the blend's in the same launch, mode 3 --
+        //  `fused_blend_fwd<3>` 53.0 us where the plain forward takes 50.5 and the footprint launch behind it took 9.8: 8-frame
+        //  clip fits 0.824-0.831 s against 0.826-0.843 s, three alternations on one box; a snapshot iteration keeps the launch)
+        const bool foot = st->foot_flags && !(hp->bg > 0.f) && st->N > 0;
+        if (foot && !st->keep) return GFL_ERR_INVALID;
+        const bool foot_inside = foot && !snap_u8;
+        if (!snap_u8)
+            launch_blend_fwd(st, hp->bg, gx, blend_grid(T, FWD_WG_PER_CU), st->render, st->final_T, st->n_contrib, q, w,
+                             foot_inside ? 3 : 0, nullptr, nullptr, fwd_split_min(), s);
         if (st->foot_flags) {
             // keep is in/out here: the footprint of this iteration's flagged splats is cleared from it, so it
             // carries the running union over the iterations of the stage exactly like the reference, which
@@ -309,7 +316,7 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
             //  stream, forked and joined with events inside the captured graph, 4-frame clip fits took 0.455-0.456 s against
             //  0.445-0.455 s with it behind the forward: like the snapshot before it, a fork inside a graph does not pay.)
             if (!st->keep) return GFL_ERR_INVALID;
-            if (!(hp->bg > 0.f) && st->N > 0) launch_footprint(st, gx, T, s);
+            if (foot && !foot_inside) launch_footprint(st, gx, T, s);
         }
     }
     return check_launch();

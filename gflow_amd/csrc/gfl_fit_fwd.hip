@@ -78,6 +78,76 @@ __device__ __forceinline__ float row_last(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x10 | (0x0F << 5)));
 }
 
+// ------------------------------------------------- moving-splat footprint (camera-only stage)
+// GFlow renders the tentative moving splats on their own and masks every pixel whose grey value
+// is > 0 (trainer.py:426-451).  With a black background that is exactly the set of pixels some
+// moving splat reaches with alpha >= 1/255 in a tile it was binned into: the first such splat in
+// depth order always blends (T = 1), and every colour is a sigmoid, hence > 0.  So no second sort
+// and composite: the flagged splats of every tile list mark their pixels, in any order.
+// One workgroup per tile walks the tile's list (already binned and sorted by the forward that just
+// ran) and evaluates only the flagged splats, lanes = pixels as in the blend; a wave stops as soon
+// as all its pixels are marked.  (A first version gave every flagged splat one wave that walked the
+// splat's bounding box: later frames of a clip grow moving splats hundreds of pixels wide, and
+// that launch then took 325 us.)
+// Round 5: in the fit's own iterations these workgroups ride BEHIND the blend kernel's in the same launch (mode 3 of
+// fused_blend_fwd_kernel: blocks past the blend grid each take a tile here) -- they are dispatched as the CUs whose queues have run
+// dry free their registers, i.e. into the launch's idle tail, instead of a launch of their own behind it (9.8 us, a third of a
+// clip's iterations).
+__device__ __forceinline__ void footprint_tile(const float* __restrict__ rec, const int32_t* __restrict__ ids,
+                                               const int32_t* __restrict__ tile_range, const uint8_t* __restrict__ foot_flags,
+                                               int W, int H, int gx, uint8_t* __restrict__ keep, int tile, RecLDS* recs,
+                                               unsigned char* s_mask) {
+    const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int px = tx * GFL_TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * GFL_TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float fx = (float)px, fy = (float)py;
+    const int start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
+    bool marked = !inside;                               // nothing left to find for this lane
+    for (int base = start; base < end; base += FB) {
+        if (__syncthreads_and(marked)) break;
+        const int idx = base + tid;
+        unsigned char m = 0;
+        if (idx < end) {
+            const int g = ids[idx];
+            if (foot_flags[g]) {
+                const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g * REC);
+                const float4 p0 = r4[0], p1 = r4[1], p2 = r4[2];
+                recs[tid].p0 = p0; recs[tid].p1 = p1;
+                m = (unsigned char)block_mask(p0, p1, p2.z, tx * GFL_TILE, ty * GFL_TILE);
+            }
+        }
+        s_mask[tid] = m;
+        __syncthreads();
+        const int cnt = min(FB, end - base);
+        for (int c0 = 0; c0 < cnt && !__all(marked); c0 += 64) {
+            const int slot = c0 + lane;
+            unsigned long long bits = __ballot(slot < cnt && ((s_mask[slot] >> wave) & 1));
+            while (bits) {
+                const int j = c0 + (int)__builtin_ctzll(bits);
+                bits &= bits - 1;
+                float alpha, G;
+                if (splat_alpha2(recs[j].p0, recs[j].p1, fx, fy, alpha, G)) marked = true;
+            }
+        }
+    }
+    if (inside && marked) keep[(size_t)py * W + px] = 0;
+}
+__global__ void __launch_bounds__(256) footprint_kernel(const float* __restrict__ rec, const int32_t* __restrict__ ids,
+                                                        const int32_t* __restrict__ tile_range,
+                                                        const uint8_t* __restrict__ foot_flags, int W, int H, int gx,
+                                                        uint8_t* __restrict__ keep) {
+    __shared__ RecLDS recs[FB];
+    __shared__ unsigned char s_mask[FB];
+    footprint_tile(rec, ids, tile_range, foot_flags, W, H, gx, keep, blockIdx.x, recs, s_mask);
+}
+struct FootArgs {            // mode 3 of the blend kernel
+    const uint8_t* flags;
+    uint8_t* keep;
+    int n_blend;             // workgroups of the blend itself; block n_blend + t takes tile t's footprint
+};
+
 // a float image value as render2img stores it (render.py:158-166): clamp to [0, 1], x 255, truncate
 __device__ __forceinline__ uint8_t img_u8(float v) {
     const float x = fminf(fmaxf(v, 0.f), 1.f) * 255.f;
@@ -103,9 +173,11 @@ __global__ void __launch_bounds__(256, mode == 2 ? FWD_WG_PER_CU - 1 : FWD_WG_PE
                                                               const float* __restrict__ cmap_lut, int split_min,
                                                               int32_t* __restrict__ tile_work,
                                                               const int32_t* __restrict__ first_slot,
-                                                              int32_t* __restrict__ stamp, uint8_t* __restrict__ snap_u8) {
+                                                              int32_t* __restrict__ stamp, uint8_t* __restrict__ snap_u8,
+                                                              FootArgs foot) {
     constexpr bool FIT = mode != 1;          // the fit's own forward: stamp, work feedback
     constexpr bool DC = mode == 2;           // ... which also composes depth_map_color
+    constexpr bool FOOT = mode == 3;         // ... with the footprint workgroups of the camera-only stage behind its own
     // the number of this forward: the backward blend stamps its pair rows with it, the per-splat launch takes only rows that
     // carry it (FitWs.stamp; nobody reads it before this launch has ended)
     if (FIT && stamp && blockIdx.x == 0 && threadIdx.x == 0) *stamp += 1;
@@ -120,6 +192,12 @@ __global__ void __launch_bounds__(256, mode == 2 ? FWD_WG_PER_CU - 1 : FWD_WG_PE
     __shared__ int32_t s_ticket;
     __shared__ int32_t s_simd[4];
     __shared__ int32_t s_vote[2];
+    if constexpr (FOOT) {
+        if ((int)blockIdx.x >= foot.n_blend) {
+            footprint_tile(rec, ids, tile_range, foot.flags, W, H, gx, foot.keep, (int)blockIdx.x - foot.n_blend, recs, s_mask);
+            return;
+        }
+    }
     if (threadIdx.x == 0) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         recs[FBL].p0 = z; recs[FBL].p1 = z; recs[FBL].p2 = z;
@@ -140,7 +218,7 @@ __global__ void __launch_bounds__(256, mode == 2 ? FWD_WG_PER_CU - 1 : FWD_WG_PE
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const TileItem item = next_item(queue, &s_ticket, first, true);
+    const TileItem item = next_item(queue, &s_ticket, first, true, FOOT ? (unsigned)foot.n_blend : gridDim.x);
     if (item.tile < 0) {
         if (item.part < 0) break;                    // the queue is empty
         if (item.part == 0) continue;                // ... but its items 1..3 may have to help other queues
@@ -564,61 +642,6 @@ __global__ void __launch_bounds__(256, mode == 2 ? FWD_WG_PER_CU - 1 : FWD_WG_PE
 #endif
   }
 }
-// ------------------------------------------------- moving-splat footprint (camera-only stage)
-// GFlow renders the tentative moving splats on their own and masks every pixel whose grey value
-// is > 0 (trainer.py:426-451).  With a black background that is exactly the set of pixels some
-// moving splat reaches with alpha >= 1/255 in a tile it was binned into: the first such splat in
-// depth order always blends (T = 1), and every colour is a sigmoid, hence > 0.  So no second sort
-// and composite: the flagged splats of every tile list mark their pixels, in any order.
-// One workgroup per tile walks the tile's list (already binned and sorted by the forward that just
-// ran) and evaluates only the flagged splats, lanes = pixels as in the blend; a wave stops as soon
-// as all its pixels are marked.  (A first version gave every flagged splat one wave that walked the
-// splat's bounding box: later frames of a clip grow moving splats hundreds of pixels wide, and
-// that launch then took 325 us.)
-__global__ void __launch_bounds__(256) footprint_kernel(const float* __restrict__ rec, const int32_t* __restrict__ ids,
-                                                        const int32_t* __restrict__ tile_range,
-                                                        const uint8_t* __restrict__ foot_flags, int W, int H, int gx,
-                                                        uint8_t* __restrict__ keep) {
-    __shared__ RecLDS recs[FB];
-    __shared__ unsigned char s_mask[FB];
-    const int tile = blockIdx.x;
-    const int tx = tile % gx, ty = tile / gx;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int px = tx * GFL_TILE + (wave & 1) * 8 + (lane & 7);
-    const int py = ty * GFL_TILE + (wave >> 1) * 8 + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const float fx = (float)px, fy = (float)py;
-    const int start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
-    bool marked = !inside;                               // nothing left to find for this lane
-    for (int base = start; base < end; base += FB) {
-        if (__syncthreads_and(marked)) break;
-        const int idx = base + tid;
-        unsigned char m = 0;
-        if (idx < end) {
-            const int g = ids[idx];
-            if (foot_flags[g]) {
-                const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)g * REC);
-                const float4 p0 = r4[0], p1 = r4[1], p2 = r4[2];
-                recs[tid].p0 = p0; recs[tid].p1 = p1;
-                m = (unsigned char)block_mask(p0, p1, p2.z, tx * GFL_TILE, ty * GFL_TILE);
-            }
-        }
-        s_mask[tid] = m;
-        __syncthreads();
-        const int cnt = min(FB, end - base);
-        for (int c0 = 0; c0 < cnt && !__all(marked); c0 += 64) {
-            const int slot = c0 + lane;
-            unsigned long long bits = __ballot(slot < cnt && ((s_mask[slot] >> wave) & 1));
-            while (bits) {
-                const int j = c0 + (int)__builtin_ctzll(bits);
-                bits &= bits - 1;
-                float alpha, G;
-                if (splat_alpha2(recs[j].p0, recs[j].p1, fx, fy, alpha, G)) marked = true;
-            }
-        }
-    }
-    if (inside && marked) keep[(size_t)py * W + px] = 0;
-}
 // ------------------------------------------------- the "center" image of a snapshot (render.py:98-106)
 // alpha_blending over the SAME sorted lists with conic (1, 0, 1) and opacity 1: a unit blob at every splat's centre, which reaches
 // pixels within sqrt(2 ln 255) = 3.33 of it and nobody else.  Until round 5 this was the blend kernel in a mode of its own -- 57 us
@@ -749,10 +772,14 @@ __global__ void __launch_bounds__(256) snapshot_stage_kernel(StageCopy c) {
 void launch_blend_fwd(const gfl_fit_state* st, float bg, int gx, int grid, float* out, float* final_T, int32_t* n_contrib,
                       const TileQueue& q, const FitWs& w, int mode, const unsigned* cmap_mm, const float* cmap_lut, int split_min,
                       hipStream_t s, uint8_t* snap_u8) {
-    auto kern = mode == 0 ? fused_blend_fwd_kernel<0> : (mode == 1 ? fused_blend_fwd_kernel<1> : fused_blend_fwd_kernel<2>);
-    kern<<<grid, 256, 0, s>>>(st->rec, st->ids, st->tile_range, bg, st->W, st->H, gx, inv_of(gx), out, final_T, n_contrib, q, w.ckpt,
-                              cmap_mm, cmap_lut, split_min, w.sched_fwd.work, w.sched.first_slot, mode != 1 ? w.stamp : nullptr,
-                              snap_u8);
+    auto kern = mode == 0 ? fused_blend_fwd_kernel<0> : (mode == 1 ? fused_blend_fwd_kernel<1> :
+                (mode == 2 ? fused_blend_fwd_kernel<2> : fused_blend_fwd_kernel<3>));
+    // mode 3: one more workgroup per tile behind the blend's own (footprint_tile)
+    const FootArgs foot = {st->foot_flags, st->keep, grid};
+    const int T = gx * ((st->H + GFL_TILE - 1) / GFL_TILE);
+    kern<<<mode == 3 ? grid + T : grid, 256, 0, s>>>(st->rec, st->ids, st->tile_range, bg, st->W, st->H, gx, inv_of(gx), out, final_T,
+                              n_contrib, q, w.ckpt, cmap_mm, cmap_lut, split_min, w.sched_fwd.work, w.sched.first_slot,
+                              mode != 1 ? w.stamp : nullptr, snap_u8, foot);
 }
 
 void launch_footprint(const gfl_fit_state* st, int gx, int T, hipStream_t s) {

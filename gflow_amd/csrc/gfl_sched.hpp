@@ -519,7 +519,8 @@ struct TileItem {
 };
 
 // next item of this workgroup's queue.  Whole workgroup.  `split`: backward launch.
-__device__ __forceinline__ TileItem next_item(const TileQueue& q, int32_t* s_ticket, bool first, bool split) {
+// grid: the workgroups that pull from the queues (a launch may carry others behind them).
+__device__ __forceinline__ TileItem next_item(const TileQueue& q, int32_t* s_ticket, bool first, bool split, unsigned grid) {
     TileItem it;
     it.queue = blockIdx.x % q.nq;
     it.part = -1;
@@ -528,7 +529,7 @@ __device__ __forceinline__ TileItem next_item(const TileQueue& q, int32_t* s_tic
     int idx = blockIdx.x / q.nq;                     // first pull: the slot number, no atomic
     if (!first) {
         __syncthreads();                             // the previous tile's LDS traffic is complete
-        if (threadIdx.x == 0) *s_ticket = (int)(gridDim.x / q.nq) + atomicAdd(&q.counter[it.queue], 1);
+        if (threadIdx.x == 0) *s_ticket = (int)(grid / q.nq) + atomicAdd(&q.counter[it.queue], 1);
         __syncthreads();
         idx = *s_ticket;
     }

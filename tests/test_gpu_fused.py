@@ -441,6 +441,15 @@ def test_footprint_mask_matches_the_extra_render(setup):
     eng.forward()
     keep2 = eng.keep.bool().cpu()
     assert not (keep2 & ~keep).any() and (keep & ~keep2).any()
+    # the footprint's workgroups ride in the forward blend's launch (mode 3); a snapshot iteration keeps the footprint launch of
+    # its own behind the blend: the same mask from the same rows and the same mask before it
+    a = _engine(raw, s, img, dep, pose=POSE, lr=0.0, lr_camera=0.0)
+    b = _engine(raw, s, img, dep, pose=POSE, lr=0.0, lr_camera=0.0)
+    for e in (a, b):
+        e.set_footprint_mask(move_mask, moving)
+    a.iteration()
+    b.iteration(snapshot=True)
+    assert torch.equal(a.keep, b.keep) and torch.equal(a.keep.bool().cpu(), keep) and torch.equal(a.render, b.render)
     # a non-black background lights every pixel of the extra render: everything is masked
     eng.hp.bg = 0.5
     eng.set_footprint_mask(move_mask, moving)
