@@ -82,7 +82,7 @@ size_t gfl_fit_workspace_bytes(int cap, int K_cap, int W, int H) {
            + up256(2 * SCHED_MAX_QUEUES * sizeof(int32_t))                          // ... queue lengths
            + up256(gfl_loss_workspace_bytes(W, H)) + 256
            + up256((size_t)6 * W * H * sizeof(float))                                  // SSIM statistics of the target
-           + up256((size_t)fit_nblk(cap > 0 ? cap : 1) * sizeof(int32_t))              // rows of the scale term per block
+           + up256((size_t)2 * fit_nblk(cap > 0 ? cap : 1) * sizeof(int32_t))          // rows of the scale term per 256 splats
            + up256((T * 4 + SORT_ORDER_TRAILER) * sizeof(int32_t))                     // the tile sort's order (+ its split list)
            + up256((T * 4 + SORT_ORDER_TRAILER) * sizeof(int32_t))                     // reserved tile regions: the next sort order,
            + up256(T * sizeof(int4)) + up256(T * sizeof(int32_t));                      //   {start, capacity, position} per tile, fill counters
@@ -145,7 +145,7 @@ static FitWs carve(const gfl_fit_state* st) {
     w.loss_ws_bytes = up256(gfl_loss_workspace_bytes(st->W, st->H));
     w.gt_stats = (float*)((char*)p + w.loss_ws_bytes + 256);
     w.scale_cnt = (int32_t*)((char*)w.gt_stats + up256((size_t)6 * st->W * st->H * sizeof(float)));
-    w.sort_order = (int4*)((char*)w.scale_cnt + up256((size_t)fit_nblk(st->cap > 0 ? st->cap : 1) * sizeof(int32_t)));
+    w.sort_order = (int4*)((char*)w.scale_cnt + up256((size_t)2 * fit_nblk(st->cap > 0 ? st->cap : 1) * sizeof(int32_t)));
     w.sort_order_next = (int4*)((char*)w.sort_order + up256((T * 4 + SORT_ORDER_TRAILER) * sizeof(int32_t)));
     w.region = (int4*)((char*)w.sort_order_next + up256((T * 4 + SORT_ORDER_TRAILER) * sizeof(int32_t)));
     w.fill = (int32_t*)((char*)w.region + up256(T * sizeof(int4)));
@@ -474,7 +474,7 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
     const int rows = reduce_rows(st->N > 0 ? st->N : 1);
     RegCfg rcfg;
     rcfg.lambda_scale = hp->lambda_scale;
-    rcfg.scale_blocks = fit_nblk(st->N > 0 ? st->N : 1);
+    rcfg.scale_blocks = 2 * fit_nblk(st->N > 0 ? st->N : 1);      // (one partial per 256 splats: preprocess_block)
     rcfg.lambda_var = st->N > 0 ? hp->lambda_var / (float)st->N : 0.f;
     rcfg.lambda_flow = hp->lambda_flow;
     rcfg.lambda_still = hp->lambda_still;

@@ -25,6 +25,16 @@
 namespace gfl {
 
 constexpr int BIN_BLOCK = 512;
+// splats per workgroup of the one-launch binning on reserved tile regions (fused_preprocess_bin_kernel).  That launch is a chain of
+// latencies with ONE splat per lane -- 60 000 splats are 940 waves for 1 024 SIMDs, and 512-lane workgroups put them two to a SIMD
+// on 118 of the 256 CUs -- but 256-lane workgroups on 235 CUs are SLOWER: 23.0 us against 19.7 (tools/quick_trace.sh, round 5;
+// every workgroup clears its own T-int histogram, requests the T regions and reserves its part of every tile it touches: that
+// share of the launch doubles, the preprocess in between is a fifth of it).  -DGFL_RBIN_BLOCK=256 keeps the measurement repeatable.
+#ifndef GFL_RBIN_BLOCK
+#define GFL_RBIN_BLOCK 512
+#endif
+constexpr int RBIN_BLOCK = GFL_RBIN_BLOCK;
+static_assert(RBIN_BLOCK == 256 || RBIN_BLOCK == 512, "two scale-row partials per 512 splats (PreArgs.scale_cnt)");
 #ifndef GFL_WIDE_TILES
 #define GFL_WIDE_TILES 16
 #endif

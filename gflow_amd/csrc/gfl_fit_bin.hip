@@ -16,7 +16,7 @@
 namespace gfl {
 
 // BINNED: the block's histogram stays in LDS and what the scatter needs of the splat comes back in `po` (PreOut, gfl_fit.hpp)
-template <bool EWA_MFMA, bool PHASES, bool BINNED = false>
+template <bool EWA_MFMA, bool PHASES, bool BINNED = false, int BLOCK = BIN_BLOCK>
 __device__ __forceinline__ void preprocess_block(const PreArgs& a, const float4 (&row_v)[4], unsigned own_flags, int i,
                                                  int32_t* __restrict__ hist, PreOut* po = nullptr) {
     // op_mode (gfl_render_fwd): activated attributes in the rows, camera = the extrinsic in extr_out
@@ -107,13 +107,15 @@ __device__ __forceinline__ void preprocess_block(const PreArgs& a, const float4 
     if (a.scale_rows_mode) {
         // (no atomics on global memory: one partial per block, folded by every block of the backward kernel)
         const int wcnt = __popcll(__ballot(in_scale_rows));
-        __shared__ int32_t s_cnt[BIN_BLOCK / 64];
+        // (scale_cnt: one partial per 256 splats -- a 512-splat block leaves its count in the first of its two)
+        __shared__ int32_t s_cnt[BLOCK / 64];
         if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = wcnt;
         __syncthreads();
         if (threadIdx.x == 0) {
             int tot = 0;
-            for (int w = 0; w < BIN_BLOCK / 64; ++w) tot += s_cnt[w];
-            a.scale_cnt[blockIdx.x] = tot;
+            for (int w = 0; w < BLOCK / 64; ++w) tot += s_cnt[w];
+            if (BLOCK == 512) { a.scale_cnt[2 * blockIdx.x] = tot; a.scale_cnt[2 * blockIdx.x + 1] = 0; }
+            else a.scale_cnt[blockIdx.x] = tot;
         }
     }
     if (PHASES) GFL_PHASE(0, 5);
@@ -162,14 +164,15 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_fwd_kernel(const f
 // regions reserved at the end of the void iteration are sized by what the tiles WANTED, so the next iteration fits), and the
 // host runs one more iteration for each (FitEngine.settle_overflow).  Launches per iteration: 8 -> 6.
 template <bool EWA_MFMA>
-__global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_bin_kernel(const float* __restrict__ params, PreArgs a,
-                                                                         const uint8_t* __restrict__ row_flags, BinArgs b) {
+__global__ void __launch_bounds__(RBIN_BLOCK) fused_preprocess_bin_kernel(const float* __restrict__ params, PreArgs a,
+                                                                          const uint8_t* __restrict__ row_flags, BinArgs b) {
+    constexpr int BLOCK = RBIN_BLOCK;
     extern __shared__ int32_t hist[];               // [T] counts, then cursors; [T] limits behind them; 64 idle cursors
     const int T = a.gx * a.gy;
     int32_t* lim = hist + T;
     const int tid = threadIdx.x;
     GFL_PHASE(1, 0);                                 // (the column scan's row of the phase trace: it does not run here)
-    const int i = blockIdx.x * BIN_BLOCK + tid;
+    const int i = blockIdx.x * BLOCK + tid;
     float4 row_v[4] = {};
     unsigned own_flags = 0;
     if (i < a.N) {
@@ -179,35 +182,35 @@ __global__ void __launch_bounds__(BIN_BLOCK) fused_preprocess_bin_kernel(const f
         if (a.scale_rows_mode && row_flags) own_flags = row_flags[i];
     }
     // this lane's tiles' regions: requested here, used after the preprocess
-    constexpr int PER_MAX = 8;                       // (T <= 4096: fit_reserved_ok)
+    constexpr int PER_MAX = 4096 / BLOCK;            // (T <= 4096: fit_reserved_ok)
     int4 reg[PER_MAX];
 #pragma unroll
-    for (int k = 0; k < PER_MAX; ++k) reg[k] = tid + k * BIN_BLOCK < T ? b.region[tid + k * BIN_BLOCK] : make_int4(0, 0, 0, 0);
+    for (int k = 0; k < PER_MAX; ++k) reg[k] = tid + k * BLOCK < T ? b.region[tid + k * BLOCK] : make_int4(0, 0, 0, 0);
     if (blockIdx.x == 0 && tid == 0) {
         if (*b.regions_valid == 0) *a.overflow = 2;      // the host asked for regions nobody has reserved
         *b.regions_valid = 0;
         *b.extent = *b.extent_next;
     }
     if (blockIdx.x == 0)
-        for (int c = tid; c < b.n_pull; c += BIN_BLOCK) b.pull_counters[c] = 0;
-    for (int t = tid; t < T; t += BIN_BLOCK) hist[t] = 0;
+        for (int c = tid; c < b.n_pull; c += BLOCK) b.pull_counters[c] = 0;
+    for (int t = tid; t < T; t += BLOCK) hist[t] = 0;
     __syncthreads();
     GFL_PHASE(1, 1);
     PreOut o = {0.f, 0.f, 0.f, 0.f, 0};
-    preprocess_block<EWA_MFMA, false, true>(a, row_v, own_flags, i, hist, &o);      // (ends behind a barrier)
+    preprocess_block<EWA_MFMA, false, true, BLOCK>(a, row_v, own_flags, i, hist, &o);      // (ends behind a barrier)
     GFL_PHASE(1, 2);
     // ---- this block's part of every tile's region
     int got[PER_MAX], cnt[PER_MAX];
 #pragma unroll
     for (int k = 0; k < PER_MAX; ++k) {
-        const int t = tid + k * BIN_BLOCK;
+        const int t = tid + k * BLOCK;
         cnt[k] = t < T ? hist[t] : 0;
         got[k] = cnt[k] > 0 ? atomicAdd(&b.fill[reg[k].z], cnt[k]) : 0;
     }
     bool over = false, over_cap = false;
 #pragma unroll
     for (int k = 0; k < PER_MAX; ++k) {
-        const int t = tid + k * BIN_BLOCK;
+        const int t = tid + k * BLOCK;
         if (t < T) {
             hist[t] = reg[k].x + got[k];
             lim[t] = min(reg[k].x + reg[k].y, b.K_cap);
@@ -502,7 +505,8 @@ void launch_preprocess_bin(const float* params, const PreArgs& a, const uint8_t*
                            hipStream_t s) {
     const size_t lds = (size_t)a.gx * a.gy * sizeof(int32_t);
     auto kern = mfma ? fused_preprocess_bin_kernel<true> : fused_preprocess_bin_kernel<false>;
-    kern<<<nblk, BIN_BLOCK, 2 * lds + 64 * sizeof(int32_t), s>>>(params, a, row_flags, b);
+    (void)nblk;      // (the exact path's blocks; this launch has its own block size)
+    kern<<<(a.N + RBIN_BLOCK - 1) / RBIN_BLOCK, RBIN_BLOCK, 2 * lds + 64 * sizeof(int32_t), s>>>(params, a, row_flags, b);
 }
 
 void launch_colscan(const FitWs& w, int nblk, int T, int32_t* overflow, hipStream_t s) {
