@@ -19,7 +19,10 @@
  *       GFL_EWA_MFMA=1        J Sigma J^T on the matrix cores (same results to rounding; gfl_ewa_on_mfma() reports it);
  *       GFL_RESERVED=0        every iteration bins on the exact three-launch path (no reserved tile regions): the sorted
  *                             lists, render and gradients are bit-identical either way;
- *       GFL_FWD_SPLIT_MIN=<n> list length from which the forward blend walks a long tile on four CUs: scheduling only;
+ *       GFL_FWD_SPLIT_MIN=<n> list length from which the forward blend walks a queue's first tile on four CUs, sixteen splats
+ *                             a step: scheduling only -- that walk forms a pixel's transmittance products in tree order, so T and
+ *                             the render differ in the last bits on the tiles that take it (which tiles do depends on the
+ *                             schedule as well), lists and contributor counts not at all;
  *     tests/test_gpu_switches.py flips each one in a process of its own and holds the results against the defaults.
  *     (Rounds 3-4 had fourteen; the measured-and-rejected variants behind the others now live in tools/experiments/.)
  *   - return value: GFL_OK or a negative gfl_status; HIP launch errors are
