@@ -653,8 +653,12 @@ __global__ void __launch_bounds__(256, mode == 2 ? FWD_WG_PER_CU - 1 : FWD_WG_PE
 __global__ void __launch_bounds__(256) center_blend_kernel(const float* __restrict__ rec, const int32_t* __restrict__ ids,
                                                            const int32_t* __restrict__ tile_range, float bg, int W, int H, int gx,
                                                            float* __restrict__ out, uint8_t* __restrict__ out_u8) {
-    __shared__ RecLDS recs[FB];
+    __shared__ RecLDS recs[FB + 1];          // recs[FB]: an all-zero record (opacity 0: never blends)
     __shared__ unsigned char s_mask[FB];
+    if (threadIdx.x == 0) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        recs[FB].p0 = z; recs[FB].p1 = z; recs[FB].p2 = z;
+    }
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -684,19 +688,36 @@ __global__ void __launch_bounds__(256) center_blend_kernel(const float* __restri
         for (int c0 = 0; c0 < cnt && !__all(Tw == 0.f); c0 += 64) {
             const int slot = c0 + lane;
             unsigned long long bits = __ballot(slot < cnt && ((s_mask[slot] >> wave) & 1));
+            // four hit blobs per trip, as the blend kernel's whole-tile walk: records fetched and alphas evaluated together, only
+            // the T recurrence is serial (a pile's thousand blobs are walked by ONE wave for the ring of pixels around it)
             while (bits) {
-                const int j = c0 + (int)__builtin_ctzll(bits);
-                bits &= bits - 1;
-                const float4 q1 = recs[j].p1;
-                float al, G;
-                const bool val = splat_alpha2(recs[j].p0, q1, fx, fy, al, G);
-                const float a = val ? al : 0.f;
-                const float test_T = Tw * (1.f - a);
-                const bool stop = test_T < GFL_T_MIN;
-                const float w = stop ? 0.f : a * Tw;
-                a0 = fmaf(q1.z, w, a0); a1 = fmaf(q1.w, w, a1); a2 = fmaf(recs[j].p2.x, w, a2);
-                T = stop ? T : test_T;
-                Tw = stop ? 0.f : test_T;
+                int j[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    j[u] = bits ? c0 + (int)__builtin_ctzll(bits) : FB;      // (missing blobs of the last trip: the null record)
+                    bits &= bits - 1;
+                }
+                float4 q0[4], q1[4];
+                float cb[4], al[4];
+                bool val[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { q0[u] = recs[j[u]].p0; q1[u] = recs[j[u]].p1; cb[u] = recs[j[u]].p2.x; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float G;
+                    val[u] = splat_alpha2(q0[u], q1[u], fx, fy, al[u], G);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float a = val[u] ? al[u] : 0.f;
+                    const float test_T = Tw * (1.f - a);
+                    const bool stop = test_T < GFL_T_MIN;
+                    const float w = stop ? 0.f : a * Tw;
+                    a0 = fmaf(q1[u].z, w, a0); a1 = fmaf(q1[u].w, w, a1); a2 = fmaf(cb[u], w, a2);
+                    T = stop ? T : test_T;
+                    Tw = stop ? 0.f : test_T;
+                }
+                if (__all(Tw == 0.f)) break;
             }
         }
     }
