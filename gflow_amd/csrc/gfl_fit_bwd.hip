@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
     __syncthreads();
     const bool simd_ok = ((1 << s_simd[0]) | (1 << s_simd[1]) | (1 << s_simd[2]) | (1 << s_simd[3])) == 15;
   for (bool first = true;; first = false) {
-    const TileItem item = next_item(queue, &s_ticket, first, true, gridDim.x);
+    const TileItem item = next_item(queue, &s_ticket, first, HEAVY_PARTS, gridDim.x);
     const int tile = item.tile;
     if (tile < 0) break;
     const unsigned plan = item.plan;

@@ -3,6 +3,10 @@
 // kernel in mode 1, its center image a kernel of its own).
 #include "gfl_fit.hpp"
 
+#ifndef GFL_FWD_PARTS
+#define GFL_FWD_PARTS 4      // items the first tile of a forward queue counts as (next_item)
+#endif
+
 namespace gfl {
 
 // (RecLDS, splat_alpha2: gfl_fit.hpp; block_test / box_hit / block_mask: gfl_math.hpp)
@@ -218,7 +222,7 @@ __global__ void __launch_bounds__(256, mode == 2 ? FWD_WG_PER_CU - 1 : FWD_WG_PE
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const TileItem item = next_item(queue, &s_ticket, first, true, FOOT ? (unsigned)foot.n_blend : gridDim.x);
+    const TileItem item = next_item(queue, &s_ticket, first, GFL_FWD_PARTS, FOOT ? (unsigned)foot.n_blend : gridDim.x);
     if (item.tile < 0) {
         if (item.part < 0) break;                    // the queue is empty
         if (item.part == 0) continue;                // ... but its items 1..3 may have to help other queues
@@ -232,7 +236,7 @@ __global__ void __launch_bounds__(256, mode == 2 ? FWD_WG_PER_CU - 1 : FWD_WG_PE
     // reached by less than half of the splats that reach the block, and the launch lasts as long as the longest chain of
     // one wave (real fits pile ~1 000 splats into single tiles: their waves finished at 50-73 us, the mean CU at 29 us).
     int tile = item.tile, owner = item.queue;
-    if (item.part >= 4) continue;                    // (the backward pass has more segments than the forward pass blocks)
+    if (item.part >= 4) continue;                    // (only with -DGFL_FWD_PARTS=8, the mapping of rounds 2-4)
     if (item.part > 0) {
         owner = (item.queue + item.part * (queue.nq / 4)) % queue.nq;
         tile = queue.count[owner] > 0 ? (queue.list[(size_t)owner * queue.cap_q] & 0xffff) : -1;

@@ -518,9 +518,11 @@ struct TileItem {
     unsigned plan;   // block plan (ITEM_PLAN_*): plan >> (2 * simd) & 3 = the block the wave on that SIMD walks
 };
 
-// next item of this workgroup's queue.  Whole workgroup.  `split`: backward launch.
+// next item of this workgroup's queue.  Whole workgroup.  `parts`: the queue's first tile is that many items (the backward
+// launch: HEAVY_PARTS segments; the forward launch: four blocks -- with HEAVY_PARTS there too, every queue's tickets 4..7 were
+// drawn for nothing, a round trip each at the start of the launch).
 // grid: the workgroups that pull from the queues (a launch may carry others behind them).
-__device__ __forceinline__ TileItem next_item(const TileQueue& q, int32_t* s_ticket, bool first, bool split, unsigned grid) {
+__device__ __forceinline__ TileItem next_item(const TileQueue& q, int32_t* s_ticket, bool first, int parts, unsigned grid) {
     TileItem it;
     it.queue = blockIdx.x % q.nq;
     it.part = -1;
@@ -533,9 +535,8 @@ __device__ __forceinline__ TileItem next_item(const TileQueue& q, int32_t* s_tic
         __syncthreads();
         idx = *s_ticket;
     }
-    // backward: the first tile of the queue is HEAVY_PARTS items
-    const int k = split ? max(idx - (HEAVY_PARTS - 1), 0) : idx;
-    if (split && idx < HEAVY_PARTS) it.part = idx;   // (also when this queue is empty: the forward pass helps other queues)
+    const int k = max(idx - (parts - 1), 0);
+    if (idx < parts) it.part = idx;                  // (also when this queue is empty: the forward pass helps other queues)
     if (k >= q.count[it.queue]) return it;
     const int item = q.list[(size_t)it.queue * q.cap_q + k];
     it.tile = item & 0xffff;
