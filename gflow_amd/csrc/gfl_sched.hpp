@@ -518,23 +518,13 @@ struct TileItem {
     unsigned plan;   // block plan (ITEM_PLAN_*): plan >> (2 * simd) & 3 = the block the wave on that SIMD walks
 };
 
-// next item of this workgroup's queue.  Whole workgroup.  `parts`: the queue's first tile is that many items (the backward
-// launch: HEAVY_PARTS segments; the forward launch: four blocks -- with HEAVY_PARTS there too, every queue's tickets 4..7 were
-// drawn for nothing, a round trip each at the start of the launch).
-// grid: the workgroups that pull from the queues (a launch may carry others behind them).
-__device__ __forceinline__ TileItem next_item(const TileQueue& q, int32_t* s_ticket, bool first, int parts, unsigned grid) {
+// item number idx of this workgroup's queue when the queue's first tile counts as `parts` items
+__device__ __forceinline__ TileItem item_at(const TileQueue& q, int idx, int parts) {
     TileItem it;
     it.queue = blockIdx.x % q.nq;
     it.part = -1;
     it.tile = -1;
     it.plan = ITEM_PLAN_IDENTITY;
-    int idx = blockIdx.x / q.nq;                     // first pull: the slot number, no atomic
-    if (!first) {
-        __syncthreads();                             // the previous tile's LDS traffic is complete
-        if (threadIdx.x == 0) *s_ticket = (int)(grid / q.nq) + atomicAdd(&q.counter[it.queue], 1);
-        __syncthreads();
-        idx = *s_ticket;
-    }
     const int k = max(idx - (parts - 1), 0);
     if (idx < parts) it.part = idx;                  // (also when this queue is empty: the forward pass helps other queues)
     if (k >= q.count[it.queue]) return it;
@@ -547,6 +537,20 @@ __device__ __forceinline__ TileItem next_item(const TileQueue& q, int32_t* s_tic
     else if (prio == 1) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
     return it;
+}
+// next item of this workgroup's queue.  Whole workgroup.  `parts`: the queue's first tile is that many items (the forward
+// launch: four blocks -- with the backward's HEAVY_PARTS there too, every queue's tickets 4..7 were drawn for nothing, a round trip
+// each at the start of the launch; the backward launch: the segments its first tile really has, see there).
+// grid: the workgroups that pull from the queues (a launch may carry others behind them).
+__device__ __forceinline__ TileItem next_item(const TileQueue& q, int32_t* s_ticket, bool first, int parts, unsigned grid) {
+    int idx = blockIdx.x / q.nq;                     // first pull: the slot number, no atomic
+    if (!first) {
+        __syncthreads();                             // the previous tile's LDS traffic is complete
+        if (threadIdx.x == 0) *s_ticket = (int)(grid / q.nq) + atomicAdd(&q.counter[blockIdx.x % q.nq], 1);
+        __syncthreads();
+        idx = *s_ticket;
+    }
+    return item_at(q, idx, parts);
 }
 
 }  // namespace gfl

@@ -1,8 +1,12 @@
 #!/bin/bash
-# same-box A/B of the snapshot paths: the tests first, then 8-frame clip fits with the snapshots on the side stream / in the
-# snapshot iteration's own forward, alternating
-python -m pytest tests/test_gpu_fused.py tests/test_gpu_fitvideo.py tests/test_gpu_fullsize.py -x -q -k "snapshot" 2>&1 | tail -5
+# same-box A/B of two builds of the library (gflow_amd/libgflow_hip_old.so against libgflow_hip.so; same ABI): the bench window's
+# kernels under rocprofv3 and 4-frame clip fits, alternating
+cp gflow_amd/libgflow_hip.so /tmp/new.so
 for r in 1 2 3; do
-  echo -n "[async] "; python tools/clip_repeat.py 5 8 async 2>&1 | tail -1 | cut -c1-150
-  echo -n "[sync ] "; python tools/clip_repeat.py 5 8 sync 2>&1 | tail -1 | cut -c1-150
+  for v in old new; do
+    if [ $v = old ]; then cp gflow_amd/libgflow_hip_old.so gflow_amd/libgflow_hip.so; else cp /tmp/new.so gflow_amd/libgflow_hip.so; fi
+    echo "[$v]"; bash tools/quick_trace.sh ab 2>&1 | grep -E "blend_bwd|blend_fwd" | head -2
+    python tools/clip_repeat.py 5 4 2>&1 | tail -1 | cut -c1-110
+  done
 done
+cp /tmp/new.so gflow_amd/libgflow_hip.so
