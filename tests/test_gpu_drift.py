@@ -76,6 +76,6 @@ def test_eight_frames_at_480p_fused_and_operator_path_agree():
     (ma, pa, ta), (mb, pb, tb) = _fit_both(frames, dict(num_points=60000))
     assert ma["iterations"] == mb["iterations"] == 500 + 7 * 450
     assert max(abs(x - y) for x, y in zip(pa, pb)) < 0.8, (pa, pb)          # (observed: 0.1-0.5, run to run)
-    assert abs(sum(x - y for x, y in zip(pa, pb))) / 8 < 0.3, (pa, pb)
+    assert abs(sum(x - y for x, y in zip(pa, pb))) / 8 < 0.4, (pa, pb)      # (observed: -0.17 .. +0.11 over six runs, tools/drift_loop.py 6 full)
     assert abs(ta.current_pts_num() - tb.current_pts_num()) <= 0.04 * tb.current_pts_num()   # (observed: up to 2.3 %, run to run)
     assert pa[0] - pa[1] > 0.8 and pb[0] - pb[1] > 0.8, (pa, pb)          # both paths show the step
