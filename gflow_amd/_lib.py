@@ -20,7 +20,7 @@ _lib = None
 
 c_void_p, c_int, c_float, c_size_t, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_int64
 
-MIN_VERSION = 301          # GFL_VERSION of the include/gflow_hip.h this binding mirrors (overflow[4], sort-order trailer)
+MIN_VERSION = 302          # GFL_VERSION of the include/gflow_hip.h this binding mirrors (overflow[4], sort-order trailer)
 
 # name -> (restype, argtypes); mirrors include/gflow_hip.h one to one
 _P = c_void_p
@@ -54,9 +54,8 @@ SIGNATURES = {
     "gfl_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, c_float, c_float, c_float, c_float, _P, c_float, c_int, _P]),
     "gfl_step_increment": (c_int, [_P, _P]),
     "gfl_tile_sort_only": (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),
-    "gfl_tile_sort_with_slots": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
-    "gfl_tile_sort_ordered": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
-    "gfl_tile_sort_reserved": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "gfl_tile_sort_ordered": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "gfl_tile_sort_reserved": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     "gfl_fit_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "gfl_fit_forward": (c_int, [_P, _P, _P]),          # struct pointers; typed in gflow_amd/fused.py
     "gfl_fit_backward_step": (c_int, [_P, _P, _P]),

@@ -137,29 +137,6 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr a, int n) {
     }
 }
 
-// Optional inverse map for the fused backward: slot_rec = [cap][12] render records (u, v at 0,1,
-// radius bits at 11), slot_inv = [cap][SLOT_MAX]: for a splat whose tile rectangle has <= SLOT_MAX tiles,
-// slot_inv[g][rect-local tile index] = position of (g, tile) in the sorted lists.
-// (u, v, radius: the splat's record fields, loaded by the caller -- several at a time; (tx, ty): the tile)
-__device__ __forceinline__ void write_slot(float u, float v, int radius, int32_t* __restrict__ slot_inv,
-                                           int32_t* __restrict__ slot_pool, int g, int tx, int ty, int gx, int gy, int pos) {
-    int x0, x1, y0, y1;
-    tile_rect(u, v, radius, gx, gy, x0, x1, y0, y1);
-    const int nx = x1 - x0;
-    if (nx * (y1 - y0) <= SLOT_MAX) {
-        // scattered 4-byte store: write-through (sc1), no partially dirty L2 lines left behind
-        __hip_atomic_store(&slot_inv[(size_t)g * SLOT_MAX + (ty - y0) * nx + (tx - x0)], pos, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    } else if (slot_pool) {
-        // more tiles than slots: the preprocess kernel reserved a run of the pool and left its
-        // offset in the first slot as -2 - offset
-        const int code = slot_inv[(size_t)g * SLOT_MAX];
-        if (code <= -2)
-            __hip_atomic_store(&slot_pool[-2 - code + (ty - y0) * nx + (tx - x0)], pos, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 }  // namespace gfl
 
 #include "gfl_tile_sort.hpp"
@@ -222,7 +199,7 @@ int gfl_bin_sort(const float* uv, const float* depth, const int32_t* radius, con
             bin_scatter_kernel<false><<<(N + 255) / 256, 256, 0, s>>>(uv, depth, radius, cutoff, N, gx, gy, tile_offsets,
                                                                       cursor, K_cap, keys, overflow);
     }
-    bin_tile_sort_kernel<<<T, SORT_THREADS, 0, s>>>(tile_offsets, K_cap, keys, ids, tile_range, nullptr, nullptr, nullptr, gx, gy, nullptr, nullptr, nullptr, nullptr);
+    bin_tile_sort_kernel<<<T, SORT_THREADS, 0, s>>>(tile_offsets, K_cap, keys, ids, tile_range, gx, gy, nullptr, nullptr, nullptr, nullptr);
     return check_launch();
 }
 
@@ -231,44 +208,27 @@ int gfl_tile_sort_only(const int32_t* tile_offsets, int T, int K_cap, void* keys
     if (T <= 0 || K_cap < 0 || !tile_offsets || !keys || !tile_range || (K_cap > 0 && !ids)) return GFL_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* k64 = (unsigned long long*)keys;
-    bin_tile_sort_kernel<<<T, SORT_THREADS, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, nullptr, nullptr, nullptr, 1, T, nullptr, nullptr, nullptr, nullptr);
-    return check_launch();
-}
-
-int gfl_tile_sort_with_slots(const int32_t* tile_offsets, int W, int H, int K_cap, void* keys, int32_t* ids,
-                             int32_t* tile_range, const float* rec, int32_t* slot_inv, int32_t* slot_pool,
-                             gfl_stream_t stream) {
-    if (W <= 0 || H <= 0 || K_cap < 0 || !tile_offsets || !keys || !tile_range || (K_cap > 0 && !ids) || !rec ||
-        !slot_inv)
-        return GFL_ERR_INVALID;
-    const int gx = (W + GFL_TILE - 1) / GFL_TILE, gy = (H + GFL_TILE - 1) / GFL_TILE;
-    hipStream_t s = (hipStream_t)stream;
-    unsigned long long* k64 = (unsigned long long*)keys;
-    bin_tile_sort_kernel<<<gx * gy, SORT_THREADS, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, rec, slot_inv, slot_pool, gx, gy,
-                                                        nullptr, nullptr, nullptr, nullptr);
+    bin_tile_sort_kernel<<<T, SORT_THREADS, 0, s>>>(tile_offsets, K_cap, k64, ids, tile_range, 1, T, nullptr, nullptr, nullptr, nullptr);
     return check_launch();
 }
 
 int gfl_tile_sort_ordered(const int32_t* order, int W, int H, int K_cap, void* keys, int32_t* ids, int32_t* tile_range,
-                          const float* rec, int32_t* slot_inv, int32_t* slot_pool, gfl_stream_t stream) {
-    if (W <= 0 || H <= 0 || K_cap < 0 || !order || !keys || !tile_range || (K_cap > 0 && !ids) || (slot_inv && !rec))
-        return GFL_ERR_INVALID;
+                          gfl_stream_t stream) {
+    if (W <= 0 || H <= 0 || K_cap < 0 || !order || !keys || !tile_range || (K_cap > 0 && !ids)) return GFL_ERR_INVALID;
     const int gx = (W + GFL_TILE - 1) / GFL_TILE, gy = (H + GFL_TILE - 1) / GFL_TILE;
     bin_tile_sort_kernel<<<SORT_MAX_SPLIT + gx * gy, SORT_THREADS, 0, (hipStream_t)stream>>>(
-        nullptr, K_cap, (unsigned long long*)keys, ids, tile_range, rec, slot_inv, slot_pool, gx, gy,
+        nullptr, K_cap, (unsigned long long*)keys, ids, tile_range, gx, gy,
         reinterpret_cast<const int4*>(order), nullptr, nullptr, nullptr);
     return check_launch();
 }
 
 int gfl_tile_sort_reserved(const int32_t* order, const int32_t* fill, int32_t* tile_counts, int32_t* void_words, int W, int H,
-                           int K_cap, void* keys, int32_t* ids, int32_t* tile_range, const float* rec, int32_t* slot_inv,
-                           int32_t* slot_pool, gfl_stream_t stream) {
-    if (W <= 0 || H <= 0 || K_cap < 0 || !order || !fill || !tile_counts || !keys || !tile_range || (K_cap > 0 && !ids) ||
-        (slot_inv && !rec))
+                           int K_cap, void* keys, int32_t* ids, int32_t* tile_range, gfl_stream_t stream) {
+    if (W <= 0 || H <= 0 || K_cap < 0 || !order || !fill || !tile_counts || !keys || !tile_range || (K_cap > 0 && !ids))
         return GFL_ERR_INVALID;
     const int gx = (W + GFL_TILE - 1) / GFL_TILE, gy = (H + GFL_TILE - 1) / GFL_TILE;
     bin_tile_sort_kernel<<<SORT_MAX_SPLIT + gx * gy, SORT_THREADS, 0, (hipStream_t)stream>>>(
-        nullptr, K_cap, (unsigned long long*)keys, ids, tile_range, rec, slot_inv, slot_pool, gx, gy,
+        nullptr, K_cap, (unsigned long long*)keys, ids, tile_range, gx, gy,
         reinterpret_cast<const int4*>(order), fill, tile_counts, void_words);
     return check_launch();
 }

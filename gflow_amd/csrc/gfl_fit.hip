@@ -255,7 +255,7 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
         {
             StageScope p(ST_TILE_SORT, s);
             rc = gfl_tile_sort_reserved((const int32_t*)w.sort_order_next, w.fill, w.tile_counts, st->overflow + 2, st->W, st->H,
-                                        st->K_cap, w.keys, st->ids, st->tile_range, nullptr, nullptr, nullptr, stream);
+                                        st->K_cap, w.keys, st->ids, st->tile_range, stream);
         }
         if (rc) return rc;
     } else {
@@ -278,7 +278,7 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
             StageScope p(ST_TILE_SORT, s);
             if (ordered)
                 rc = gfl_tile_sort_ordered((const int32_t*)w.sort_order, st->W, st->H, st->K_cap, w.keys, st->ids, st->tile_range,
-                                           nullptr, nullptr, nullptr, stream);
+                                           stream);
             else
                 rc = gfl_tile_sort_only(st->tile_offsets, gx * gy, st->K_cap, w.keys, st->ids, st->tile_range, stream);
         }

@@ -141,47 +141,18 @@ __device__ __forceinline__ void sort_tile_regs(const unsigned long long* seg, in
 template <int E>
 __device__ __forceinline__ void sort_tile_and_emit(const unsigned long long* seg, int n, int npow,
                                                    unsigned long long* __restrict__ sk, int start, int tile,
-                                                   int32_t* __restrict__ ids, const float* __restrict__ slot_rec,
-                                                   int32_t* __restrict__ slot_inv, int32_t* __restrict__ slot_pool,
-                                                   int gx, int gy, bool seg_in_sk = false) {
+                                                   int32_t* __restrict__ ids, bool seg_in_sk = false) {
     unsigned long long key[E];
     const int sort_trace_row = tile;
     (void)sort_trace_row;
     sort_tile_regs<E>(seg, n, npow, sk, key, tile, seg_in_sk);
     SORT_TRACE(2);
     const int tid = threadIdx.x;
-    // from here on only the splat ids are live (the depth halves of the keys would keep E more registers busy: at the
-    // 64-register budget the compiler then re-used the address registers of one record load for the next -- a wait for
-    // memory between every two loads of the loop below)
-    int gid[E];
+    // the sorted ids.  (Until round 5 this also filled a table of every pair's list position for the per-splat launch's gather;
+    //  the pair rows now lie where that launch finds them without one, gfl_fit.hpp: FitWs.pair_grad.)
 #pragma unroll
-    for (int e = 0; e < E; ++e) gid[e] = tid * E + e < n ? (int32_t)(unsigned)(key[e] & 0xffffffffull) : -1;
-    const int tx = tile % gx, ty = tile / gx;
-    // the slot table needs (u, v, radius) of every key's splat: the records of up to four keys are requested before the
-    // first is used (one record, one store per trip was E dependent round trips: 5.6 us at the end of the longest tile's
-    // workgroup, tools/sort_trace.py --fit)
-    constexpr int EB = E < 4 ? E : 4;
-#pragma unroll
-    for (int e0 = 0; e0 < E; e0 += EB) {
-        float2 uv[EB];
-        int rr[EB];
-        if (slot_inv) {
-#pragma unroll
-            for (int e = 0; e < EB; ++e) {
-                const float* r = slot_rec + (size_t)max(gid[e0 + e], 0) * 12;
-                uv[e] = *reinterpret_cast<const float2*>(r);
-                rr[e] = __float_as_int(r[11]);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < EB; ++e) {
-            const int g = gid[e0 + e], pos = start + tid * E + e0 + e;
-            if (g >= 0) {
-                ids[pos] = g;
-                if (slot_inv) write_slot(uv[e].x, uv[e].y, rr[e], slot_inv, slot_pool, g, tx, ty, gx, gy, pos);
-            }
-        }
-    }
+    for (int e = 0; e < E; ++e)
+        if (tid * E + e < n) ids[start + tid * E + e] = (int32_t)(unsigned)(key[e] & 0xffffffffull);
 }
 
 // Register budget: 64 VGPRs (eight waves per SIMD).  With a 16-keys-per-lane variant in the same kernel the compiler
@@ -189,10 +160,7 @@ __device__ __forceinline__ void sort_tile_and_emit(const unsigned long long* seg
 __global__ void __launch_bounds__(SORT_THREADS, 8) bin_tile_sort_kernel(const int32_t* __restrict__ offsets, int K_cap,
                                                                         unsigned long long* __restrict__ keys,
                                                                         int32_t* __restrict__ ids,
-                                                                        int32_t* __restrict__ tile_range,
-                                                                        const float* __restrict__ slot_rec,
-                                                                        int32_t* __restrict__ slot_inv,
-                                                                        int32_t* __restrict__ slot_pool, int gx, int gy,
+                                                                        int32_t* __restrict__ tile_range, int gx, int gy,
                                                                         const int4* __restrict__ order,
                                                                         const int32_t* __restrict__ fill,
                                                                         int32_t* __restrict__ counts_out,
@@ -321,9 +289,9 @@ __global__ void __launch_bounds__(SORT_THREADS, 8) bin_tile_sort_kernel(const in
             const int start2 = start + (half == 0 ? 0 : n_lower);
             // (waves the shorter list does not need leave here; the barrier inside the key load counts only the others)
             if ((int)threadIdx.x >= max(np2 / E2, 64)) return;
-            if (E2 == 1) sort_tile_and_emit<1>(sk, m, np2, sk, start2, tile, ids, slot_rec, slot_inv, slot_pool, gx, gy, true);
-            else if (E2 == 2) sort_tile_and_emit<2>(sk, m, np2, sk, start2, tile, ids, slot_rec, slot_inv, slot_pool, gx, gy, true);
-            else sort_tile_and_emit<4>(sk, m, np2, sk, start2, tile, ids, slot_rec, slot_inv, slot_pool, gx, gy, true);
+            if (E2 == 1) sort_tile_and_emit<1>(sk, m, np2, sk, start2, tile, ids, true);
+            else if (E2 == 2) sort_tile_and_emit<2>(sk, m, np2, sk, start2, tile, ids, true);
+            else sort_tile_and_emit<4>(sk, m, np2, sk, start2, tile, ids, true);
             SORT_TRACE(3);
             return;
         }
@@ -339,16 +307,16 @@ __global__ void __launch_bounds__(SORT_THREADS, 8) bin_tile_sort_kernel(const in
     const int E = npow <= SORT_THREADS ? 1 : (npow <= 2 * SORT_THREADS ? 2 : (npow <= 4 * SORT_THREADS ? 4 : 8));
     if (npow <= 8 * SORT_THREADS && (int)threadIdx.x >= max(npow / E, 64)) return;
     if (npow <= SORT_THREADS) {
-        sort_tile_and_emit<1>(seg, n, npow, sk, start, tile, ids, slot_rec, slot_inv, slot_pool, gx, gy);
+        sort_tile_and_emit<1>(seg, n, npow, sk, start, tile, ids);
         SORT_TRACE(3);
     } else if (npow <= 2 * SORT_THREADS) {
-        sort_tile_and_emit<2>(seg, n, npow, sk, start, tile, ids, slot_rec, slot_inv, slot_pool, gx, gy);
+        sort_tile_and_emit<2>(seg, n, npow, sk, start, tile, ids);
         SORT_TRACE(3);
     } else if (npow <= 4 * SORT_THREADS) {
-        sort_tile_and_emit<4>(seg, n, npow, sk, start, tile, ids, slot_rec, slot_inv, slot_pool, gx, gy);
+        sort_tile_and_emit<4>(seg, n, npow, sk, start, tile, ids);
         SORT_TRACE(3);
     } else if (npow <= 8 * SORT_THREADS) {
-        sort_tile_and_emit<8>(seg, n, npow, sk, start, tile, ids, slot_rec, slot_inv, slot_pool, gx, gy);
+        sort_tile_and_emit<8>(seg, n, npow, sk, start, tile, ids);
         SORT_TRACE(3);
     } else {
         // the all-ascending network directly on global memory (one CU, its own L1; the
@@ -358,10 +326,6 @@ __global__ void __launch_bounds__(SORT_THREADS, 8) bin_tile_sort_kernel(const in
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const int g = (int32_t)(unsigned)(seg[i] & 0xffffffffull);
             ids[start + i] = g;
-            if (slot_inv) {
-                const float* r = slot_rec + (size_t)g * 12;
-                write_slot(r[0], r[1], __float_as_int(r[11]), slot_inv, slot_pool, g, tile % gx, tile / gx, gx, gy, start + i);
-            }
         }
     }
 }

@@ -158,8 +158,7 @@ class FitEngine:
         self._alloc_pairs(max(int(self.K_cap_req) if self.K_cap_req else max(4_000_000, 8 * cap), k_min))
 
     def _alloc_pairs(self, K_cap):
-        """The buffers whose size follows K_cap (the sorted ids, and the workspace: keys, per-pair gradient rows, slot
-        pools, the tile scheduler's state, checkpoints, cached target statistics -- everything in it is rebuilt by the
+        """The buffers whose size follows K_cap (the sorted ids, and the workspace: keys, per-pair gradient rows, the tile scheduler's state, checkpoints, cached target statistics -- everything in it is rebuilt by the
         next forward / set_targets)."""
         self.K_cap = int(K_cap)                                                         # (64 B per pair: 0.25-0.5 GB of 288)
         self.ids = torch.zeros(self.K_cap, dtype=torch.int32, device=self.dev)

@@ -90,9 +90,11 @@ typedef enum gfl_status {
 /* 300 (round 5): gfl_fit_state.overflow is int32[4] (was [1] before 200's reserved regions), gfl_tile_sort_ordered reads a
  * trailer of GFL_SORT_ORDER_TRAILER ints behind order[T][4], gfl_fit_iterations' flags are GFL_ITER_RESERVED only
  * (GFL_ITER_PRE_DONE / _PRE_NEXT / _ODD, gfl_fit_next_preprocess_supported and gfl_bwd_rows_on are gone), the fit
- * workspace is smaller (one slot pool).  301: gfl_fit_iteration_snapshot.
+ * workspace is smaller.  301: gfl_fit_iteration_snapshot.  302: the tile sorts no longer fill a table of list positions
+ * (gfl_tile_sort_with_slots is gone, gfl_tile_sort_ordered / _reserved lost their rec / slot_inv / slot_pool arguments): the
+ * per-splat launch finds its pair rows without one.
  * A binding checks gfl_version() >= GFL_VERSION of the header it was written for. */
-#define GFL_VERSION 301
+#define GFL_VERSION 302
 int gfl_version(void);
 /* out[10] = TILE, NEAREST, EXTENT, FOV_CLAMP, LOWPASS, EIG_FLOOR, RADIUS_SIGMA, ALPHA_MIN, ALPHA_MAX, T_MIN of this build */
 int gfl_constants(float* out10);
@@ -277,7 +279,7 @@ typedef struct gfl_fit_state {
     int32_t* n_contrib;                         /* [H][W] */
     float *d_render, *err_px, *sums;            /* [4][H][W], [H][W], [8] as gfl_loss_fwd_bwd */
     int32_t *tile_offsets, *ids, *tile_range, *overflow; /* [T+1], [K_cap], [T][2], [4].  overflow[0] is sticky: 1 = a
-                                                          * forward produced more than K_cap pairs (or slot-pool entries) and
+                                                          * forward produced more than K_cap pairs (or wide-splat pair rows) and
                                                           * dropped some, 2 = GFL_ITER_RESERVED without reserved regions.
                                                           * It is only ever raised by the binning launches of a forward --
                                                           * never by a launch that also reads it --, so every update launch of
@@ -393,13 +395,6 @@ int gfl_fit_schedule_info_fwd(const gfl_fit_state* st, int* n_queues, int* queue
 /* the per-tile sort of gfl_bin_sort alone (keys already scattered into segments) */
 int gfl_tile_sort_only(const int32_t* tile_offsets, int T, int K_cap, void* keys, int32_t* ids,
                        int32_t* tile_range, gfl_stream_t stream);
-/* same, and additionally fills slot_inv[cap][16] from the render records rec[cap][12]:
- * slot_inv[g][rect-local tile index] = list position of the pair (g, tile) for splats
- * whose tile rectangle has at most 32 tiles; wider splats use a run of slot_pool whose offset the
- * fused preprocess left in slot_inv[g][0] as -2 - offset (the fused backward gathers through both) */
-int gfl_tile_sort_with_slots(const int32_t* tile_offsets, int W, int H, int K_cap, void* keys, int32_t* ids,
-                             int32_t* tile_range, const float* rec, int32_t* slot_inv, int32_t* slot_pool,
-                             gfl_stream_t stream);
 /* same, with the order the workgroups take the tiles in given by the caller: order[T][4] = {tile, start, end, split} per
  * position (16-byte aligned; positions are assigned to the XCDs in contiguous runs, T / 8 each, like the tiles without it),
  * followed by a trailer of GFL_SORT_ORDER_TRAILER ints: trailer[0] = n_split (0 .. GFL_SORT_MAX_SPLIT), trailer[1 + j] =
@@ -411,14 +406,13 @@ int gfl_tile_sort_with_slots(const int32_t* tile_offsets, int W, int H, int K_ca
 #define GFL_SORT_MAX_SPLIT 64
 #define GFL_SORT_ORDER_TRAILER (GFL_SORT_MAX_SPLIT + 4)
 int gfl_tile_sort_ordered(const int32_t* order, int W, int H, int K_cap, void* keys, int32_t* ids, int32_t* tile_range,
-                          const float* rec, int32_t* slot_inv, int32_t* slot_pool, gfl_stream_t stream);
+                          gfl_stream_t stream);
 /* same for reserved tile regions: order[T][4] = {tile, start, capacity, split}; the list of `tile` is the first
  * min(fill[position], capacity) keys behind `start` (fill[T]: what the binning launch counted, by position in the order);
  * tile_counts[tile] = fill[position];
  * void_words (may be NULL): void_words[0] = void_words[1], void_words[1] = 0 (gfl_fit_state.overflow + 2). */
 int gfl_tile_sort_reserved(const int32_t* order, const int32_t* fill, int32_t* tile_counts, int32_t* void_words, int W, int H,
-                           int K_cap, void* keys, int32_t* ids, int32_t* tile_range, const float* rec, int32_t* slot_inv,
-                           int32_t* slot_pool, gfl_stream_t stream);
+                           int K_cap, void* keys, int32_t* ids, int32_t* tile_range, gfl_stream_t stream);
 
 /* ---- optional per-stage timing of the fused iteration ---------------------------
  * HIP events are recorded on the launch stream around the stages whose bit is set in

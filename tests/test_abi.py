@@ -106,5 +106,5 @@ def test_reserved_entry_points_reject_bad_arguments_without_a_gpu():
     from gflow_amd import _lib
     lib = _lib.load()
     null = ctypes.c_void_p(0)
-    assert lib.gfl_tile_sort_reserved(null, null, null, null, 64, 64, 16, null, null, null, null, null, null, null) != 0
+    assert lib.gfl_tile_sort_reserved(null, null, null, null, 64, 64, 16, null, null, null, null) != 0
     assert lib.gfl_fit_reserved_supported(null, null) == 0

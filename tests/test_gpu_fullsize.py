@@ -3,7 +3,7 @@
 * configs[1] (480x854, 60 000 splats): the fused iteration -- render, losses, ALL 14 + 7 + 2 gradients -- against the
   CPU oracle's fit step DIRECTLY (not against the operator path, which itself meets the oracle only on small scenes):
   once on the bench scene (mid-optimisation footprint) and once on a post-densification scene with a tile list longer
-  than 1200 entries (heavy-tile segments, 8-keys-per-lane sort tier) and splats wider than 32 tiles (slot pool).
+  than 1200 entries (heavy-tile segments, 8-keys-per-lane sort tier) and splats wider than 32 tiles (pair rows of their own).
 * configs[2] shape: an 8-frame 480p / 60k clip through fit_video.fit_clip with the README iteration counts.
 * configs[4]: 720x1280, 200 000 splats, densify_interval = 150 for 320 iterations.
 """

@@ -122,13 +122,13 @@ def test_block_culling_never_drops_a_visible_pixel(box):
 
 def test_tile_sort_in_any_order_of_the_tiles():
     """gfl_tile_sort_ordered (the fused iteration's sort: every XCD's longest lists first) against
-    gfl_tile_sort_with_slots on the same keys: ids, tile ranges and the slot table bit-identical, for a random
+    gfl_tile_sort_only (the tiles in their own order) on the same keys: ids and tile ranges bit-identical, for a random
     permutation of the tiles inside every XCD's run and with lists of every register tier (1 ... 2 500 keys)."""
     import numpy as np
     from gflow_amd import _lib as L
     lib = L.load()
     dev = torch.device("cuda", 0)
-    W, H, SLOT_MAX = 160, 96, 32
+    W, H = 160, 96
     gx, gy = 10, 6
     T = gx * gy
     g = torch.Generator().manual_seed(11)
@@ -181,8 +181,6 @@ def test_tile_sort_in_any_order_of_the_tiles():
         k = torch.from_numpy(keys.view(np.int64).copy()).to(dev)
         ids = torch.full((K,), -7, dtype=torch.int32, device=dev)
         tr = torch.full((T, 2), -7, dtype=torch.int32, device=dev)
-        slot = torch.full((n, SLOT_MAX), -1, dtype=torch.int32, device=dev)
-        rec_d = rec.to(dev)
         if ordered:
             o_np = np.concatenate([order.reshape(-1), np.zeros(TRAILER, dtype=np.int32)])
             if split:
@@ -192,28 +190,21 @@ def test_tile_sort_in_any_order_of_the_tiles():
                     o_np[4 * p_ + 3] = 1 + j
                     o_np[4 * T + 1 + j] = p_
             o = torch.from_numpy(o_np).to(dev)
-            L.check(lib.gfl_tile_sort_ordered(L.ptr(o), W, H, K, L.ptr(k), L.ptr(ids), L.ptr(tr), L.ptr(rec_d), L.ptr(slot),
-                                              None, L.stream()), "sort ordered")
+            L.check(lib.gfl_tile_sort_ordered(L.ptr(o), W, H, K, L.ptr(k), L.ptr(ids), L.ptr(tr), L.stream()), "sort ordered")
         else:
             off = torch.from_numpy(offsets).to(dev)
-            L.check(lib.gfl_tile_sort_with_slots(L.ptr(off), W, H, K, L.ptr(k), L.ptr(ids), L.ptr(tr), L.ptr(rec_d),
-                                                 L.ptr(slot), None, L.stream()), "sort")
+            L.check(lib.gfl_tile_sort_only(L.ptr(off), T, K, L.ptr(k), L.ptr(ids), L.ptr(tr), L.stream()), "sort")
         torch.cuda.synchronize()
-        return ids.cpu(), tr.cpu(), slot.cpu()
+        return ids.cpu(), tr.cpu()
 
-    ids0, tr0, slot0 = run(False)
-    ids1, tr1, slot1 = run(True)
-    assert torch.equal(tr0, tr1) and torch.equal(ids0, ids1) and torch.equal(slot0, slot1)
-    ids2, tr2, slot2 = run(True, split=True)             # ... and with the long lists cut at a pivot, two workgroups each
-    assert torch.equal(tr0, tr2) and torch.equal(ids0, ids2) and torch.equal(slot0, slot2)
-    # and the plain one is right: every list ascending in (depth, id), every pair's position in its splat's slot row
+    ids0, tr0 = run(False)
+    ids1, tr1 = run(True)
+    assert torch.equal(tr0, tr1) and torch.equal(ids0, ids1)
+    ids2, tr2 = run(True, split=True)                    # ... and with the long lists cut at a pivot, two workgroups each
+    assert torch.equal(tr0, tr2) and torch.equal(ids0, ids2)
+    # and the plain one is right: every list ascending in (depth, id)
     for t in (0, 3 * gx + 4, T - 1):
         seg = ids0[offsets[t]:offsets[t + 1]].long()
         d = depth[seg]
         assert bool(((d[1:] > d[:-1]) | ((d[1:] == d[:-1]) & (seg[1:] > seg[:-1]))).all())
         assert sorted(seg.tolist()) == sorted(lists[t])
-    t = 3 * gx + 4
-    pos = int(offsets[t]) + 5
-    gidx = int(ids0[pos])
-    local = (t // gx - (int(cy[gidx]) - 1)) * 3 + (t % gx - (int(cx[gidx]) - 1))
-    assert int(slot0[gidx, local]) == pos
