@@ -39,7 +39,7 @@ def test_fused_and_operator_clips_reach_similar_quality():
     a = fit_clip(frames, DEV, SMALL, seed=0, fused=True)
     b = fit_clip(frames, DEV, SMALL, seed=0, fused=False)
     assert abs(a["psnr_sum"] - b["psnr_sum"]) / 3 < 1.5
-    assert abs(a["splats_final"] - b["splats_final"]) <= 0.04 * b["splats_final"]
+    assert abs(a["splats_final"] - b["splats_final"]) <= 0.06 * b["splats_final"]      # (~2 700 splats: up to 3 % apart run to run)
 
 
 def test_camera_only_phase_moves_the_pose_not_the_splats():
@@ -243,8 +243,11 @@ def test_concurrent_fits_on_one_device_equal_the_fits_one_after_another():
     assert len(together) == 3
     for a, b in zip(alone, together):
         assert b["frames"] == 3 and b["iterations"] == a["iterations"] and b["clips"] == 1
-        assert abs(a["psnr_sum"] - b["psnr_sum"]) / 3 < 0.7, (a, b)       # (the backward's LDS atomics are unordered)
-        assert abs(a["splats_final"] - b["splats_final"]) <= 0.04 * a["splats_final"], (a, b)   # (observed: up to 2.1 %)
+        # (the backward's LDS atomics are unordered: two runs of ONE fit differ as much.  Thirty pairs sampled on one box,
+        #  tools/conc_loop.py: up to 0.60 dB per frame and 2.7 % of the splats -- the old bounds, 0.7 dB and 4 %, failed one
+        #  run of the suite in a dozen; a clip that shared anything with another would be off by tens of dB)
+        assert abs(a["psnr_sum"] - b["psnr_sum"]) / 3 < 1.2, (a, b)
+        assert abs(a["splats_final"] - b["splats_final"]) <= 0.06 * a["splats_final"], (a, b)
     # an exception inside one clip's fit reaches the caller
     with pytest.raises(Exception):
         fit_clips_concurrent([clips[0], [dict(clips[1][0], image=None)]], DEV, SMALL)
@@ -556,7 +559,7 @@ def test_concurrent_fits_draw_their_trajectories_too():
     torch.cuda.synchronize()
     for a, b in zip(alone, together):
         assert b["iterations"] == a["iterations"] and b["rasterisations"] == a["rasterisations"]
-        assert abs(a["psnr_sum"] - b["psnr_sum"]) / 3 < 0.7, (a, b)
+        assert abs(a["psnr_sum"] - b["psnr_sum"]) / 3 < 1.2, (a, b)       # (as test_concurrent_fits_on_one_device...: up to 0.6 seen)
 
 
 def test_host_writes_invalidate_the_reserved_regions():
