@@ -39,10 +39,12 @@ def test_twenty_four_frames_fused_and_operator_path_agree(seed):
     assert ma["iterations"] == mb["iterations"] == 60 + (n - 1) * 60
     assert ta.current_pts_num() == tb.current_pts_num() > 1500
     d = [x - y for x, y in zip(pa, pb)]
-    assert max(abs(v) for v in d) < 0.9, (pa, pb)                       # every frame (observed: <= 0.52)
-    assert abs(sum(d)) / n < 0.25, (pa, pb)                               # no systematic offset (observed: <= 0.05)
+    # (ten fits sampled on one box, tools/drift_loop2.py: single frames up to 0.86 dB apart, mean -0.19 .. +0.07, second half
+    #  -0.24 .. +0.10 -- two chaotic optimisations; the bounds of round 4, 0.9 / 0.25 / 0.35, sat on the largest of them)
+    assert max(abs(v) for v in d) < 1.5, (pa, pb)                       # every frame
+    assert abs(sum(d)) / n < 0.4, (pa, pb)                                # no systematic offset
     # ... and no drift: the second half of the clip is no further apart than the first
-    assert abs(sum(d[n // 2:]) / (n - n // 2)) < 0.35, d
+    assert abs(sum(d[n // 2:]) / (n - n // 2)) < 0.5, d
     differ = int((ta.still_mask != tb.still_mask).sum())
     assert differ <= 0.05 * ta.current_pts_num(), differ                  # (observed: 50 of 2192)
     assert abs(float(ta.still_mask.float().mean()) - float(tb.still_mask.float().mean())) < 0.02
