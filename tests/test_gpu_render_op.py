@@ -207,5 +207,6 @@ def test_operator_costs_about_one_fused_iteration():
     print(f"operator fwd+bwd {t_op * 1e3:.3f} ms, fused fit iteration {t_fit * 1e3:.3f} ms")
     # measured 1.0x - 1.3x (0.23-0.30 ms against 0.228 ms; half of the operator's time is HOST time: autograd, one
     # concatenation, two allocations per direction -- the fused iteration is one graph replay).  The bound is a
-    # regression guard (the operator-by-operator path costs 9x), with room for a slow host on the test box.
-    assert t_op < 2.0 * t_fit, (t_op, t_fit)
+    # regression guard (the operator-by-operator path costs 9x), with room for a slow host on the test box: 2.0x failed one
+    # run in twenty-five in round 5 (the operator's half is host time, and the fit iteration has become faster since).
+    assert t_op < 3.5 * t_fit, (t_op, t_fit)
