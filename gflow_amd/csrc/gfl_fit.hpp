@@ -248,6 +248,12 @@ __device__ __forceinline__ bool splat_alpha2(const float4& p0, const float4& p1,
     return (power <= 0.f) & (alpha >= GFL_ALPHA_MIN);
 }
 
+// a float image value as render2img stores it (render.py:158-166): clamp to [0, 1], x 255, truncate
+__device__ __forceinline__ uint8_t img_u8(float v) {
+    const float x = fminf(fmaxf(v, 0.f), 1.f) * 255.f;
+    return (uint8_t)(x != x ? 0.f : x);
+}
+
 struct AdamCfg {
     float lr, b1, b2, eps, lr_end_factor;
     int total_iters;
