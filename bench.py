@@ -114,6 +114,72 @@ def coresident_fits(dev, frames_n, snapshot_interval, levels=(1, 2, 3)):
     return out
 
 
+def drop_in_levels(dev, Hh=None, Ww=None, Nn=None, repeats=3, n=20):
+    """What the three levels of the drop-in cost per rasterisation forward + backward on one frame of the bench workload
+     -- REPORTED, never asserted (tests/test_gpu_render_op.py used to hold a wall-clock ratio):
+      five_operators_ms  the five msplat operators one by one, as /root/reference/gflow/utils/render.py:21-64 calls them
+                         (the one-line ``import msplat`` swap; gflow_amd.msplat warns once when it sees that pattern),
+      fused_render_ms    gflow_amd.render.render: ONE differentiable operator, two library calls,
+      fit_iteration_ms   the fused fit iteration (the same rasterisation + losses + Adam): the level bench's value runs on.
+    Best of ``repeats`` runs of ``n`` calls each (host time included: that is what a caller pays)."""
+    import warnings
+    import gflow_amd.render as R
+    from gflow_amd import synthetic as S
+    from gflow_amd.fused import FitEngine
+    Hh, Ww, Nn = Hh or H, Ww or W, Nn or N_SPLATS
+    frame = S.make_frame(Hh, Ww, seed=0)
+    raw = S.init_splats(frame, Nn, seed=0, grown=True)
+    act = [raw["xyz"], raw["scale"].abs(), torch.nn.functional.normalize(raw["rotate"]),
+           torch.sigmoid(10 * raw["opacity"]), torch.sigmoid(raw["rgb"])]
+    leaves = [v.to(dev).requires_grad_(True) for v in act]
+    group = [*leaves, raw["intr"].to(dev), raw["extr"].to(dev), 0.0, Ww, Hh]
+    g3 = ((torch.rand(3, Hh, Ww, device=dev) - 0.5) / (Hh * Ww)).contiguous()
+    g1 = ((torch.rand(1, Hh, Ww, device=dev) - 0.5) / (Hh * Ww)).contiguous()
+    images = {}
+
+    def op_step(fused, keep=None):
+        R.USE_FUSED = fused
+        try:
+            out = R.render_multiple(group, ["rgb", "uv", "depth", "depth_map"])
+        finally:
+            R.USE_FUSED = True
+        torch.autograd.backward([out["rgb"], out["depth_map"]], [g3, g1])
+        if keep is not None:
+            images[keep] = out["rgb"].detach()
+
+    eng = FitEngine(Ww, Hh, 2 * Nn, dev)
+    eng.set_splats({k: raw[k] for k in ("xyz", "scale", "rotate", "opacity", "rgb")})
+    eng.intr.copy_(raw["intr"].to(dev))
+    eng.set_targets(frame["image"], frame["depth"])
+    eng.hp.lr, eng.hp.lambda_depth, eng.hp.lambda_var = 0.0, 0.1, 10.0
+    eng.reset_optimizer()
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        best = float("inf")
+        for _ in range(repeats):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / n)
+        return best * 1e3
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)              # (the slow level is run on purpose here)
+        op_step(False, "ops")
+        op_step(True, "fused")
+        t_ops = timed(lambda: op_step(False))
+    t_fused = timed(lambda: op_step(True))
+    t_fit = timed(lambda: eng.iteration(use_graph=True))
+    diff = float((images["ops"] - images["fused"]).abs().max())
+    return {"five_operators_ms": t_ops, "fused_render_ms": t_fused, "fit_iteration_ms": t_fit,
+            "five_operators_vs_fused_render": t_ops / t_fused, "fused_render_vs_fit_iteration": t_fused / t_fit,
+            "rgb_max_abs_diff": diff, "size": f"{Hh}x{Ww}, {Nn} splats", "calls": f"best of {repeats} x {n}"}
+
+
 def cpu_baseline():
     """The oracle's fit iteration on the host cores: 3 warm-ups + 20 timed iterations of
     the bench workload (480x854, 60 000 splats) and of the C1-size workload (10 000 splats)."""
@@ -288,6 +354,9 @@ def main():
     ap.add_argument("--no-coresident", action="store_true",
                     help="skip the secondary table of 1 / 2 / 3 clip fits sharing this GPU (clips_per_gpu)")
     ap.add_argument("--coresident-frames", type=int, default=8, help="frames per clip of that secondary table")
+    ap.add_argument("--no-drop-in-levels", action="store_true",
+                    help="skip the secondary table of what the three levels of the drop-in cost (five operators / fused "
+                         "render operator / fused fit iteration)")
     ap.add_argument("--collective", action="store_true",
                     help="initialise the process group and run the barriers and the two metric all-reduces even when the "
                          "world is ONE rank (under torchrun): the RCCL path of an N > 1 run on a one-GPU box")
@@ -350,7 +419,7 @@ def main():
         else:
             res = FV.fit_clips_concurrent(clips, dev, cfg, seeds=[rank * c + j for j in range(c)],
                                           snapshot_interval=args.snapshot_interval)
-            clip = {k: sum(r[k] for r in res) for k in res[0]}
+            clip = {k: sum(r[k] for r in res) for k in FV.NUMERIC_KEYS}
         torch.cuda.synchronize()
         own_wall = time.perf_counter() - t0
         barrier()
@@ -447,6 +516,11 @@ def main():
                 out["clips_per_gpu"] = coresident_fits(dev, args.coresident_frames, args.snapshot_interval)
             except Exception as e:                   # a secondary table must not cost the line
                 out["clips_per_gpu"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_drop_in_levels:
+            try:
+                out["drop_in_levels"] = drop_in_levels(dev)
+            except Exception as e:                   # a secondary table must not cost the line
+                out["drop_in_levels"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

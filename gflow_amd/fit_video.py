@@ -148,6 +148,10 @@ def select_traj_seeds(tr, traj_num, traj_offset):
             out.append(d.argmin(dim=0))
         return torch.cat(out)
 
+    if len(sparse) == 0:
+        # (H or W <= 50: the stride-50 grid has no pixel at all -- the reference would index an empty array, :200-203; the
+        #  plain rule is what it falls back to without a mask)
+        return plain, None
     sp = closest(sparse)
     sp_still = sp[still[sp]]
     if len(dense):
@@ -159,7 +163,9 @@ def select_traj_seeds(tr, traj_num, traj_offset):
 
 def fit_clip(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, log=None, load_extr=True, keep=None,
              async_snapshots=None):
-    """Fit one clip; returns the metrics dict of this clip (PSNR summed over its frames).
+    """Fit one clip; returns the metrics dict of this clip (PSNR summed over its frames; with ``cfg["traj_num"]`` > 0 also
+    ``"traj"``: the per-frame trajectory images and seed projections, host arrays -- what the reference's frame loop collects in
+    ``frames_sequence_traj / frames_sequence_traj_upon / sequence_traj``).
     ``load_extr`` (default True, like the reference's flag): frames that carry a camera pose
     (``extr``, read from the sequence's camera files) load it before they are fitted
     (fit_video.py:115-116, :252-253).  ``keep``: a dict that receives the trainer (``keep["trainer"]``) and the
@@ -314,10 +320,20 @@ def fit_clip_steps(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=
             traj_out = dict(images=imgs_d.numpy(), uv=uvs_d.numpy(), index=list(traj_index), split_interval=split_interval)
         if keep is not None:
             keep["traj"] = traj_out
-    return dict(psnr_sum=float(psnr_sum), frames=len(frames), iterations=tr.iterations_done,
-                rasterisations=tr.rasterisations_done, clips=1, splats_final=tr.current_pts_num(),
-                # iterations that stepped nothing because a tile outgrew its reserved region, and were made up for
-                void_iterations=getattr(tr.engine, "regions_outgrown", 0) if tr.engine is not None else 0)
+    out = dict(psnr_sum=float(psnr_sum), frames=len(frames), iterations=tr.iterations_done,
+               rasterisations=tr.rasterisations_done, clips=1, splats_final=tr.current_pts_num(),
+               # iterations that stepped nothing because a tile outgrew its reserved region, and were made up for
+               void_iterations=getattr(tr.engine, "regions_outgrown", 0) if tr.engine is not None else 0)
+    if traj:
+        # what the reference appends per frame -- frames_sequence_traj, frames_sequence_traj_upon, sequence_traj
+        # (fit_video.py:226-238, 335-349): images (frames, 2, H, W, 3) uint8 [trajectories alone, upon the render],
+        # uv (frames, seeds, 2), index, split_interval.  Not a number: callers that sum the dicts skip it (NUMERIC_KEYS)
+        out["traj"] = traj_out
+    return out
+
+
+# the keys of fit_clip's dict that are per-clip numbers (sums over clips make sense); "traj" is the trajectory output
+NUMERIC_KEYS = ("psnr_sum", "frames", "iterations", "rasterisations", "clips", "splats_final", "void_iterations")
 
 
 def fit_clips_concurrent(clips, device, cfg=None, seeds=None, snapshot_interval=0, chunk=32):

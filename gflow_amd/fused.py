@@ -486,6 +486,7 @@ class FitEngine:
         because a tile outgrew its reserved region.  0: nothing happened.  (K_cap is max(4 M, 8 x capacity), ~15 x what fits
         produce: this is the rare path, but a silent or fatal one it must not be.)"""
         self._ovf_event = None
+        self._pend_event = None        # (a blocking look supersedes an outstanding watch: its words are read and cleared here)
         code, skipped = (int(v) for v in self.overflow[:2].tolist())                   # the host read
         if code == 0:
             if skipped > 0:
@@ -508,6 +509,7 @@ class FitEngine:
 
     def grow_pairs(self):
         """Twice the room for (splat, tile) pairs, before they run out (the caller has drained the stream)."""
+        self._pend_event = None
         self._K_grown = True
         self._alloc_pairs(2 * self.K_cap)
         with _GRAPH_LOCK:
@@ -524,7 +526,11 @@ class FitEngine:
     def watch_pending(self):
         """Non-blocking: the four overflow words and the pair count as they are once everything queued so far has run, copied
         to page-locked memory behind that work.  ``read_pending`` waits for exactly that copy -- not for work queued after
-        this call: the trainer queues one more iteration first, so the device is busy while the host looks."""
+        this call: the trainer queues one more iteration first, so the device is busy while the host looks.
+        The pair count is ``tile_offsets[T]``: the exact binning path writes it (gfl_fit_bin.hip, the scatter's scan) and so
+        does an iteration on reserved regions -- the region-reserving workgroup of its LAST launch stores the sum of the
+        tile counts there (gfl_fit_order.hpp: ``*ro.total = pairs``, ``ro.total = tile_offsets + T`` in gfl_fit.hip) -- so the
+        word is at most one iteration old, whichever path ran (ADVICE r05 asked whether the reserved path leaves it stale)."""
         if getattr(self, "_pend_host", None) is None:
             self._pend_host = torch.zeros(8, dtype=torch.int32, pin_memory=True)
         self._pend_host[0:5].copy_(self._offsets_and_flags[self.T:self.T + 5], non_blocking=True)      # K, then the four words

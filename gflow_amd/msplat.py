@@ -226,9 +226,34 @@ class _Blend(torch.autograd.Function):
         return d_uv, d_conic, d_op, d_feat, None, None, None, None, None
 
 
+# The five operators driven one by one in the training pattern (several DIFFERENTIABLE composites over the same sorted lists,
+# iteration after iteration: render.py:58-106 under trainer.py:404-407) are the slow level of this drop-in: ~2.2 ms per render
+# forward + backward at 480p / 60 k against 0.23-0.35 ms for the fused ``render`` operator (INTEGRATION.md section 1,
+# bench.py ``drop_in_levels``).  A maintainer who does only the ``import msplat`` swap gets that silently -- so say it, once.
+_TRAINING_PATTERN = {"blends": 0, "warned": False}
+_TRAINING_PATTERN_AFTER = 8          # differentiable composites (two iterations of the training call's four)
+
+
+def _note_training_pattern(*tensors):
+    st = _TRAINING_PATTERN
+    if st["warned"] or not torch.is_grad_enabled() or not any(t.requires_grad for t in tensors):
+        return
+    st["blends"] += 1
+    if st["blends"] >= _TRAINING_PATTERN_AFTER:
+        st["warned"] = True
+        import warnings
+        warnings.warn(
+            "gflow_amd.msplat: the five operators are being driven one by one in a training loop (differentiable "
+            "alpha_blending calls).  That is the slow level of this drop-in (about 7-10x the fused path at 480p / 60k splats): "
+            "replace utils/render.py's render_multiple by gflow_amd.render.render_multiple (same signature; the training "
+            "call's outputs go through ONE fused operator), or call gflow_amd.render.render(gaussians, camera).  "
+            "See INTEGRATION.md section 1.", RuntimeWarning, stacklevel=3)
+
+
 def alpha_blending(uv, conic, opacity, feature, gaussian_ids_sorted, tile_range, bg, W, H):
     """Front-to-back compositing of feature (N,C) -> (C,H,W); ``bg`` is a python
     float applied to every channel (trainer.py:29-36)."""
+    _note_training_pattern(uv, conic, opacity, feature)
     uv = _f32(uv, "uv", (2,))
     conic = _f32(conic, "conic", (3,))
     n = uv.shape[0]

@@ -578,6 +578,7 @@ class SimpleGaussian:
         W, H, dev = self.W, self.H, self.device
         self.lr, self.lr_camera = lr, lr_camera
         eng = self._pack_to_engine()
+        eng._pend_event = None                     # (a watch the last stage queued and never read is not this stage's)
         eng.pose.copy_(self.pose.detach())
         eng.invalidate_regions()                   # (new pose, new frame's warp of the moving splats: the first iteration bins exactly)
         self.pose = eng.pose                       # live: get_extr() follows the optimised pose
@@ -818,9 +819,12 @@ class SimpleGaussian:
                 i = st.iteration
                 if st.yielding and not is_plain(i) and self.exact_snapshots and not eng.pending_ready():
                     return                           # (the caller comes back: train_steps)
-                if is_plain(i) and not is_plain(i + 1) and self.exact_snapshots:
+                if is_plain(i) and not is_plain(i + 1) and i + 1 < iterations and self.exact_snapshots:
                     # the plain iteration in front of a looked-at one: what ran before it is accounted for while IT runs
-                    # (one_iteration: account) -- on the exact path, so that nothing is left unaccounted for
+                    # (one_iteration: account) -- on the exact path, so that nothing is left unaccounted for.  Not the LAST
+                    # iteration of the stage: index ``iterations`` is never run, so a watch queued there would be read by
+                    # the next stage's first iteration -- after the end-of-stage settle() has already made up for the same
+                    # void iterations (they were made up twice, under the next stage's hyper-parameters)
                     if st.unchecked:
                         eng.watch_pending()
                         st.unchecked = 0
@@ -832,7 +836,8 @@ class SimpleGaussian:
                     st.iteration += 1
                     continue
                 k = 0
-                while (k < 4 and i + k < end and is_plain(i + k) and (is_plain(i + k + 1) or not self.exact_snapshots)):
+                while (k < 4 and i + k < end and is_plain(i + k)
+                       and (is_plain(i + k + 1) or i + k + 1 >= iterations or not self.exact_snapshots)):
                     k += 1
                 if k < 2 or not self.use_graph:
                     one_iteration()

@@ -19,8 +19,56 @@ def golden_dir():
     return GOLDEN
 
 
+# The driver runs ``pytest -x``: whatever fails first hides everything behind it.  So the gate is ordered by what a
+# failure MEANS: tier 0 = the CPU suite as collected; tier 1 = operator / loss / fused-iteration parity
+# against the oracle and the golden fixtures (deterministic); tier 2 = deterministic properties of the fit machinery
+# (bit-identity between paths, graphs, overflow handling, switches); tier 3 = whole fits whose bounds are SAMPLED (chaotic
+# optimisation: a flake here must not leave a parity row unreached); tier 4 = bench.py run as a process and
+# anything that looks at a clock.  Inside a tier: file order below, then the file's own order.
+_TIER1_FILES = ["test_gpu_parity", "test_gpu_loss_optim", "test_gpu_primitives", "test_gpu_fused", "test_gpu_fullsize",
+                "test_gpu_render_op", "test_gpu_densify", "test_gpu_frame_state", "test_gpu_eval_ckpt", "test_gpu_config0",
+                "test_gpu_msplat_golden"]
+_TIER2_FILES = ["test_gpu_switches", "test_gpu_fitvideo"]
+_TIER3_FILES = ["test_gpu_drift"]
+# tests of tier-1 / tier-2 FILES that belong further back: whole fits held to sampled bounds ...
+_SAMPLED = {
+    "test_config3_shape_eight_frame_clip_at_480p_60k", "test_config3_sixty_frame_clip_at_480p_60k",
+    "test_config5_720p_200k_with_densification", "test_1440p_has_14400_tiles_and_fits", "test_more_than_4096_tiles_1080p",
+    "test_fused_and_operator_clips_reach_similar_quality", "test_three_frame_clip_runs_and_improves",
+    "test_static_scene_keeps_every_parameter_finite", "test_clip_read_back_from_disk_fits_like_the_in_memory_clip",
+    "test_concurrent_fits_on_one_device_equal_the_fits_one_after_another", "test_concurrent_fits_draw_their_trajectories_too",
+    "test_camera_only_phase_moves_the_pose_not_the_splats", "test_move_seg_covers_the_moving_splats",
+    "test_trainer_fused_and_operator_paths_agree", "test_a_fit_whose_pair_lists_overflow_ends_where_one_with_room_ends",
+}
+# ... and tests that launch bench.py as processes of their own or report a wall-clock figure
+_LAST = {
+    "test_bench_collectives_over_rccl_with_one_rank", "test_bench_with_two_ranks_on_this_box",
+    "test_operator_cost_is_reported_not_asserted",
+}
+
+
+def gate_tier(nodeid):
+    """(tier, position of the file inside the tier) of a test; tests/test_host_logic.py holds the order to this function."""
+    path, _, rest = nodeid.partition("::")
+    name = rest.split("[")[0].split("::")[-1]
+    stem = os.path.splitext(os.path.basename(path))[0]
+    if not stem.startswith("test_gpu"):
+        return (0, 0)
+    if name in _LAST:
+        return (4, 0)
+    if name in _SAMPLED or stem in _TIER3_FILES:
+        return (3, (_TIER1_FILES + _TIER2_FILES + _TIER3_FILES).index(stem) if stem in _TIER1_FILES + _TIER2_FILES + _TIER3_FILES else 99)
+    if stem in _TIER1_FILES:
+        return (1, _TIER1_FILES.index(stem))
+    if stem in _TIER2_FILES:
+        return (2, _TIER2_FILES.index(stem))
+    return (2, 99)                                   # a new GPU file nobody has placed: behind parity, before the sampled fits
+
+
 def pytest_collection_modifyitems(config, items):
-    """The -m gpu tests need a HIP device: skip (not fail) them where there is none."""
+    """Order the gate (above); and the -m gpu tests need a HIP device: skip (not fail) them where there is none."""
+    order = {id(it): k for k, it in enumerate(items)}
+    items.sort(key=lambda it: (gate_tier(it.nodeid), order[id(it)]))
     try:
         import torch
         has_gpu = torch.cuda.is_available()

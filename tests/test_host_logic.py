@@ -59,7 +59,6 @@ def test_device_sampler_draws_from_the_same_distribution():
 def test_native_concave_hull_is_the_numpy_statement_of_the_algorithm():
     """gfl_concave_hull (csrc/gfl_hull.hip, host C++) against hull.concave_hull_py, the numpy statement it was written from:
     the same ring, vertex for vertex, on uniform clouds, clustered clouds, an L shape, a ring, collinear and tiny inputs."""
-    import time
     from gflow_amd.hull import concave_hull, concave_hull_py
     rng = np.random.default_rng(4)
     cases = [rng.uniform(0, 100, (n, 2)) for n in (4, 5, 17, 300, 2000)]
@@ -72,12 +71,11 @@ def test_native_concave_hull_is_the_numpy_statement_of_the_algorithm():
     cases.append(np.stack([np.arange(10.0), 2 * np.arange(10.0)], 1))                      # collinear
     cases.append(np.round(rng.uniform(0, 20, (500, 2))))                                   # integer pixels: duplicates, ties
     cases += [np.zeros((0, 2)), np.array([[1.0, 2.0]]), np.array([[0.0, 0.0], [1.0, 0.0], [0.0, 1.0]])]
-    t_py = t_c = 0.0
     for pts in cases:
-        t0 = time.perf_counter(); a = concave_hull(pts); t1 = time.perf_counter(); b = concave_hull_py(pts); t2 = time.perf_counter()
-        t_c += t1 - t0; t_py += t2 - t1
+        a, b = concave_hull(pts), concave_hull_py(pts)
         assert a.shape == b.shape and np.array_equal(a, b), (len(pts), a.shape, b.shape)
-    assert t_c < t_py
+    # (what the host function buys -- 125 -> 8 ms per clip -- is a measurement; no wall-clock assert in a
+    #  correctness test: ADVICE r05)
 
 
 def test_concave_hull_properties():
