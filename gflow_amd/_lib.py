@@ -13,20 +13,24 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "libgflow_hip.so")
+# GFLOW_HIP_LIB: another build of the same sources (e.g. one made with other rasteriser constants,
+# make CONSTS="-DGFL_PIXEL_CENTER=0.5f": include/gflow_hip.h, tests/test_gpu_pixel_center.py).  Still the HIP library -- there
+# is no other kind.
+LIB_PATH = os.environ.get("GFLOW_HIP_LIB") or os.path.join(_HERE, "libgflow_hip.so")
 
 _lock = threading.Lock()
 _lib = None
 
 c_void_p, c_int, c_float, c_size_t, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_int64
 
-MIN_VERSION = 302          # GFL_VERSION of the include/gflow_hip.h this binding mirrors (overflow[4], sort-order trailer)
+MIN_VERSION = 303          # GFL_VERSION of the include/gflow_hip.h this binding mirrors (overflow[4], sort-order trailer, gfl_constants_n)
 
 # name -> (restype, argtypes); mirrors include/gflow_hip.h one to one
 _P = c_void_p
 SIGNATURES = {
     "gfl_version": (c_int, []),
     "gfl_constants": (c_int, [_P]),
+    "gfl_constants_n": (c_int, [_P, c_int]),
     "gfl_ewa_on_mfma": (c_int, []),
     "gfl_status_string": (ctypes.c_char_p, [c_int]),
     "gfl_last_hip_error": (c_int, []),

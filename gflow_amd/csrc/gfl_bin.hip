@@ -22,6 +22,7 @@ __device__ __forceinline__ bool tile_hit(float u, float v, float cutoff, int tx,
     // box [16tx, 16tx+15] x [16ty, 16ty+15]
     const float x_lo = (float)(tx * GFL_TILE), x_hi = x_lo + (float)(GFL_TILE - 1);
     const float y_lo = (float)(ty * GFL_TILE), y_hi = y_lo + (float)(GFL_TILE - 1);
+    u = gridf(u); v = gridf(v);
     const float ddx = fmaxf(fmaxf(x_lo - u, u - x_hi), 0.f);
     const float ddy = fmaxf(fmaxf(y_lo - v, v - y_hi), 0.f);
     return ddx * ddx + ddy * ddy <= cutoff;

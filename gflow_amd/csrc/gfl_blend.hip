@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(const float* __restrict_
     const int px = tx * GFL_TILE + (wave & 1) * 8 + (lane & 7);
     const int py = ty * GFL_TILE + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
-    const float fx = (float)px, fy = (float)py;
+    const float fx = pixf(px), fy = pixf(py);
     const int start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
 
     float T = 1.f;
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(const float* __restrict_
     const int px = tx * GFL_TILE + (wave & 1) * 8 + (lane & 7);
     const int py = ty * GFL_TILE + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
-    const float fx = (float)px, fy = (float)py;
+    const float fx = pixf(px), fy = pixf(py);
     const int start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
     const int total = end - start;
 

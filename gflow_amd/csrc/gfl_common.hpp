@@ -26,6 +26,19 @@ inline int check(hipError_t e) {
 }
 
 constexpr int WAVE = 64;
+
+// where pixel p is sampled (include/gflow_hip.h: GFL_PIXEL_CENTER).  With the default 0 this is (float)p and the kernels are
+// instruction for instruction what they were without the constant.
+constexpr float PIXEL_CENTER = GFL_PIXEL_CENTER;
+__host__ __device__ __forceinline__ float pixf(int p) {
+    if constexpr (PIXEL_CENTER != 0.0f) return (float)p + PIXEL_CENTER;
+    return (float)p;
+}
+// a splat centre as the pixel GRID sees it (tests of a centre against boxes of pixel indices)
+__host__ __device__ __forceinline__ float gridf(float u) {
+    if constexpr (PIXEL_CENTER != 0.0f) return u - PIXEL_CENTER;
+    return u;
+}
 // tile sort: lists longer than SORT_SPLIT_MIN keys are cut at a pivot and sorted by two workgroups; at most SORT_MAX_SPLIT
 // tiles per launch (gfl_tile_sort.hpp; the list of such tiles is the trailer of the sort's order: gfl_fused.hip build_sort_order)
 #ifndef GFL_SORT_SPLIT_MIN

@@ -129,6 +129,7 @@ __device__ __forceinline__ bool tile_hit2(float u, float v, float cutoff, int tx
 #pragma clang fp contract(off)     // (no fused multiply-adds: the same bits in every kernel this is inlined into, and the oracle's arithmetic)
     const float x_lo = (float)(tx * GFL_TILE), x_hi = x_lo + (float)(GFL_TILE - 1);
     const float y_lo = (float)(ty * GFL_TILE), y_hi = y_lo + (float)(GFL_TILE - 1);
+    u = gridf(u); v = gridf(v);
     const float ddx = fmaxf(fmaxf(x_lo - u, u - x_hi), 0.f);
     const float ddy = fmaxf(fmaxf(y_lo - v, v - y_hi), 0.f);
     return ddx * ddx + ddy * ddy <= cutoff;

@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
     const int px = tx * GFL_TILE + (blk & 1) * 8 + (lane & 7);
     const int py = ty * GFL_TILE + (blk >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
-    const float fx = (float)px, fy = (float)py;
+    const float fx = pixf(px), fy = pixf(py);
     const int start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
     const int total = end - start;
     const int parts = item.part >= 0 ? heavy_parts(total) : 1;

@@ -106,7 +106,7 @@ __device__ __forceinline__ void footprint_tile(const float* __restrict__ rec, co
     const int px = tx * GFL_TILE + (wave & 1) * 8 + (lane & 7);
     const int py = ty * GFL_TILE + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
-    const float fx = (float)px, fy = (float)py;
+    const float fx = pixf(px), fy = pixf(py);
     const int start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
     bool marked = !inside;                               // nothing left to find for this lane
     for (int base = start; base < end; base += FB) {
@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(256, mode == 2 ? FWD_WG_PER_CU - 1 : FWD_WG_PE
         // (the FIRST splat behind which T would fall below 1e-4) and the last contributor are found on the scanned values.
         const int ls = lane & 15, lr = lane >> 4;
         const int qx0 = tx * GFL_TILE + (blk & 1) * 8 + (wave & 1) * 4, qy0 = ty * GFL_TILE + (blk >> 1) * 8 + (wave >> 1) * 4;
-        const float fxq = (float)(qx0 + lr);
+        const float fxq = pixf(qx0 + lr);
         float Tq[4], c0q[4], c1q[4], c2q[4], c3q[4];
         float d0q[4], d1q[4], d2q[4];                // (mode 2: depth_map_color)
         int lastq[4];
@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(256, mode == 2 ? FWD_WG_PER_CU - 1 : FWD_WG_PE
                     if (DC) dq = s_dc[j];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const float fyq = (float)(qy0 + g);
+                        const float fyq = pixf(qy0 + g);
                         float al, G;
                         const bool val = splat_alpha2(q0, q1, fxq, fyq, al, G);
                         const float a = val ? al : 0.f;
@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(256, mode == 2 ? FWD_WG_PER_CU - 1 : FWD_WG_PE
     const int px0w = org_x + (wb & 1) * 8, py0w = org_y + (wb >> 1) * 8;
     const int px = px0w + (lane & 7), py = py0w + (lane >> 3);
     const bool inside = px < W && py < H;
-    const float fx = (float)px, fy = (float)py;
+    const float fx = pixf(px), fy = pixf(py);
     float* ck = ckpt + (size_t)max(slot, 0) * (HEAVY_PARTS - 1) * 5 * 256 + wb * 64 + lane;
     int ck_next = 1;                                 // next boundary to checkpoint: position ck_next * seg
 #ifdef GFL_TRACE

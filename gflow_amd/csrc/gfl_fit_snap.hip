@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(256) center_blend_kernel(const float* __restri
     const int px = tx * GFL_TILE + (wave & 1) * 8 + (lane & 7);
     const int py = ty * GFL_TILE + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
-    const float fx = (float)px, fy = (float)py;
+    const float fx = pixf(px), fy = pixf(py);
     const int start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
     const float blob_cutoff = alpha_cutoff(1.f, 1.f);
     float T = 1.f, Tw = inside ? 1.f : 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;

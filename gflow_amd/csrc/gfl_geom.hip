@@ -173,6 +173,14 @@ int gfl_constants(float* out10) {
     return GFL_OK;
 }
 
+int gfl_constants_n(float* out, int n) {
+    if (!out || n < 0) return GFL_ERR_INVALID;
+    const float c[GFL_N_CONSTANTS] = {(float)GFL_TILE, GFL_NEAREST, GFL_EXTENT, GFL_FOV_CLAMP, GFL_LOWPASS, GFL_EIG_FLOOR,
+                                      GFL_RADIUS_SIGMA, GFL_ALPHA_MIN, GFL_ALPHA_MAX, GFL_T_MIN, GFL_PIXEL_CENTER};
+    for (int k = 0; k < n && k < GFL_N_CONSTANTS; ++k) out[k] = c[k];
+    return GFL_N_CONSTANTS;
+}
+
 const char* gfl_status_string(int status) {
     switch (status) {
         case GFL_OK: return "ok";

@@ -318,7 +318,7 @@ struct BlockTest {
 };
 __device__ __forceinline__ BlockTest block_test(const float4& p0, const float4& p1, float cutoff) {
     BlockTest t;
-    t.u = p0.x; t.v = p0.y; t.A = p0.z; t.B2 = 2.f * p0.w; t.C = p1.x;
+    t.u = gridf(p0.x); t.v = gridf(p0.y); t.A = p0.z; t.B2 = 2.f * p0.w; t.C = p1.x;
     t.bA = p0.w * __builtin_amdgcn_rcpf(p0.z);
     t.bC = p0.w * __builtin_amdgcn_rcpf(p1.x);
     const float r = 255.f * p1.y;

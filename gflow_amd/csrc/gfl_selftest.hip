@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(256) selftest_block_mask_kernel(const float* _
         for (int y = 0; y < bs; ++y)
             for (int x = 0; x < bs; ++x) {
 #pragma clang fp contract(off)
-                const float fx = (float)(x0 + (w & 1) * bs + x), fy = (float)(y0 + (w >> 1) * bs + y);
+                const float fx = pixf(x0 + (w & 1) * bs + x), fy = pixf(y0 + (w >> 1) * bs + y);
                 const float dx = p0.x - fx, dy = p0.y - fy;
                 const float q = __builtin_fmaf(p0.z * dx, dx, (p1.x * dy) * dy);
                 const float power = __builtin_fmaf(-0.5f, q, -((p0.w * dx) * dy));

@@ -85,6 +85,14 @@ typedef enum gfl_status {
 #ifndef GFL_T_MIN
 #define GFL_T_MIN 1e-4f
 #endif
+/* where inside pixel (px, py) the composite is SAMPLED: at (px + GFL_PIXEL_CENTER, py + GFL_PIXEL_CENTER) in the coordinates
+ * project_point returns.  0 = pixel centres at integer coordinates (3DGS's ndc2Pix convention; what GFlow itself suggests:
+ * splats are created AT integer pixels, complex_texture_sampling.py:39, and targets are read at uv.long(), trainer.py:473);
+ * 0.5f = the gsplat convention.  If upstream msplat samples at +0.5 every render here is half a pixel off until this is
+ * set.  Only the sampling moves: uv, radius and tiles_touched are coordinate quantities and stay. */
+#ifndef GFL_PIXEL_CENTER
+#define GFL_PIXEL_CENTER 0.0f
+#endif
 #define GFL_MAX_BLEND_CHANNELS 4 /* per launch; the host splits wider features */
 
 /* 300 (round 5): gfl_fit_state.overflow is int32[4] (was [1] before 200's reserved regions), gfl_tile_sort_ordered reads a
@@ -92,12 +100,16 @@ typedef enum gfl_status {
  * (GFL_ITER_PRE_DONE / _PRE_NEXT / _ODD, gfl_fit_next_preprocess_supported and gfl_bwd_rows_on are gone), the fit
  * workspace is smaller.  301: gfl_fit_iteration_snapshot.  302: the tile sorts no longer fill a table of list positions
  * (gfl_tile_sort_with_slots is gone, gfl_tile_sort_ordered / _reserved lost their rec / slot_inv / slot_pool arguments): the
- * per-splat launch finds its pair rows without one.
+ * per-splat launch finds its pair rows without one.  303: GFL_PIXEL_CENTER, gfl_constants_n.
  * A binding checks gfl_version() >= GFL_VERSION of the header it was written for. */
-#define GFL_VERSION 302
+#define GFL_VERSION 303
 int gfl_version(void);
 /* out[10] = TILE, NEAREST, EXTENT, FOV_CLAMP, LOWPASS, EIG_FLOOR, RADIUS_SIGMA, ALPHA_MIN, ALPHA_MAX, T_MIN of this build */
 int gfl_constants(float* out10);
+/* 303: the same list with what came later behind it -- [10] = PIXEL_CENTER.  Writes min(n, GFL_N_CONSTANTS) values, returns
+ * GFL_N_CONSTANTS (so a binding written for a shorter list keeps working and one written for a longer list sees the gap). */
+#define GFL_N_CONSTANTS 11
+int gfl_constants_n(float* out, int n);
 /* 1 when this process runs the J Sigma J^T contraction of gfl_fit_forward / gfl_render_fwd on the matrix cores
  * (GFL_EWA_MFMA=1 in the environment when the library first looked), 0 for the VALU form */
 int gfl_ewa_on_mfma(void);

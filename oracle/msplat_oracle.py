@@ -32,6 +32,7 @@ RADIUS_SIGMA = 3.0        # pixel radius = ceil(RADIUS_SIGMA * sqrt(lambda_max))
 ALPHA_MIN = 1.0 / 255.0   # skip a splat at a pixel when alpha < ALPHA_MIN
 ALPHA_MAX = 0.99          # alpha cap (straight-through in the backward, 3DGS)
 T_MIN = 1e-4              # stop compositing a pixel when T would drop below
+PIXEL_CENTER = 0.0        # pixel (x, y) is sampled at (x + PIXEL_CENTER, y + PIXEL_CENTER): 0 = 3DGS, 0.5 = gsplat
 
 
 # --------------------------------------------------------------------------- A4
@@ -208,7 +209,7 @@ def alpha_blending(uv, conic, opacity, feature, gaussian_ids_sorted, tile_range,
                    max_elems=6_000_000):
     """Front-to-back compositing.  feature (N,C) -> out (C,H,W).
 
-    Per pixel p at integer coordinates (x,y), for the splats of its tile in sorted
+    Per pixel (x,y), sampled at p = (x + PIXEL_CENTER, y + PIXEL_CENTER), for the splats of its tile in sorted
     order: d = uv_i - p; power = -0.5(a dx^2 + c dy^2) - b dx dy; skip if power > 0;
     alpha = min(ALPHA_MAX, o_i exp(power)); skip if alpha < ALPHA_MIN; stop (before
     adding this splat) when T(1-alpha) < T_MIN; out += f_i alpha T; T *= 1-alpha.
@@ -225,7 +226,7 @@ def alpha_blending(uv, conic, opacity, feature, gaussian_ids_sorted, tile_range,
     if ids_all.numel() > 0:
         order = torch.argsort(lens, descending=True)
         order = order[lens[order] > 0]
-        px_off = torch.arange(TILE, dtype=dt)
+        px_off = torch.arange(TILE, dtype=dt) + PIXEL_CENTER
         pos = 0
         pieces = []
         while pos < order.numel():
@@ -361,7 +362,7 @@ def alpha_blending_loops(uv, conic, opacity, feature, gaussian_ids_sorted, tile_
             last = 0
             for k in range(s, e):
                 g = ids[k]
-                dx, dy = uvn[g, 0] - x, uvn[g, 1] - y
+                dx, dy = uvn[g, 0] - (x + PIXEL_CENTER), uvn[g, 1] - (y + PIXEL_CENTER)
                 power = -0.5 * (cn[g, 0] * dx * dx + cn[g, 2] * dy * dy) - cn[g, 1] * dx * dy
                 if power > 0:
                     continue

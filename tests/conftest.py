@@ -27,7 +27,7 @@ def golden_dir():
 # anything that looks at a clock.  Inside a tier: file order below, then the file's own order.
 _TIER1_FILES = ["test_gpu_parity", "test_gpu_loss_optim", "test_gpu_primitives", "test_gpu_fused", "test_gpu_fullsize",
                 "test_gpu_render_op", "test_gpu_densify", "test_gpu_frame_state", "test_gpu_eval_ckpt", "test_gpu_config0",
-                "test_gpu_msplat_golden"]
+                "test_gpu_msplat_golden", "test_gpu_pixel_center"]
 _TIER2_FILES = ["test_gpu_switches", "test_gpu_fitvideo"]
 _TIER3_FILES = ["test_gpu_drift"]
 # tests of tier-1 / tier-2 FILES that belong further back: whole fits held to sampled bounds ...

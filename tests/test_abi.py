@@ -86,6 +86,20 @@ def test_library_and_oracle_use_the_same_constants():
             MO.ALPHA_MAX, MO.T_MIN]
     for got, ref in zip(out, want):
         assert abs(got - ref) <= 1e-7 * max(1.0, abs(ref)), (list(out), want)
+    # the whole list, the tenth assumption of SURVEY.md 8c included: where a pixel is sampled (GFL_PIXEL_CENTER)
+    hdr = open(os.path.join(ROOT, "include", "gflow_hip.h")).read()
+    n_hdr = int(re.search(r"^#define GFL_N_CONSTANTS (\d+)$", hdr, flags=re.M).group(1))
+    lib = _lib.load()
+    lib.gfl_constants_n.restype = ctypes.c_int
+    lib.gfl_constants_n.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_int]
+    full = (ctypes.c_float * 16)(*([-7.0] * 16))
+    assert lib.gfl_constants_n(full, 16) == n_hdr == len(want) + 1
+    want_full = want + [MO.PIXEL_CENTER]
+    for got, ref in zip(full, want_full):
+        assert abs(got - ref) <= 1e-7 * max(1.0, abs(ref)), (list(full), want_full)
+    assert full[n_hdr] == -7.0                       # nothing written past the list
+    short = (ctypes.c_float * 4)(*([-7.0] * 4))
+    assert lib.gfl_constants_n(short, 3) == n_hdr and abs(short[2] - want[2]) < 1e-6 and short[3] == -7.0
 
 
 def test_iteration_flags_of_the_host_side_are_the_headers():
