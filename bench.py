@@ -64,25 +64,26 @@ def profile_read(lib):
     return {STAGES[i]: tot[i] / cnt[i] for i in range(len(STAGES)) if cnt[i]}
 
 
-def pmc_block(kind):
-    """What the committed rocprofv3 counter passes of this same command say about the dominant kernel
+def pmc_block(kind, window="first_frame"):
+    """What the committed rocprofv3 counter passes of this same command say about a kernel of a pinned window
     (profiles/pmc_current.json, written by tools/profile_round.sh -> tools/summarise_profile.py; counters cannot be read
     from inside the process): ``traffic`` = HBM bytes per launch (FETCH_SIZE and WRITE_SIZE in separate passes,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), and ``secondary`` = the issue bound SURVEY.md 8d
     asks for beside the HBM bound: VALU wave-instructions per launch, the share of the launch the VALUs were busy
     (SQ_ACTIVE_INST_VALU quad-cycles x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)) and the lane efficiency of a
-    (splat, 8x8 block) unit (tools/lane_efficiency.py on the same scene)."""
+    (splat, 8x8 block) unit.  ``window``: "first_frame" | "camera" | "joint" (bench.py's three pinned windows)."""
     path = os.path.join(ROOT, "profiles", "pmc_current.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        src = "profiles/pmc_current.json (" + d.get("tag", "?") + ")"
-        out = {"traffic": float(d["hbm_bytes_per_launch"][kind]), "traffic_source": src}
-        v = d.get("valu", {}).get(kind)
+        src = "profiles/pmc_current.json (" + d.get("tag", "?") + ", window " + window + ")"
+        w = d["windows"][window] if "windows" in d else (d if window == "first_frame" else None)
+        out = {"traffic": float(w["hbm_bytes_per_launch"][kind]), "traffic_source": src}
+        v = w.get("valu", {}).get(kind)
         if v:
             out["secondary"] = dict(v, bound="valu", source=src)
         return out
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, TypeError):
         return {"traffic": None}
 
 
@@ -180,6 +181,172 @@ def drop_in_levels(dev, Hh=None, Ww=None, Nn=None, repeats=3, n=20):
             "rgb_max_abs_diff": diff, "size": f"{Hh}x{Ww}, {Nn} splats", "calls": f"best of {repeats} x {n}"}
 
 
+# The clip's own stages, pinned like the first-frame window: frame CLIP_WINDOW_FRAME of the metric's clip, after a real fit
+# of the frames before it -- N ~ 70 k splats with the piles of thirty frames' densification, frozen colours, flow and still
+# terms -- its camera-only stage at iterations [CAM_I0, +20) (backward blend <6>, forward <3> with the footprint workgroups,
+# fused_camera_adam) and its joint stage at [JOINT_I0, +20) (backward blend <7>: behind both densifications, 0 and 99).
+# 98 % of the metric's 27 050 iterations are of these two kinds (59 x 150 and 59 x 300); the first-frame window describes 500.
+CLIP_WINDOW_FRAME, CAM_I0, JOINT_I0 = 30, 60, 120
+STAGE_SHARE = {"first_frame": 500 / 27050.0, "camera": 59 * 150 / 27050.0, "joint": 59 * 300 / 27050.0}
+
+
+def measure_window(eng, stepper, saved, args, barrier, lib, units=True):
+    """Time the pinned window the stepper stands at the start of: W warm-up steps, then EXACTLY K steps between two barriers
+    (-> elapsed: what ms_per_step is quoted on), then the same K steps ``args.repeats`` times more, each between barriers of
+    its own (-> repeats: a 4 ms region on a box whose minutes differ by 5 % says little alone), then once more with the
+    library's HIP events around every stage (-> stage_ms) and the pair count of every iteration read (-> K).  K > 20 timed
+    steps replay the same 20 iterations: the state is put back after every 20."""
+    import gc
+
+    def run_window(n):
+        done = 0
+        while done < n:
+            k = min(STEP_WINDOW, n - done)
+            if done:
+                eng.restore_state(saved)
+            stepper.run(k)
+            done += k
+
+    # (at least one whole window, a restore and 4 + 2 + 1 steps untimed: the replayed graphs hold one, two or four iterations,
+    #  and the one that follows a restore starts on the exact binning path -- every variant is captured before the clock runs)
+    # The interpreter's collection comes BEFORE the warm-up steps, not between them and the clock: it takes tens of
+    # milliseconds, the device sat idle meanwhile, and the first launches of a 4 ms timed region then ran on clocks that had
+    # dropped (--steps 20: 0.208 ms per step against 0.196 at --steps 200, the same kernels).
+    gc.collect()
+    gc.disable()          # (a generation-2 collection of the interpreter inside a 4 ms timed region is not the kernels' time)
+    try:
+        run_window(max(args.warmup, STEP_WINDOW + 7))
+        eng.restore_state(saved)
+        # timed region: exactly K steps, no instrumentation (an event pair between two kernels
+        # opens a 5-10 us bubble on the stream, measured with rocprofv3)
+        barrier()
+        void0 = int(eng.overflow[1].item())
+        t0 = time.perf_counter()
+        run_window(args.steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        # iterations of the timed region that stepped nothing because a tile outgrew its reserved region (FitEngine.settle_overflow)
+        void_iterations = int(eng.overflow[1].item()) - void0
+        reps = []
+        for _ in range(max(0, args.repeats)):
+            eng.restore_state(saved)
+            barrier()
+            t0 = time.perf_counter()
+            run_window(args.steps)
+            barrier()
+            reps.append((time.perf_counter() - t0) / args.steps * 1e3)
+    finally:
+        gc.enable()
+    # the same K steps again with HIP events recorded by the library on the launch stream
+    # around every stage: per-kernel durations for the roofline block; and the window's pair counts K
+    stage_ms = {}
+    n_k = min(args.steps, STEP_WINDOW)
+    k_dev = torch.zeros(STEP_WINDOW, dtype=torch.int32, device=eng.dev)
+    if not args.no_stage_pass:
+        from gflow_amd.fused import set_profile
+        set_profile((1 << len(STAGES)) - 1)
+        for i in range(args.steps):
+            if i % STEP_WINDOW == 0:
+                eng.restore_state(saved)
+            stepper()
+            k_dev[i % STEP_WINDOW:i % STEP_WINDOW + 1].copy_(eng.tile_offsets[eng.T:eng.T + 1])
+        torch.cuda.synchronize()
+        set_profile(0)
+        stage_ms = profile_read(lib)
+    else:
+        eng.restore_state(saved)
+        for i in range(n_k):
+            stepper()
+            k_dev[i:i + 1].copy_(eng.tile_offsets[eng.T:eng.T + 1])
+    eng.check_overflow()                   # (the stepper is driven directly here: no train() looks at the pair lists' flag)
+    ks = k_dev[:n_k].cpu().tolist()
+    out = {"elapsed": elapsed, "ms_per_step": elapsed / args.steps * 1e3, "timed_region_s": elapsed, "stage_ms": stage_ms,
+           "K_list": ks, "K_mean": sum(ks) / len(ks),          # mean over the window's iterations: what the kernels' average durations belong to
+           "void_iterations": void_iterations, "reserved_on": bool(eng._reserved_flag()), "splats": int(eng.N)}
+    if reps:
+        r = sorted(reps)
+        out["repeats"] = {"n": len(r), "median": r[len(r) // 2], "min": r[0], "max": r[-1], "steps_each": args.steps,
+                          "note": "the same window timed again in this process, a barrier + synchronise on both sides of "
+                                  "each; ms per step"}
+    if units:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from unit_stats import unit_stats
+            out["work"] = unit_stats(eng)          # of the window's LAST iteration's forward
+        except Exception as e:
+            out["work"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def window_report(m, name, kernels, N, P):
+    """A window's entry of the JSON line: step time, its spread, the work, the blend kernels against the HBM roofline."""
+    K = m["K_mean"]
+    kern = {}
+    for kind in ("blend_fwd", "loss", "blend_bwd"):
+        ms = m["stage_ms"].get(kind)
+        if ms:
+            b = algorithmic_bytes(kind, N, K, P)
+            kern[kind] = {"kernel": kernels.get(kind), "ms": ms, "algorithmic_bytes": b, "GBps": b / (ms * 1e-3) / 1e9,
+                          "frac_of_hbm_peak": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    out = {"name": name, "share_of_the_clips_iterations": STAGE_SHARE.get(name), "ms_per_step": m["ms_per_step"],
+           "timed_region_s": m["timed_region_s"], "ms_per_step_repeats": m.get("repeats"), "splats": m["splats"],
+           "K_mean": K, "K_first": m["K_list"][0], "K_last": m["K_list"][-1], "void_iterations": m["void_iterations"],
+           "stage_ms": m["stage_ms"], "stage_sum_ms": sum(m["stage_ms"].values()) if m["stage_ms"] else None,
+           "kernels": kern, "work": m.get("work"),
+           "algorithmic_bytes_per_iteration": 724 * N + 124 * K + 96 * P}
+    if m["stage_ms"]:
+        out["end_to_end_algorithmic_GBps"] = out["algorithmic_bytes_per_iteration"] / (m["ms_per_step"] * 1e-3) / 1e9
+    return out
+
+
+def measure_clip_windows(dev, rank, args, barrier, lib, which=("camera", "joint")):
+    """The two mid-clip windows (see CLIP_WINDOW_FRAME above).  The frames before the window's frame are really fitted
+    (README recipe, snapshots on), then the frame's camera-only stage is set up and timed, run for real, and the joint stage
+    set up and timed: the trainer's own calls (fit_video.begin_frame / stage_kwargs), no shortcut."""
+    from gflow_amd import synthetic as S
+    from gflow_amd import fit_video as FV
+    f_i = min(CLIP_WINDOW_FRAME, args.clip_frames - 1)
+    if f_i < 1:
+        return None
+    c = dict(FV.DEFAULTS)
+    c.update(num_points=N_SPLATS)
+    frames = FV.upload_clip(S.make_clip(f_i + 1, H, W, seed=rank, device=dev), dev)      # (a clip's frames do not depend on its length)
+    keep = {}
+    FV.fit_clip(frames[:f_i], dev, dict(num_points=N_SPLATS), seed=rank, snapshot_interval=args.snapshot_interval, keep=keep)
+    tr = keep["trainer"]
+    common = dict(lambda_rgb=c["lambda_rgb"], lambda_depth=c["lambda_depth"], lambda_scale=c["lambda_scale"],
+                  densify_occ_percent=c["densify_occ_percent"], densify_err_thre=c["densify_err_thre"],
+                  densify_err_percent=c["densify_err_percent"])
+    out = {"frame": f_i, "note": f"frame {f_i} of the metric's clip after a real fit of frames [0, {f_i}); camera-only stage "
+                                 f"iterations [{CAM_I0}, {CAM_I0 + STEP_WINDOW}), joint stage [{JOINT_I0}, {JOINT_I0 + STEP_WINDOW})"}
+    P = H * W
+    FV.begin_frame(tr, frames, f_i)
+    # camera-only stage: a stepper of our own for the window, then the pose is put back and the stage is run for real
+    pose0 = tr.pose.detach().clone()
+    st = tr.make_stepper(**FV.stage_kwargs(c, frames, f_i, "camera"), snapshot_interval=0, **common)
+    eng = tr.engine
+    if "camera" in which:
+        st.run(CAM_I0)
+        m = measure_window(eng, st, eng.save_state(), args, barrier, lib)
+        out["camera"] = window_report(m, "camera", {"blend_fwd": "fused_blend_fwd_kernel<3>", "blend_bwd": "fused_blend_bwd_kernel<6>"},
+                                      m["splats"], P)
+    del st
+    eng.pose.copy_(pose0)
+    if "joint" not in which:
+        return out
+    tr.train(**FV.stage_kwargs(c, frames, f_i, "camera"), snapshot_interval=args.snapshot_interval, lazy_images=True, **common)
+    # joint stage (the stepper's set-up carries the moving splats along the flow, appends the occlusion splats at iteration 0
+    # and the error splats at 99: the window lies behind both)
+    st = tr.make_stepper(**FV.stage_kwargs(c, frames, f_i, "joint"), snapshot_interval=0, **common)
+    eng = tr.engine
+    st.run(JOINT_I0)
+    m = measure_window(eng, st, eng.save_state(), args, barrier, lib)
+    out["joint"] = window_report(m, "joint", {"blend_fwd": "fused_blend_fwd_kernel<0>", "blend_bwd": "fused_blend_bwd_kernel<7>"},
+                                 m["splats"], P)
+    del st, tr, keep
+    return out
+
+
 def cpu_baseline():
     """The oracle's fit iteration on the host cores: 3 warm-ups + 20 timed iterations of
     the bench workload (480x854, 60 000 splats) and of the C1-size workload (10 000 splats)."""
@@ -247,12 +414,26 @@ def reduce_and_report(local, dist, red_dev, rank, world, args, backend, size=Non
             # rank 0's kernels on rank 0's scene
             b = algorithmic_bytes(kind, Nn, local["K"], P)
             roof[kind] = {"ms": ms, "algorithmic_bytes": b, "GBps": b / (ms * 1e-3) / 1e9}
-    roofline = None
+    roofline = roofline_first = None
     if roof:
         dom = max(roof, key=lambda k: roof[k]["ms"])
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": roof[dom]["GBps"], "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": roof[dom]["GBps"] / HBM_PEAK_GBPS}
-        roofline.update(pmc_block(dom))
+        roofline_first = {"bound": "hbm", "kernel": dom, "window": "first_frame", "achieved": roof[dom]["GBps"],
+                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": roof[dom]["GBps"] / HBM_PEAK_GBPS}
+        roofline_first.update(pmc_block(dom, "first_frame"))
+        roofline = roofline_first
+    # The dominant kernel of the METRIC's workload: 65 % of a clip's iterations are joint-stage iterations of later frames
+    # (backward blend <7>, frozen colours), 33 % camera-only (<6>), 2 % first-frame (<10>) -- so the roofline block describes
+    # the joint-stage window when it was measured, and the first-frame window's block stays beside it.
+    cwin = local.get("clip_windows") or {}
+    jw = cwin.get("joint") if isinstance(cwin, dict) else None
+    if jw and jw.get("kernels"):
+        kk = jw["kernels"]
+        dom = max(kk, key=lambda k: kk[k]["ms"])
+        roofline = {"bound": "hbm", "kernel": kk[dom]["kernel"] or dom, "window": "joint (step_window_clip)",
+                    "achieved": kk[dom]["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": kk[dom]["GBps"] / HBM_PEAK_GBPS,
+                    "algorithmic_bytes_per_launch": kk[dom]["algorithmic_bytes"], "avg_launch_ms": kk[dom]["ms"],
+                    "share_of_the_clips_iterations": STAGE_SHARE["joint"]}
+        roofline.update(pmc_block(dom, "joint"))
     derived = it_per_s / ITERS_PER_FRAME
     workload = ("configs[1]" if (Hh, Ww, Nn) == (480, 854, 60000) else "other") + f": {Hh}x{Ww}, {Nn} splats"
     if clip is not None:
@@ -295,6 +476,8 @@ def reduce_and_report(local, dist, red_dev, rank, world, args, backend, size=Non
         "config": {"workload": workload, "iterations_per_frame": ITERS_PER_FRAME, "splat_tile_pairs_K": K_mean,
                    "step_window": {"iterations": [STEP_I0, STEP_I0 + STEP_WINDOW], "K_first": local.get("K_first"),
                                    "K_last": local.get("K_last"), "K_mean": local["K"],
+                                   "timed_region_s": local["elapsed"], "splats": Nn,
+                                   "work": (local.get("window") or {}).get("work"),
                                    # the window's first iteration follows restore_state and bins on the exact path (three
                                    # launches); the other 19 bin into the tile regions the iteration before reserved (one)
                                    "binning": ("reserved tile regions in %d of %d iterations" % (STEP_WINDOW - 1, STEP_WINDOW))
@@ -311,12 +494,40 @@ def reduce_and_report(local, dist, red_dev, rank, world, args, backend, size=Non
         "frames_per_s_derived_from_step": derived,
         "psnr_step_mean_db": float(stats[2].item()) / world,
         "roofline": roofline,
+        "roofline_first_frame_window": roofline_first,
         "kernels": roof,
         "stage_ms": local["stage_ms"],
+        # the same window timed `--repeats` times more in this process (a 4 ms region alone cannot carry a 3-5 % claim)
+        "ms_per_step_repeats": (local.get("window") or {}).get("repeats"),
+        "step_window_camera": cwin.get("camera") if isinstance(cwin, dict) else None,
+        "step_window_clip": jw,
+        "clip_windows": {k: v for k, v in cwin.items() if k not in ("camera", "joint")} if isinstance(cwin, dict) else cwin,
+        "clip_iteration_model": clip_iteration_model(local, cwin, clip_out, world),
         # whole job (all ranks) and per GPU
         "end_to_end_algorithmic_GBps": bytes_per_iteration * it_per_s / 1e9,
         "end_to_end_algorithmic_GBps_per_gpu": bytes_per_iteration * it_per_s / world / 1e9,
     }
+
+
+def clip_iteration_model(local, cw, clip_out, world=1):
+    """Do the three pinned windows explain the clip fit?  Their step times weighted by the stages' shares of the clip's
+    iterations, against the clip fit's own wall time per iteration (which also holds densification events, snapshots,
+    frame boundaries and host time)."""
+    try:
+        w1 = local["elapsed"] / local["steps"] * 1e3
+        cam, joint = cw["camera"]["ms_per_step"], cw["joint"]["ms_per_step"]
+        model = STAGE_SHARE["first_frame"] * w1 + STAGE_SHARE["camera"] * cam + STAGE_SHARE["joint"] * joint
+        out = {"windows_weighted_ms_per_iteration": model,
+               "weights": STAGE_SHARE, "note": "first-frame, camera-only and joint window step times weighted by the stages' "
+                                               "shares of a 60-frame clip's 27 050 iterations (mid-clip state: frame %d)" % CLIP_WINDOW_FRAME}
+        if clip_out:
+            # (iterations of all ranks' clips; a rank's clips run one after another unless --clips-per-gpu says otherwise)
+            meas = clip_out["wall_s"] / max(clip_out["iterations"] / world, 1) * 1e3
+            out["clip_fit_ms_per_iteration"] = meas
+            out["unexplained_frac"] = (meas - model) / meas
+        return out
+    except (KeyError, TypeError, ZeroDivisionError):
+        return None
 
 
 def respawn(args):
@@ -354,6 +565,13 @@ def main():
     ap.add_argument("--no-coresident", action="store_true",
                     help="skip the secondary table of 1 / 2 / 3 clip fits sharing this GPU (clips_per_gpu)")
     ap.add_argument("--coresident-frames", type=int, default=8, help="frames per clip of that secondary table")
+    ap.add_argument("--no-clip-windows", action="store_true",
+                    help="skip the two mid-clip step windows (camera-only and joint stage of frame %d)" % CLIP_WINDOW_FRAME)
+    ap.add_argument("--only-window", choices=("first_frame", "camera", "joint"), default=None,
+                    help="profiling runs (tools/profile_round.sh): nothing but this pinned window -- no clip fit, no secondary "
+                         "tables -- so that the LAST launches of every kernel in a rocprofv3 trace are the window's")
+    ap.add_argument("--repeats", type=int, default=10,
+                    help="time every pinned window this many times more (ms_per_step_repeats: median / min / max)")
     ap.add_argument("--no-drop-in-levels", action="store_true",
                     help="skip the secondary table of what the three levels of the drop-in cost (five operators / fused "
                          "render operator / fused fit iteration)")
@@ -365,6 +583,8 @@ def main():
                          "trainer.py:573-582); 0 = none")
     args = ap.parse_args()
 
+    if args.only_window:
+        args.no_clip = args.no_coresident = args.no_drop_in_levels = args.no_cpu_baseline = True
     global H, W, N_SPLATS
     if args.size:
         H, W, N_SPLATS = (int(v) for v in args.size.lower().split("x"))
@@ -445,70 +665,26 @@ def main():
     eng = tr.engine
     # the pinned window: iterations [STEP_I0, STEP_I0 + STEP_WINDOW) of this fit, whatever --steps / --warmup are
     stepper.run(STEP_I0)
-    saved = eng.save_state()
-
-    def run_window(n):
-        """n timed or untimed steps: the window's iterations, over and over"""
-        done = 0
-        while done < n:
-            k = min(STEP_WINDOW, n - done)
-            if done:
-                eng.restore_state(saved)
-            stepper.run(k)
-            done += k
-
-    # (at least one whole window, a restore and 4 + 2 + 1 steps untimed: the replayed graphs hold one, two or four iterations,
-    #  and the one that follows a restore starts on the exact binning path -- every variant is captured before the clock runs)
-    # The interpreter's collection comes BEFORE the warm-up steps, not between them and the clock: it takes tens of
-    # milliseconds, the device sat idle meanwhile, and the first launches of a 4 ms timed region then ran on clocks that had
-    # dropped (--steps 20: 0.208 ms per step against 0.196 at --steps 200, the same kernels).
-    import gc
-    gc.collect()
-    gc.disable()          # (a generation-2 collection of the interpreter inside a 4 ms timed region is not the kernels' time)
-    run_window(max(args.warmup, STEP_WINDOW + 7))
-    eng.restore_state(saved)
-    # timed region: exactly K steps, no instrumentation (an event pair between two kernels
-    # opens a 5-10 us bubble on the stream, measured with rocprofv3)
-    barrier()
-    void0 = int(eng.overflow[1].item())
-    t0 = time.perf_counter()
-    run_window(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
-    # iterations of the timed region that stepped nothing because a tile outgrew its reserved region (FitEngine.settle_overflow)
-    void_iterations = int(eng.overflow[1].item()) - void0
-    # the same K steps again with HIP events recorded by the library on the launch stream
-    # around every stage: per-kernel durations for the roofline block; and the window's pair counts K
-    kern_all = {}
-    k_dev = torch.zeros(STEP_WINDOW, dtype=torch.int32, device=dev)
-    if not args.no_stage_pass:
-        from gflow_amd.fused import set_profile
-        set_profile((1 << len(STAGES)) - 1)
-        for i in range(args.steps):
-            if i % STEP_WINDOW == 0:
-                eng.restore_state(saved)
-            stepper()
-            k_dev[i % STEP_WINDOW:i % STEP_WINDOW + 1].copy_(eng.tile_offsets[eng.T:eng.T + 1])
-        torch.cuda.synchronize()
-        set_profile(0)
-        kern_all = profile_read(lib)
-    else:
-        eng.restore_state(saved)
-        for i in range(min(args.steps, STEP_WINDOW)):
-            stepper()
-            k_dev[i:i + 1].copy_(eng.tile_offsets[eng.T:eng.T + 1])
+    m1 = measure_window(eng, stepper, eng.save_state(), args, barrier, lib)
+    elapsed, kern_all, K, ks = m1["elapsed"], m1["stage_ms"], m1["K_mean"], m1["K_list"]
+    void_iterations, reserved_on = m1["void_iterations"], m1["reserved_on"]
     kern = {k: kern_all[k] for k in ("blend_fwd", "loss", "blend_bwd") if k in kern_all}
-    eng.check_overflow()                   # (the stepper is driven directly here: no train() looks at the pair lists' flag)
-    reserved_on = bool(eng._reserved_flag())
-    ks = k_dev[:min(args.steps, STEP_WINDOW)].cpu().tolist()
-    K = sum(ks) / len(ks)                  # mean over the window's iterations: what the kernels' average durations belong to
     psnr_step = float(tr.psnr_of(stepper.last_render))
-    del stepper, tr, eng, saved
+    del stepper, tr, eng
+
+    # ------------------------------------------------ the clip's own two stages, pinned the same way (rank 0's scene)
+    clip_windows = None
+    want_cw = (args.only_window in ("camera", "joint")) or (not args.only_window and not args.no_clip_windows and not args.no_clip)
+    if want_cw and (H, W, N_SPLATS) == (480, 854, 60000):
+        try:
+            clip_windows = measure_clip_windows(dev, rank, args, barrier, lib,
+                                                which=(args.only_window,) if args.only_window else ("camera", "joint"))
+        except Exception as e:                       # secondary windows must not cost the line
+            clip_windows = {"error": f"{type(e).__name__}: {e}"}
 
     local = {"elapsed": elapsed, "steps": args.steps, "psnr_step": psnr_step, "K": K, "K_first": ks[0], "K_last": ks[-1],
              "clip": clip, "clip_wall": clip_wall, "clip_wall_own": own_wall, "kernels_ms": kern, "stage_ms": kern_all,
-             "void_iterations": void_iterations, "reserved_on": reserved_on}
+             "void_iterations": void_iterations, "reserved_on": reserved_on, "window": m1, "clip_windows": clip_windows}
     out = reduce_and_report(local, dist, red_dev, rank, world, args, backend)
     if out is not None:
         if world == 1 and not args.no_clip and not args.no_coresident:

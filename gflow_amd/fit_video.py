@@ -161,6 +161,34 @@ def select_traj_seeds(tr, traj_num, traj_offset):
     return sp_still.tolist(), None
 
 
+def begin_frame(tr, frames, i, load_extr=True):
+    """What the frame loop does before frame i >= 1 is fitted (fit_video.py:242-253): the new targets, the flow from frame
+    i - 1 to i, the frame's camera pose if the sequence carries one."""
+    fr = frames[i]
+    tr.set_gt_image(fr["image"])
+    tr.set_gt_depth(fr["depth"])
+    tr.set_gt_flow(frames[i - 1]["flow"])                # flow from frame i-1 to i (fit_video.py:250)
+    if load_extr and fr.get("extr") is not None:
+        tr.load_camera(extr=fr["extr"])                  # fit_video.py:252-253
+
+
+def stage_kwargs(c, frames, i, stage):
+    """The keyword arguments of frame i's (>= 1) two ``train`` calls -- ``stage`` "camera": the camera-only stage
+    (fit_video.py:256-278), "joint": splats and nothing else (:288-315) -- without the per-call ones (snapshot interval,
+    loss weights every call shares).  One place, because bench.py pins its mid-clip step windows on exactly these stages."""
+    fr = frames[i]
+    if stage == "camera":
+        return dict(iterations=c["iterations_camera"], lr_camera=c["lr_camera_after"], lambda_var=0.0, lambda_still=0.0,
+                    lambda_flow=c["lambda_flow"], densify_interval=c["densify_interval"], densify_times=c["densify_times"],
+                    camera_only=True, move_mask=fr["move_mask"])
+    if stage == "joint":
+        return dict(iterations=c["iterations_after"], lr=c["lr_after"], lr_camera=0.0, lambda_var=c["lambda_var"],
+                    lambda_still=c["lambda_still"], lambda_flow=c["lambda_flow"], densify_interval=c["densify_interval_after"],
+                    densify_times=c["densify_times_after"], mask=fr.get("occ_mask"), mask_count=fr.get("occ_count"),
+                    move_mask=fr["move_mask"])
+    raise ValueError(stage)
+
+
 def fit_clip(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, log=None, load_extr=True, keep=None,
              async_snapshots=None):
     """Fit one clip; returns the metrics dict of this clip (PSNR summed over its frames; with ``cfg["traj_num"]`` > 0 also
@@ -277,22 +305,11 @@ def fit_clip_steps(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=
     if log:
         log(f"frame 0: psnr {float(psnr_sum):.2f} dB, splats {tr.current_pts_num()}")
     for i, fr in enumerate(frames[1:], start=1):
-        tr.set_gt_image(fr["image"])
-        tr.set_gt_depth(fr["depth"])
-        tr.set_gt_flow(frames[i - 1]["flow"])            # flow from frame i-1 to i (fit_video.py:250)
-        if load_extr and fr.get("extr") is not None:
-            tr.load_camera(extr=fr["extr"])              # fit_video.py:252-253
+        begin_frame(tr, frames, i, load_extr)
         if c["camera_first"]:                            # fit_video.py:256-278
-            yield from tr.train_steps(iterations=c["iterations_camera"], lr_camera=c["lr_camera_after"], lambda_var=0.0,
-                                      lambda_still=0.0, lambda_flow=c["lambda_flow"],
-                                      densify_interval=c["densify_interval"], densify_times=c["densify_times"],
-                                      camera_only=True, move_mask=fr["move_mask"], **common)
+            yield from tr.train_steps(**stage_kwargs(c, frames, i, "camera"), **common)
         if c["iterations_after"] > 0:                    # fit_video.py:288-315
-            yield from tr.train_steps(iterations=c["iterations_after"], lr=c["lr_after"], lr_camera=0.0,
-                                      lambda_var=c["lambda_var"], lambda_still=c["lambda_still"],
-                                      lambda_flow=c["lambda_flow"], densify_interval=c["densify_interval_after"],
-                                      densify_times=c["densify_times_after"], mask=fr.get("occ_mask"),
-                                      mask_count=fr.get("occ_count"), move_mask=fr["move_mask"], **common)
+            yield from tr.train_steps(**stage_kwargs(c, frames, i, "joint"), **common)
         if traj:
             record_trajectories()
         p = tr.psnr()

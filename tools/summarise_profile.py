@@ -2,10 +2,11 @@
 per-kernel average duration (kernel-trace) and HBM bytes per launch (FETCH_SIZE and
 WRITE_SIZE passes; FETCH_SIZE doubled, the gfx950 correction of MI355X_MICROARCH.md 'HBM'), the SQ issue counters.
 
-Every figure is an average over the launches of bench.py's PINNED WINDOW only -- the last WINDOW_LAUNCHES dispatches of
-each kernel: with the driver's flags (--steps 20 --warmup 5 --no-stage-pass) bench.py runs the fit's first 12 iterations,
-7 warm-up steps, and then the window [12, 32) twice (the timed pass and the pass that reads the pair counts) --, so the
-counters belong to the workload the bench line is timed on.  The whole-run --stats table is kept beside it.
+Every figure is an average over the launches of ONE of bench.py's three PINNED WINDOWS (first_frame / camera / joint: one
+directory of passes each, bench.py --only-window) -- the last WINDOW_LAUNCHES dispatches of each kernel: with the driver's
+flags (--steps 20 --warmup 5 --no-stage-pass --repeats 0) bench.py runs up to the window, 27 warm-up steps, and then the
+window twice (the timed pass and the pass that reads the pair counts) --, so the counters belong to the workload the bench
+line is timed on.  The whole-run --stats table is kept beside it.
 
     python tools/summarise_profile.py gpurun_out/<tag>  > gpurun_out/<tag>_summary.json
 """
@@ -87,12 +88,42 @@ def counter_avg(root, counter, last=WINDOW_LAUNCHES):
     return out
 
 
-def main():
-    root = sys.argv[1]
+def full_names(root, last=WINDOW_LAUNCHES):
+    """the template instantiations among the last ``last`` dispatches of every (folded) kernel name"""
+    path = find(root, "*kernel_trace.csv")
+    per = defaultdict(list)
+    if path:
+        for r in csv.DictReader(open(path)):
+            nm = r["Kernel_Name"].split("(")[0].replace("gfl::", "").replace("void ", "").strip()
+            per[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), nm))
+    return {k: sorted({n for _, n in sorted(v)[-last:]}) for k, v in per.items()}
+
+
+def bench_line(root):
+    """the JSON line bench.py printed under the trace pass (its `work` blocks: units and lane efficiency per window)"""
+    path = os.path.join(root, "bench_trace.log")
+    if not os.path.exists(path):
+        return None
+    for line in open(path, errors="replace"):
+        line = line.strip()
+        if line.startswith("{") and '"metric"' in line:
+            try:
+                return json.loads(line)
+            except ValueError:
+                pass
+    return None
+
+
+WORK_KEY = {"first_frame": lambda d: d["config"]["step_window"].get("work"), "camera": lambda d: (d.get("step_window_camera") or {}).get("work"),
+            "joint": lambda d: (d.get("step_window_clip") or {}).get("work")}
+
+
+def one_window(root, name):
     whole_run = kernel_stats(os.path.join(root, "trace"))
     stats = window_durations(os.path.join(root, "trace"))
     for k, v in stats.items():
         v["pct"] = whole_run.get(k, {}).get("pct", 0.0)
+    inst = full_names(os.path.join(root, "trace"))
     fetch = counter_avg(os.path.join(root, "fetch"), "FETCH_SIZE")
     write = counter_avg(os.path.join(root, "write"), "WRITE_SIZE")
     # FETCH_SIZE / WRITE_SIZE are reported in KB
@@ -102,7 +133,7 @@ def main():
             continue
         rd = 2.0 * 1024.0 * fetch.get(k, 0.0)
         wr = 1024.0 * write.get(k, 0.0)
-        kernels[k] = dict(s, hbm_read_bytes=rd, hbm_write_bytes=wr, hbm_bytes=rd + wr,
+        kernels[k] = dict(s, instantiations=inst.get(k), hbm_read_bytes=rd, hbm_write_bytes=wr, hbm_bytes=rd + wr,
                           hbm_GBps=(rd + wr) / (s["avg_us"] * 1e-6) / 1e9)
         stage_bytes[STAGE_OF[k]] += rd + wr
     sq = {}
@@ -111,7 +142,6 @@ def main():
         for k, v in counter_avg(os.path.join(root, "sq"), c).items():
             if k in STAGE_OF:
                 sq.setdefault(k, {})[c] = v
-    clip = {k: v for k, v in kernel_stats(os.path.join(root, "clip")).items() if k in STAGE_OF or "blend" in k}
     # the issue bound of every stage: how busy the VALUs were.  SQ_ACTIVE_INST_VALU counts quad-cycles summed over the
     # chip's 1024 SIMDs; GRBM_GUI_ACTIVE cycles summed over the 8 XCDs.
     valu = {}
@@ -124,25 +154,42 @@ def main():
             e["avail_cycles"] += 1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0
     for e in valu.values():
         e["busy_frac"] = e.pop("busy_cycles") / e.pop("avail_cycles")
-    lane = None
-    lane_path = os.path.join(root, "lane_efficiency.json")
-    if os.path.exists(lane_path):
-        lane = json.load(open(lane_path))
-        for st in ("blend_fwd", "blend_bwd"):
-            if st in valu and st in lane:
-                valu[st]["lane_efficiency"] = lane[st]
+    work = None
+    line = bench_line(root)
+    if line:
+        try:
+            work = WORK_KEY[name](line)
+        except (KeyError, TypeError):
+            work = None
+    if work and "lane_efficiency_fwd" in work:
+        if "blend_fwd" in valu:
+            valu["blend_fwd"]["lane_efficiency"] = work["lane_efficiency_fwd"]
+            valu["blend_fwd"]["insts_per_unit"] = valu["blend_fwd"]["insts_per_launch"] / max(work["units_8x8_fwd"], 1)
+        if "blend_bwd" in valu:
+            valu["blend_bwd"]["lane_efficiency"] = work["lane_efficiency_bwd"]
+            valu["blend_bwd"]["insts_per_unit"] = valu["blend_bwd"]["insts_per_launch"] / max(work["units_8x8_bwd"], 1)
+    return {"kernels": kernels, "instantiations": {STAGE_OF[k]: v for k, v in inst.items() if k in STAGE_OF},
+            "whole_run_stats": {k: v for k, v in whole_run.items() if k in STAGE_OF},
+            "hbm_bytes_per_launch": dict(stage_bytes), "valu": valu, "work": work, "sq_counters_per_launch": sq,
+            "iteration_us": sum(v["avg_us"] for k, v in kernels.items()
+                                if not (name != "first_frame" and k in ("fused_preprocess_fwd_kernel", "bin_colscan_kernel", "fused_scatter_kernel"))),
+            "iteration_us_note": "sum of the kernels' window averages; the three exact-path binning kernels run once per 20 "
+                                 "iterations of a window and are left out of the clip windows' sum"}
+
+
+def main():
+    root = sys.argv[1]
+    windows = {w: one_window(os.path.join(root, w), w) for w in ("first_frame", "camera", "joint")
+               if os.path.isdir(os.path.join(root, w))}
+    clip = {k: v for k, v in kernel_stats(os.path.join(root, "clip")).items() if k in STAGE_OF or "blend" in k}
     print(json.dumps({
         "tag": os.path.basename(os.path.normpath(root)),
-        "command": "python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-stage-pass --no-clip  (the driver's flags)",
+        "command": "python bench.py --steps 20 --warmup 5 --no-stage-pass --repeats 0 --only-window <first_frame|camera|joint>  "
+                   "(the driver's flags; one pinned window per set of passes)",
         "method": "rocprofv3 --kernel-trace --stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE; --pmc SQ_* (separate runs); "
                   "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B), both counters in KB; every figure averaged over "
-                  f"the last {WINDOW_LAUNCHES} launches of the kernel = two passes over bench.py's pinned window",
-        "kernels": kernels,
-        "whole_run_stats": {k: v for k, v in whole_run.items() if k in STAGE_OF},
-        "hbm_bytes_per_launch": dict(stage_bytes),
-        "valu": valu,
-        "lane_efficiency": lane,
-        "sq_counters_per_launch": sq,
+                  f"the last {WINDOW_LAUNCHES} launches of the kernel = two passes over that pinned window of bench.py",
+        "windows": windows,
         "sq_note": "SQ_* summed over the chip per launch; SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES / SQ_WAIT_INST_ANY count "
                    "quad-cycles, GRBM_GUI_ACTIVE cycles summed over the 8 XCDs (MI355X_MICROARCH.md)",
         "clip_fit_kernels": clip,
