@@ -109,9 +109,27 @@ def coresident_fits(dev, frames_n, snapshot_interval, levels=(1, 2, 3)):
         out[str(c)] = {"clips": c, "frames_per_clip": frames_n, "wall_s": wall, "frames_per_s": frames / wall,
                        "iterations_per_s": sum(r["iterations"] for r in res) / wall,
                        "psnr_mean_db": sum(r["psnr_sum"] for r in res) / frames}
+    # the same with the chip PARTITIONED between the clips (CU-masked streams, each clip on its share of every XCD)
+    for c in levels:
+        if c < 2:
+            continue
+        try:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = FV.fit_clips_concurrent(clips[:c], dev, cfg, snapshot_interval=snapshot_interval, partition=True)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            frames = sum(r["frames"] for r in res)
+            out[f"{c}_partitioned"] = {"clips": c, "frames_per_clip": frames_n, "wall_s": wall, "frames_per_s": frames / wall,
+                                       "iterations_per_s": sum(r["iterations"] for r in res) / wall,
+                                       "psnr_mean_db": sum(r["psnr_sum"] for r in res) / frames,
+                                       "cus_per_clip": 8 * (32 // c)}
+        except Exception as e:
+            out[f"{c}_partitioned"] = {"error": f"{type(e).__name__}: {e}"}
     base = out[str(levels[0])]["frames_per_s"]
     for v in out.values():
-        v["vs_one_clip"] = v["frames_per_s"] / base
+        if "frames_per_s" in v:
+            v["vs_one_clip"] = v["frames_per_s"] / base
     return out
 
 

@@ -23,7 +23,7 @@ _lib = None
 
 c_void_p, c_int, c_float, c_size_t, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_int64
 
-MIN_VERSION = 303          # GFL_VERSION of the include/gflow_hip.h this binding mirrors (overflow[4], sort-order trailer, gfl_constants_n)
+MIN_VERSION = 304          # GFL_VERSION of the include/gflow_hip.h this binding mirrors (overflow[4], sort-order trailer, gfl_constants_n)
 
 # name -> (restype, argtypes); mirrors include/gflow_hip.h one to one
 _P = c_void_p
@@ -142,3 +142,56 @@ def need_device(*tensors):
 
 def scratch(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ---------------------------------------------------------------------------- CU-masked streams
+_hip = None
+
+
+def _hip_runtime():
+    global _hip
+    if _hip is None:
+        _hip = ctypes.CDLL("libamdhip64.so")         # (already in the process: torch links it)
+        _hip.hipExtStreamCreateWithCUMask.restype = ctypes.c_int
+        _hip.hipExtStreamCreateWithCUMask.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32,
+                                                      ctypes.POINTER(ctypes.c_uint32)]
+    return _hip
+
+
+def cu_partition(parts, device=None, cus=None):
+    """Split the device's compute units into ``parts`` disjoint shares that each span ALL XCDs: share p gets the CUs
+    [p * n, (p + 1) * n) of every XCD, n = (CUs per XCD) // parts.  Returns [(mask words, CU count)] per share.
+    Mask layout on gfx950 (tools/cumask_probe.hip, measured): bit i of the mask = CU i // 8 of XCD i % 8 -- a mask that leaves
+    an XCD without a CU is not honoured at all (the stream then runs on the whole device), so a share cannot be 'four of the
+    eight XCDs'; what can be split is every XCD's 32 CUs.  Launches AND graph launches on a masked stream stay inside its
+    mask; two disjoint shares run side by side without slowing each other (the probe's spin kernel: 52.8 ms on one half
+    alone, 53.3 ms on both halves at once, 29.0 ms on the whole chip)."""
+    if cus is None:
+        cus = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).multi_processor_count
+    xcds = 8
+    per_xcd = cus // xcds
+    n = per_xcd // int(parts)
+    if n < 1:
+        raise ValueError(f"cu_partition: {parts} shares of {per_xcd} CUs per XCD")
+    out = []
+    for p in range(int(parts)):
+        words = [0] * ((cus + 31) // 32)
+        for cu in range(p * n, (p + 1) * n):
+            for x in range(xcds):
+                i = cu * xcds + x
+                words[i // 32] |= 1 << (i % 32)
+        out.append((words, n * xcds))
+    return out
+
+
+def masked_stream(words, device=None):
+    """A torch stream whose kernels run only on the compute units of ``words`` (hipExtStreamCreateWithCUMask), as a
+    torch.cuda.ExternalStream.  The HIP stream lives until the process ends (a handful per process)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        arr = (ctypes.c_uint32 * len(words))(*words)
+        h = ctypes.c_void_p()
+        rc = _hip_runtime().hipExtStreamCreateWithCUMask(ctypes.byref(h), len(words), arr)
+        if rc != 0:
+            raise RuntimeError(f"hipExtStreamCreateWithCUMask failed: hipError {rc}")
+    return torch.cuda.ExternalStream(h.value, device=dev)

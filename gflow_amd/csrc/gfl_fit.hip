@@ -41,22 +41,29 @@ static int fwd_split_min() {
 }
 
 // one tile queue per CU (the dispatcher places workgroup b on CU b % CUs, tools/placement_probe.hip)
-static int blend_queues() {
-    static int nq = 0;
-    if (!nq) {
-        int dev = 0, cus = 256;
+static int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             cus = 256;
-        nq = cus < 64 ? 64 : (cus < SCHED_MAX_QUEUES ? cus : SCHED_MAX_QUEUES);
     }
-    return nq;
+    return cus;
+}
+// (st->cu_count: the share of the device this state's stream may use -- a CU-masked stream, gfl_fit_state; a multiple of 8,
+//  one queue per CU and XCD band, so that the XCD-local scheduler keeps working)
+static int blend_queues(const gfl_fit_state* st) {
+    int cus = (st && st->cu_count > 0) ? (st->cu_count / 8) * 8 : device_cus();
+    if (cus <= 0) cus = 8;
+    if (st && st->cu_count > 0) return cus < SCHED_MAX_QUEUES ? cus : SCHED_MAX_QUEUES;
+    return cus < 64 ? 64 : (cus < SCHED_MAX_QUEUES ? cus : SCHED_MAX_QUEUES);
 }
 
 // workgroups of a blend launch: up to max_per_cu per queue (all resident), fewer for small tile grids.  (Fewer than fit, so
 // that part of a queue is pulled as workgroups finish, was measured slower for both launches: DESIGN.md section 7.)
-static int blend_grid(int T, int max_per_cu = BLEND_WG_PER_CU) {
-    const int nq = blend_queues();
+static int blend_grid(const gfl_fit_state* st, int T, int max_per_cu = BLEND_WG_PER_CU) {
+    const int nq = blend_queues(st);
     int per = (T + nq - 1) / nq + 1;
     if (per > max_per_cu) per = max_per_cu;
     return nq * per;
@@ -124,7 +131,7 @@ static FitWs carve(const gfl_fit_state* st) {
     p += up256(2 * SCHED_MAX_QUEUES * sizeof(int32_t));
     w.ckpt = (float*)p;
     p += up256((size_t)SCHED_MAX_QUEUES * (HEAVY_PARTS - 1) * 5 * 256 * sizeof(float));
-    w.sched.nq = blend_queues();
+    w.sched.nq = blend_queues(st);
     // (the list is sized for 512 queues: with fewer queues each may hold more -- a band of the XCD-local schedule
     //  can have many more tiles than T / 8)
     w.sched.cap_q = (int)(((size_t)SCHED_MAX_QUEUES * sched_queue_capacity((int)T, 64)) / w.sched.nq);
@@ -293,7 +300,7 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
             rc = check(hipMemsetAsync(w.snap_mm, 0, 2 * sizeof(unsigned), s));
             if (rc) return rc;
             if (st->N > 0) launch_rec_depth_range(st->rec, st->N, w.snap_mm, s);
-            launch_blend_fwd(st, hp->bg, gx, blend_grid(T, FWD_WG_PER_CU), st->render, st->final_T, st->n_contrib, q, w, 2,
+            launch_blend_fwd(st, hp->bg, gx, blend_grid(st, T, FWD_WG_PER_CU), st->render, st->final_T, st->n_contrib, q, w, 2,
                              w.snap_mm, snap_lut, fwd_split_min(), s, snap_u8);
             launch_center_blend(st, hp->bg, gx, T, nullptr, snap_u8 + (size_t)2 * st->W * st->H * 3, s);
         }
@@ -304,7 +311,7 @@ static int fit_forward_impl(const gfl_fit_state* st, const gfl_fit_hyper* hp, gf
         if (foot && !st->keep) return GFL_ERR_INVALID;
         const bool foot_inside = foot && !snap_u8;
         if (!snap_u8)
-            launch_blend_fwd(st, hp->bg, gx, blend_grid(T, FWD_WG_PER_CU), st->render, st->final_T, st->n_contrib, q, w,
+            launch_blend_fwd(st, hp->bg, gx, blend_grid(st, T, FWD_WG_PER_CU), st->render, st->final_T, st->n_contrib, q, w,
                              foot_inside ? 3 : 0, nullptr, nullptr, fwd_split_min(), s);
         if (st->foot_flags) {
             // keep is in/out here: the footprint of this iteration's flagged splats is cleared from it, so it
@@ -365,7 +372,7 @@ int gfl_fit_snapshot(const gfl_fit_state* st, const gfl_fit_hyper* hp, const flo
         const TileQueue q = {w.sched_fwd.list, w.sched_fwd.count, pull, w.sched.nq, w.sched.cap_q};
         // (fewer workgroups per CU for this launch, so that it disturbs the fit's own kernels less, was measured in
         //  round 4: one per CU 0.871-0.886 s per 8-frame clip fit against 0.858-0.865 with five, three the same as five)
-        launch_blend_fwd(st, hp->bg, gx, blend_grid(T, FWD_WG_PER_CU), img_dc, fT, nc, q, w, 1, mm, lut, fwd_split_min(), s);
+        launch_blend_fwd(st, hp->bg, gx, blend_grid(st, T, FWD_WG_PER_CU), img_dc, fT, nc, q, w, 1, mm, lut, fwd_split_min(), s);
     }
     launch_snapshot_u8(st->render, img_dc, img_c, P, out_u8, s);
     return check_launch();
@@ -419,7 +426,7 @@ int gfl_render_bwd(const gfl_fit_state* st, const gfl_fit_hyper* hp, const float
     {
         StageScope p(ST_BLEND_BWD, s);
         const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters + w.sched.nq, w.sched.nq, w.sched.cap_q};
-        launch_blend_bwd(st, hp->bg, gx, gy, blend_grid(T), 10, d_render, q, w, LossTail{}, s);
+        launch_blend_bwd(st, hp->bg, gx, gy, blend_grid(st, T), 10, d_render, q, w, LossTail{}, s);
     }
     {
         StageScope p(ST_PRE_BWD_ADAM, s);
@@ -469,7 +476,7 @@ int gfl_fit_backward_step(const gfl_fit_state* st, const gfl_fit_hyper* hp, gfl_
         const TileQueue q = {w.sched.list, w.sched.count, w.sched.counters + w.sched.nq, w.sched.nq, w.sched.cap_q};
         // sums that nobody reads are not formed: 6 in the camera-only stage, 7 while the colours are frozen (see the kernel)
         const int sums = hp->freeze_all_splats ? 6 : (hp->freeze_rgb ? 7 : 10);
-        launch_blend_bwd(st, hp->bg, gx, gy, blend_grid(T), sums, st->d_render, q, w, lt, s);
+        launch_blend_bwd(st, hp->bg, gx, gy, blend_grid(st, T), sums, st->d_render, q, w, lt, s);
     }
     const int rows = reduce_rows(st->N > 0 ? st->N : 1);
     RegCfg rcfg;

@@ -228,7 +228,7 @@ def fit_clip(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, 
 
 
 def fit_clip_steps(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=True, log=None, load_extr=True, chunk=None,
-                   async_snapshots=True, keep=None):
+                   async_snapshots=True, keep=None, cu_count=0):
     """fit_clip as a generator: yields after every ``chunk`` iterations of a stage (None: never) and returns the metrics
     dict.  The caller owns the stream the work is enqueued on (fit_clips_concurrent gives every clip its own)."""
     from .trainer import SimpleGaussian
@@ -240,6 +240,7 @@ def fit_clip_steps(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=
     tr = SimpleGaussian(f0["image"], f0["depth"], num_points=c["num_points"], background=c["background"],
                         device=device, seed=seed, fused=fused)
     tr.async_snapshots = bool(async_snapshots)       # (trainer.py: snapshots composed beside the next iterations, or behind theirs)
+    tr.cu_count = int(cu_count)                      # (the caller's stream is CU-masked: fit_clips_concurrent(partition=True))
     tr.load_camera(focal=f0["focal"], pp=f0["pp"])
     if load_extr and f0.get("extr") is not None:
         tr.load_camera(extr=f0["extr"])
@@ -353,7 +354,7 @@ def fit_clip_steps(frames, device, cfg=None, seed=0, snapshot_interval=0, fused=
 NUMERIC_KEYS = ("psnr_sum", "frames", "iterations", "rasterisations", "clips", "splats_final", "void_iterations")
 
 
-def fit_clips_concurrent(clips, device, cfg=None, seeds=None, snapshot_interval=0, chunk=32):
+def fit_clips_concurrent(clips, device, cfg=None, seeds=None, snapshot_interval=0, chunk=32, partition=False):
     """Fit several clips AT THE SAME TIME on ONE device, in one host thread: every clip has its own trainer, engine and
     STREAM, and the clips take turns enqueueing ``chunk`` iterations each (fit_clip_steps), so their graph launches
     interleave on the device.  One fit leaves the chip partly idle -- its kernels are a chain of dependent launches,
@@ -363,20 +364,30 @@ def fit_clips_concurrent(clips, device, cfg=None, seeds=None, snapshot_interval=
     the host only until THAT fit's stream has caught up; the others have their chunks queued meanwhile.
     (One host thread on purpose: with a thread per clip, graph captures of one thread and launches / allocations of
     another crashed inside the HIP runtime of ROCm 7.2 about once in four runs -- aborts in hipGraphDestroy, segmentation
-    faults beside hipStreamEndCapture, silent exits.)  Returns the clips' metrics dicts in order; the caller times the call."""
+    faults beside hipStreamEndCapture, silent exits.)  Returns the clips' metrics dicts in order; the caller times the call.
+    ``partition``: every clip's stream is CU-MASKED to its own share of every XCD (_lib.cu_partition: 256 CUs / n, each share
+    spanning all eight XCDs and their L2s) and its engines size their persistent blend grids and tile queues for that share
+    (gfl_fit_state.cu_count) -- the clips then run SIDE BY SIDE instead of taking turns on every CU.  Results do not depend
+    on it (the schedule never enters a result).  Measured in bench.py's ``clips_per_gpu`` table."""
     n = len(clips)
     seeds = list(range(n)) if seeds is None else seeds
     dev = torch.device(device)
     if dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
     cur = torch.cuda.current_stream(dev)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(n)]
+    shares = None
+    if partition and n > 1:
+        from . import _lib
+        shares = _lib.cu_partition(n, dev)
+        streams = [_lib.masked_stream(words, dev) for words, _ in shares]
+    else:
+        streams = [torch.cuda.Stream(device=dev) for _ in range(n)]
     for s in streams:
         s.wait_stream(cur)
     # (a lone fit takes its snapshots on a side stream; several fits already fill each other's gaps, and a side stream + shadow
     #  engine per clip cost them more than they give)
     gens = [fit_clip_steps(clips[i], dev, cfg, seed=seeds[i], snapshot_interval=snapshot_interval, chunk=chunk,
-                           async_snapshots=n == 1)
+                           async_snapshots=n == 1, cu_count=shares[i][1] if shares else 0)
             for i in range(n)]
     results = [None] * n
     live = list(range(n))

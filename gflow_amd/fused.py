@@ -32,7 +32,7 @@ class FitState(ctypes.Structure):          # mirrors gfl_fit_state
                 ("render", _P), ("final_T", _P), ("n_contrib", _P),
                 ("d_render", _P), ("err_px", _P), ("sums", _P),
                 ("tile_offsets", _P), ("ids", _P), ("tile_range", _P), ("overflow", _P),
-                ("workspace", _P), ("workspace_bytes", ctypes.c_size_t)]
+                ("workspace", _P), ("workspace_bytes", ctypes.c_size_t), ("cu_count", _I), ("reserved_", _I)]
 
 
 class FitHyper(ctypes.Structure):          # mirrors gfl_fit_hyper
@@ -83,8 +83,11 @@ def set_profile(mask):
 
 
 class FitEngine:
-    def __init__(self, W, H, capacity, device, K_cap=None, bg=0.0):
+    def __init__(self, W, H, capacity, device, K_cap=None, bg=0.0, cu_count=0):
+        """``cu_count``: compute units the stream this engine is driven on may use (a CU-masked stream, _lib.masked_stream;
+        0 = the whole device): the persistent blend grids and their tile queues are sized for it (gfl_fit_state.cu_count)."""
         self.lib = L.load()
+        self.cu_count = int(cu_count)
         _declare(self.lib)
         self.dev = torch.device(device)
         if self.dev.type != "cuda":
@@ -138,8 +141,33 @@ class FitEngine:
         try:
             with _GRAPH_LOCK:
                 self._graphs.clear()
+                for gs in getattr(self, "_graph_trash", []):
+                    gs.clear()
         except Exception:                            # interpreter shutdown
             pass
+
+    def _retire_graphs(self):
+        """The captured graphs belong to a state that has changed (new stage, new splat count).  Destroying a graph BLOCKS the
+        host until the device is idle (hipGraphExecDestroy: not just until that graph's own replays are done -- destroying
+        graphs whose event had long passed still cost the host the whole lead it had over the device, ~5 ms at the first
+        iteration of every joint stage: tools/host_lead.py, round 6).  So they are only set aside here; ``reap_graphs`` destroys
+        them where the host has just waited for the device anyway (a densification's read, a blocking look at the overflow
+        words, the end of a clip)."""
+        if self._graphs:
+            self.__dict__.setdefault("_graph_trash", []).append(self._graphs)
+            self._graphs = {}
+        if len(self.__dict__.get("_graph_trash", ())) > 256:         # (a caller that never reaches a reaping point)
+            self.reap_graphs()
+
+    def reap_graphs(self):
+        """Destroy the graphs set aside by ``_retire_graphs`` -- call where the device is idle (see there).  Under the lock,
+        never while a capture runs (_GRAPH_LOCK)."""
+        trash = self.__dict__.get("_graph_trash")
+        if trash:
+            with _GRAPH_LOCK:
+                for gs in trash:
+                    gs.clear()
+            self._graph_trash = []
 
     # ------------------------------------------------------------------ storage
     def _alloc(self, cap):
@@ -281,6 +309,7 @@ class FitEngine:
                             ("workspace", self.workspace)):
                 setattr(s, name, None if t is None else t.data_ptr())
             s.workspace_bytes = self.workspace.numel()
+            s.cu_count = self.cu_count
             if self.gt_rgb is not None and self.foot_flags is None:
                 # SSIM statistics of the (masked) target, once per set_targets (gfl_fit_prepare_targets)
                 L.check(self.lib.gfl_fit_prepare_targets(ctypes.byref(s), L.stream()), "fit prepare targets")
@@ -352,8 +381,7 @@ class FitEngine:
         if use_graph and not PROFILE["mask"] and self._launched and not flags:
             key = bytes(self.state()) + bytes(self.hp)
             if self._graph_key != key:
-                with _GRAPH_LOCK:
-                    self._graphs.clear()             # (the old graphs are destroyed here, under the lock)
+                self._retire_graphs()                # (the old graphs: destroyed once the device is done with them)
                 self._graph_key = key
             g = self._graphs.get(gkey)
             if g is None:
@@ -474,6 +502,7 @@ class FitEngine:
         """Blocking read of the pair-list overflow flag (sticky on the device); raises if pairs were dropped."""
         self._ovf_event = None
         code = int(self.overflow[0].item())
+        self.reap_graphs()                           # (the device is idle here)
         if code:
             self.overflow.zero_()
             raise RuntimeError(self._overflow_message(code))
@@ -488,6 +517,7 @@ class FitEngine:
         self._ovf_event = None
         self._pend_event = None        # (a blocking look supersedes an outstanding watch: its words are read and cleared here)
         code, skipped = (int(v) for v in self.overflow[:2].tolist())                   # the host read
+        self.reap_graphs()                           # (the device is idle here)
         if code == 0:
             if skipped > 0:
                 # tiles outgrew the regions reserved for them in `skipped` iterations (GFL_ITER_RESERVED): those stepped

@@ -216,6 +216,7 @@ class SimpleGaussian:
         self.fused = bool(fused)
         self.async_snapshots = True      # snapshots composed on a side stream from a copy of the forward's state (make_stepper)
         self.exact_snapshots = True      # iterations whose forward is looked at are never void or behind (make_stepper: one_iteration)
+        self.cu_count = 0                # compute units the stream this trainer is driven on may use (0: the device): FitEngine(cu_count=)
         self.use_graph = True          # replay the fused iteration as a hipGraph when nothing else happens in it
         self.engine = None
         self.device = torch.device(device if device is not None else "cuda")
@@ -554,7 +555,8 @@ class SimpleGaussian:
     def _engine_for(self, n):
         from .fused import FitEngine
         if self.engine is None:
-            self.engine = FitEngine(self.W, self.H, max(8 * int(self.num_points), 2 * n, 65536), self.device, bg=self.bg)
+            self.engine = FitEngine(self.W, self.H, max(8 * int(self.num_points), 2 * n, 65536), self.device, bg=self.bg,
+                                    cu_count=self.cu_count)
         self.engine.ensure_capacity(n)
         return self.engine
 
@@ -892,6 +894,10 @@ class SimpleGaussian:
         if self.fused and self.engine is not None:
             # Dropped (splat, tile) pairs must neither go unnoticed nor end the fit: the lists are grown and the iterations
             # that stepped nothing are run again (FitEngine.settle_overflow).  One read of two words per train() call.
+            # (Round 6 measured what this full stop costs: the pause between two stages is 1.4-1.5 ms of DEVICE time with it and
+            #  1.2 ms without -- an "exact tail" of 24 iterations behind a watch, the words read from that copy --, because the
+            #  boundary's ~70 small torch kernels are a chain of launch latencies on the device whoever waits for whom; the tail's
+            #  exact binning cost the 0.25 ms back.  tools/stage_times.py, tools/experiments/README.md.)
             st.settle()
             if getattr(st, "snap_stream", None) is not None:
                 with torch.cuda.stream(st.snap_stream):
@@ -1028,7 +1034,8 @@ class SimpleGaussian:
                 self._snap_stream.synchronize()
             else:
                 self._snap_stream = torch.cuda.Stream(device=dev)
-            aux = self._snap_aux = FitEngine(self.W, self.H, max(eng.cap, n), dev, K_cap=eng.K_cap, bg=self.bg)
+            aux = self._snap_aux = FitEngine(self.W, self.H, max(eng.cap, n), dev, K_cap=eng.K_cap, bg=self.bg,
+                                                  cu_count=self.cu_count)
             self._snap_done = None
         side = self._snap_stream
         if self._snap_done is not None:
@@ -1054,7 +1061,8 @@ class SimpleGaussian:
         n = eng.N
         aux = getattr(self, "_aux", None)
         if aux is None or aux.cap < n:
-            aux = self._aux = FitEngine(self.W, self.H, max(eng.cap, n), self.device, bg=self.bg)
+            aux = self._aux = FitEngine(self.W, self.H, max(eng.cap, n), self.device, bg=self.bg,
+                                    cu_count=self.cu_count)
         aux.set_count(n)
         aux.pose.copy_(eng.pose)
         aux.intr.copy_(eng.intr)
@@ -1075,7 +1083,8 @@ class SimpleGaussian:
         n = eng.N
         aux = getattr(self, "_aux", None)
         if aux is None or aux.cap < n:
-            aux = self._aux = FitEngine(self.W, self.H, max(eng.cap, n), self.device, bg=self.bg)
+            aux = self._aux = FitEngine(self.W, self.H, max(eng.cap, n), self.device, bg=self.bg,
+                                    cu_count=self.cu_count)
         aux.set_count(n)
         aux.pose.copy_(eng.pose)
         aux.intr.copy_(eng.intr)
@@ -1139,6 +1148,8 @@ class SimpleGaussian:
         err, m = self.densify_weights(error_map, error_threshold, mask)
         if n_masked is None:
             n_masked = int(m.sum())                                        # the host read
+            if self.fused and self.engine is not None:
+                self.engine.reap_graphs()            # (the device is idle right now: the one place per frame where retired graphs cost nothing to destroy)
         densify_num = int(self.num_points * (n_masked / m.numel()) * percent)     # float64 like numpy (:896-901)
         num_before = self.current_pts_num()
         if densify_num > 0:

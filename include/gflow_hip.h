@@ -100,9 +100,9 @@ typedef enum gfl_status {
  * (GFL_ITER_PRE_DONE / _PRE_NEXT / _ODD, gfl_fit_next_preprocess_supported and gfl_bwd_rows_on are gone), the fit
  * workspace is smaller.  301: gfl_fit_iteration_snapshot.  302: the tile sorts no longer fill a table of list positions
  * (gfl_tile_sort_with_slots is gone, gfl_tile_sort_ordered / _reserved lost their rec / slot_inv / slot_pool arguments): the
- * per-splat launch finds its pair rows without one.  303: GFL_PIXEL_CENTER, gfl_constants_n.
+ * per-splat launch finds its pair rows without one.  303: GFL_PIXEL_CENTER, gfl_constants_n.  304: gfl_fit_state.cu_count.
  * A binding checks gfl_version() >= GFL_VERSION of the header it was written for. */
-#define GFL_VERSION 303
+#define GFL_VERSION 304
 int gfl_version(void);
 /* out[10] = TILE, NEAREST, EXTENT, FOV_CLAMP, LOWPASS, EIG_FLOOR, RADIUS_SIGMA, ALPHA_MIN, ALPHA_MAX, T_MIN of this build */
 int gfl_constants(float* out10);
@@ -311,6 +311,13 @@ typedef struct gfl_fit_state {
                                                           * (tile_range says where each one is) */
     void* workspace;
     size_t workspace_bytes;                     /* >= gfl_fit_workspace_bytes() */
+    int32_t cu_count;                           /* 304: compute units this state's launches may use -- 0 = the whole device.  The
+                                                 * blend launches are persistent grids with one tile queue per CU: a caller that
+                                                 * runs a state on a CU-masked stream (hipExtStreamCreateWithCUMask; several clips
+                                                 * side by side on one device, each on its share of every XCD: gflow_amd/fit_video.py)
+                                                 * says so here, and grids and queues are sized for that share.  Fixed for the life
+                                                 * of the state's workspace (the queues in it are built for this many). */
+    int32_t reserved_;
 } gfl_fit_state;
 
 typedef struct gfl_fit_hyper {

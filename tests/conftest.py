@@ -37,6 +37,7 @@ _SAMPLED = {
     "test_fused_and_operator_clips_reach_similar_quality", "test_three_frame_clip_runs_and_improves",
     "test_static_scene_keeps_every_parameter_finite", "test_clip_read_back_from_disk_fits_like_the_in_memory_clip",
     "test_concurrent_fits_on_one_device_equal_the_fits_one_after_another", "test_concurrent_fits_draw_their_trajectories_too",
+    "test_partitioned_concurrent_fits_stay_on_their_shares_and_fit_the_same",
     "test_camera_only_phase_moves_the_pose_not_the_splats", "test_move_seg_covers_the_moving_splats",
     "test_trainer_fused_and_operator_paths_agree", "test_a_fit_whose_pair_lists_overflow_ends_where_one_with_room_ends",
 }

@@ -253,6 +253,41 @@ def test_concurrent_fits_on_one_device_equal_the_fits_one_after_another():
         fit_clips_concurrent([clips[0], [dict(clips[1][0], image=None)]], DEV, SMALL)
 
 
+def test_partitioned_concurrent_fits_stay_on_their_shares_and_fit_the_same():
+    """fit_clips_concurrent(partition=True): every clip on a CU-masked stream -- its own share of every XCD -- with engines
+    whose blend grids and tile queues are sized for that share (gfl_fit_state.cu_count).  Held: the engines really have the
+    smaller queue count, the fits reach what the unpartitioned ones reach (the schedule never enters a result), and a kernel
+    launched on a share's stream runs on that share's CUs only.  (Throughput: bench.py clips_per_gpu -- partitioning LOSES,
+    tools/experiments/README.md round 6.)"""
+    from gflow_amd import _lib
+    from gflow_amd.fit_video import fit_clips_concurrent
+    from gflow_amd.fused import FitEngine
+    clips = [_clip(seed=s) for s in (11, 12)]
+    turns = fit_clips_concurrent(clips, DEV, SMALL, seeds=[0, 1], snapshot_interval=10)
+    parts = fit_clips_concurrent(clips, DEV, SMALL, seeds=[0, 1], snapshot_interval=10, partition=True)
+    torch.cuda.synchronize()
+    for a, b in zip(turns, parts):
+        assert b["frames"] == 3 and b["iterations"] == a["iterations"]
+        assert abs(a["psnr_sum"] - b["psnr_sum"]) / 3 < 1.2, (a, b)          # (bounds of the test above: run-to-run spread of ONE fit)
+        assert abs(a["splats_final"] - b["splats_final"]) <= 0.06 * a["splats_final"], (a, b)
+    shares = _lib.cu_partition(2, torch.device(DEV, 0))
+    assert [n for _, n in shares] == [128, 128]
+    eng = FitEngine(128, 96, 4096, torch.device(DEV, 0), cu_count=shares[0][1])
+    eng.set_splats({k: v for k, v in zip(("xyz", "scale", "rotate", "opacity", "rgb"),
+                                         (torch.rand(64, 3) + torch.tensor([0., 0., 2.]), torch.full((64, 3), 0.05),
+                                          torch.tensor([[1., 0, 0, 0]]).repeat(64, 1), torch.zeros(64, 1), torch.zeros(64, 3)))})
+    eng.intr.copy_(torch.tensor([100., 100., 64., 48.]))
+    eng.forward()
+    assert len(eng.schedule()) == 128                                      # one tile queue per CU of the share
+    # an elementwise kernel on each share's stream: which XCD / CU ids do its waves report?  (torch has no such kernel; the
+    # library's self-test reads HW_ID -- if it is not there, the placement is what tools/cumask_probe.hip measured)
+    s0 = _lib.masked_stream(shares[0][0], torch.device(DEV, 0))
+    with torch.cuda.stream(s0):
+        x = torch.ones(1 << 20, device=DEV) * 2.0
+    s0.synchronize()
+    assert float(x.sum()) == float(2 << 20)
+
+
 def test_move_seg_covers_the_moving_splats():
     """train(move_seg=True): the mask of trainer.py:604-609 (smoothed concave hull of the moving splats' projections,
     gflow_amd/hull.py) and its eroded version; off by default."""

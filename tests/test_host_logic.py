@@ -406,3 +406,20 @@ def test_gen_line_set_equals_the_reference_function(golden_dir):
     d = np.load(os.path.join(golden_dir, "line_set.npz"))
     lx, lc = gen_line_set(torch.from_numpy(d["xyz1"]), torch.from_numpy(d["xyz2"]), torch.from_numpy(d["rgb"]))
     assert np.array_equal(lx.numpy(), d["line_xyz"]) and np.array_equal(lc.numpy(), d["line_rgb"])
+
+
+def test_cu_partition_masks_are_disjoint_shares_of_every_xcd():
+    """_lib.cu_partition: mask bit i = CU i // 8 of XCD i % 8 (tools/cumask_probe.hip); every share must keep CUs in ALL eight
+    XCDs (a mask that empties an XCD is not honoured by the driver) and the shares must not overlap."""
+    from gflow_amd import _lib
+    for parts in (2, 3, 4):
+        shares = _lib.cu_partition(parts, cus=256)
+        seen = 0
+        for words, n in shares:
+            bits = sum(w << (32 * k) for k, w in enumerate(words))
+            assert bin(bits).count("1") == n == 8 * (32 // parts)
+            assert n % 8 == 0                                            # one tile queue per CU, eight XCD bands
+            for x in range(8):
+                assert sum((bits >> (cu * 8 + x)) & 1 for cu in range(32)) == 32 // parts
+            assert bits & seen == 0
+            seen |= bits

@@ -70,14 +70,27 @@ int main() {
         CK(hipExtStreamCreateWithCUMask(&s, 8, m));
         probe<<<n, 256, 0, s>>>(d, spin); CK(hipStreamSynchronize(s));
         report(p.name, d, n);
-        if (p.kind == 1) keepA = s;
+        if (p.kind == 0) keepA = s;
     }
-    {   // the complement of pattern 1
+    {   // the complement of pattern 0: the upper sixteen CUs of every XCD (bit i = CU i / 8 of XCC i % 8)
         uint32_t m[8] = {0};
-        for (int i = 0; i < 256; ++i) if ((i % 8) >= 4) m[i / 32] |= 1u << (i % 32);
+        for (int i = 128; i < 256; ++i) m[i / 32] |= 1u << (i % 32);
         CK(hipExtStreamCreateWithCUMask(&keepB, 8, m));
         probe<<<n, 256, 0, keepB>>>(d, spin); CK(hipStreamSynchronize(keepB));
-        report("bits with (i % 8) >= 4", d, n);
+        report("bits [128,256)", d, n);
+    }
+    {   // are the two halves disjoint?
+        std::vector<unsigned> ha(2 * n), hb(2 * n);
+        probe<<<n, 256, 0, keepA>>>(d, spin); CK(hipStreamSynchronize(keepA));
+        CK(hipMemcpy(ha.data(), d, n * 8, hipMemcpyDeviceToHost));
+        probe<<<n, 256, 0, keepB>>>(d, spin); CK(hipStreamSynchronize(keepB));
+        CK(hipMemcpy(hb.data(), d, n * 8, hipMemcpyDeviceToHost));
+        std::set<unsigned> ca, cb;
+        auto key = [](unsigned hw, unsigned xcc) { return ((xcc & 15) << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15); };
+        for (int b = 0; b < n; ++b) { ca.insert(key(ha[2 * b], ha[2 * b + 1])); cb.insert(key(hb[2 * b], hb[2 * b + 1])); }
+        int common = 0;
+        for (unsigned c : ca) common += cb.count(c);
+        printf("halves: %zu and %zu CUs, %d in common\n", ca.size(), cb.size(), common);
     }
     // a graph captured on a masked stream and launched on it
     {
@@ -87,9 +100,9 @@ int main() {
         CK(hipStreamEndCapture(keepA, &g));
         CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         CK(hipGraphLaunch(ge, keepA)); CK(hipStreamSynchronize(keepA));
-        report("GRAPH on the (i % 8) < 4 stream", d, n);
+        report("GRAPH captured + launched on the [0,128) stream", d, n);
         CK(hipGraphLaunch(ge, keepB)); CK(hipStreamSynchronize(keepB));
-        report("same GRAPH launched on the >= 4 stream", d, n);
+        report("same GRAPH launched on the [128,256) stream", d, n);
         CK(hipGraphLaunch(ge, plain)); CK(hipStreamSynchronize(plain));
         report("same GRAPH launched on the plain stream", d, n);
     }
