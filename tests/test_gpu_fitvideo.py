@@ -504,7 +504,13 @@ def test_bench_with_two_ranks_on_this_box():
     assert c["iterations"] == 2 * (500 + 150 + 300)
     assert abs(d["value"] - 4 / c["wall_s"]) < 1e-6 * d["value"]         # frames of ALL ranks / the slowest rank's time
     # (the dominant kernel by the library's events: blend_bwd on a GPU of its own; two ranks sharing one delay each other's)
-    assert d["roofline"] and d["roofline"]["kernel"] in d["kernels"] and 0 < d["roofline"]["frac"] < 1
+    # round 6: `roofline` describes the dominant kernel of the CLIP's iterations (the joint-stage window), the first-frame
+    # window's block stays beside it
+    first = d["roofline_first_frame_window"]
+    assert first and first["kernel"] in d["kernels"] and 0 < first["frac"] < 1
+    assert d["roofline"] and d["roofline"]["kernel"].startswith("fused_blend_") and 0 < d["roofline"]["frac"] < 1
+    for w in ("step_window_camera", "step_window_clip"):
+        assert d[w]["ms_per_step"] > 0 and d[w]["splats"] >= 60000 and d[w]["work"]["units_8x8_bwd"] > 0, d[w]
     assert d["ms_per_step"] > 0 and "cpu_baseline" not in d
 
 
