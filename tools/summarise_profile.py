@@ -171,10 +171,15 @@ def one_window(root, name):
     return {"kernels": kernels, "instantiations": {STAGE_OF[k]: v for k, v in inst.items() if k in STAGE_OF},
             "whole_run_stats": {k: v for k, v in whole_run.items() if k in STAGE_OF},
             "hbm_bytes_per_launch": dict(stage_bytes), "valu": valu, "work": work, "sq_counters_per_launch": sq,
+            # (the three exact-path binning kernels run once per 20 iterations of a window -- the last 40 launches of each reach
+            #  back in front of it -- and the camera launch does not run in the first-frame and joint windows at all: its last
+            #  launches there are the camera-only stage's)
             "iteration_us": sum(v["avg_us"] for k, v in kernels.items()
-                                if not (name != "first_frame" and k in ("fused_preprocess_fwd_kernel", "bin_colscan_kernel", "fused_scatter_kernel"))),
-            "iteration_us_note": "sum of the kernels' window averages; the three exact-path binning kernels run once per 20 "
-                                 "iterations of a window and are left out of the clip windows' sum"}
+                                if k not in ("fused_preprocess_fwd_kernel", "bin_colscan_kernel", "fused_scatter_kernel")
+                                and not (name != "camera" and k == "fused_camera_adam_kernel")),
+            "iteration_us_note": "sum of the window averages of the kernels of an iteration on reserved tile regions (19 of the "
+                                 "window's 20): preprocess_bin, tile sort, forward, the loss pair, backward, per-splat + Adam"
+                                 + (", camera Adam" if name == "camera" else "")}
 
 
 def main():
