@@ -486,6 +486,7 @@ def reduce_and_report(local, dist, red_dev, rank, world, args, backend, size=Non
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1000.0,
+        "timed_region_s": wall,                      # the K timed steps of the first-frame window: max over ranks
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

@@ -415,6 +415,33 @@ def test_a_fit_whose_pair_lists_overflow_ends_where_one_with_room_ends():
     assert abs(n_a - n_b) <= 3 and abs(p_a - p_b) < 1.0, out
 
 
+def test_no_watch_of_one_stage_is_read_by_the_next():
+    """with snapshots every 10th iteration the LAST iteration of a stage stands 'in front of a looked-at one'
+    (index ``iterations``, which is never run); a watch of the overflow words queued there was read by the next stage's first
+    iteration -- after the end-of-stage look had already made up for the same void iterations: they were made up twice, under
+    the next stage's hyper-parameters.  Now no watch is queued there, and a new stage drops any watch it finds."""
+    from gflow_amd import synthetic as S
+    from gflow_amd.trainer import SimpleGaussian
+    f = S.make_clip(2, 96, 128, seed=3)
+    tr = SimpleGaussian(f[0]["image"], f[0]["depth"], num_points=2500, device=DEV, seed=0)
+    tr.load_camera(focal=f[0]["focal"], pp=f[0]["pp"])
+    tr.init_gaussians_from_image(f[0]["image"], f[0]["depth"], num_points=2500)
+    kw = dict(lr=4e-3, lambda_rgb=1.0, lambda_depth=1e-2, lambda_var=1.0, move_mask=f[0]["move_mask"], snapshot_interval=10,
+              render_parts=False, densify_interval=0)
+    tr.train(iterations=30, **kw)                     # 29 is plain, 30 would be looked at
+    eng = tr.engine
+    assert getattr(eng, "_pend_event", None) is None and eng.read_pending() is None
+    steps = int(eng.step.item())
+    assert steps == 30
+    # a watch somebody left behind (the old behaviour) must not reach the next stage's accounting
+    eng.overflow[1:2].fill_(3)                        # "three iterations stepped nothing" ...
+    eng.watch_pending()
+    eng.overflow[1:2].zero_()                         # ... and were made up for by the look at the end of the stage
+    tr.train(iterations=20, **kw)
+    assert int(eng.step.item()) == 20                 # (a fresh optimiser per train(): exactly its own 20 steps, not 23)
+    assert getattr(eng, "regions_outgrown", 0) == 0
+
+
 def test_a_snapshot_behind_a_void_iteration_shows_the_splats_of_its_own_iteration(monkeypatch):
     """A tile outgrows its reserved region in a plain iteration right before a snapshot iteration (the host moves a third of the
     splats onto one spot, the recipe of test_a_tile_that_outgrows_its_reserved_region_voids_that_iteration_only): that iteration
