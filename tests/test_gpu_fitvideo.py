@@ -434,12 +434,14 @@ def test_no_watch_of_one_stage_is_read_by_the_next():
     steps = int(eng.step.item())
     assert steps == 30
     # a watch somebody left behind (the old behaviour) must not reach the next stage's accounting
-    eng.overflow[1:2].fill_(3)                        # "three iterations stepped nothing" ...
+    r0 = getattr(eng, "regions_outgrown", 0)
+    eng.overflow[1:2].fill_(50)                       # "fifty iterations stepped nothing" ...
     eng.watch_pending()
     eng.overflow[1:2].zero_()                         # ... and were made up for by the look at the end of the stage
+    tr.set_gt_flow(torch.zeros_like(f[0]["flow"]))    # (a second fit of the same frame: nothing moves)
     tr.train(iterations=20, **kw)
-    assert int(eng.step.item()) == 20                 # (a fresh optimiser per train(): exactly its own 20 steps, not 23)
-    assert getattr(eng, "regions_outgrown", 0) == 0
+    assert int(eng.step.item()) == 20                 # (a fresh optimiser per train(): exactly its own 20 steps, not 70)
+    assert getattr(eng, "regions_outgrown", 0) - r0 < 50      # (the first steps of a small fit may be void by themselves: a few)
 
 
 def test_a_snapshot_behind_a_void_iteration_shows_the_splats_of_its_own_iteration(monkeypatch):
