@@ -61,7 +61,7 @@ static int blend_queues(const gfl_fit_state* st) {
 }
 
 // workgroups of a blend launch: up to max_per_cu per queue (all resident), fewer for small tile grids.  (Fewer than fit, so
-// that part of a queue is pulled as workgroups finish, was measured slower for both launches: DESIGN.md section 7.)
+// that part of a queue is pulled as workgroups finish, was measured slower for both launches: docs/history.md section 7.)
 static int blend_grid(const gfl_fit_state* st, int T, int max_per_cu = BLEND_WG_PER_CU) {
     const int nq = blend_queues(st);
     int per = (T + nq - 1) / nq + 1;

@@ -152,7 +152,7 @@ __device__ __forceinline__ bool scale_row(float u, float v, int W, int H, unsign
 // path (fused_preprocess_fwd_kernel) and the one-launch binning on reserved tile regions (fused_preprocess_bin_kernel).
 // A block: splats [blockIdx.x * BIN_BLOCK, + BIN_BLOCK) (the scatter re-walks the same blocks).
 // EWA_MFMA: the J Sigma J^T contraction on the matrix cores (cov2d_mfma, gfl_math.hpp) instead of 30 FMAs in the lane
-// -- the variant north_star names; selected with GFL_EWA_MFMA=1, measured in DESIGN.md section 4, off by default.
+// -- the variant north_star names; selected with GFL_EWA_MFMA=1, measured in DESIGN.md section 4 (docs/history.md section 4 for the full account), off by default.
 struct PreArgs {
     const float* intr; const float* pose;
     int N, W, H;

@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
     // No global atomics: the four waves of the tile combine their per-splat sums in LDS and the tile writes ONE 48-byte row per
     // (splat, tile) pair with plain stores -- round 5: not at the pair's list position (the per-splat launch then needed a table
     // of positions, written by the tile sort from a gather of the records, and gathered rows scattered over 12.7 MB: 41 MB of
-    // traffic) but at row g * SLOT_MAX + (the tile's index in the splat's own tile rectangle), which the
+    // traffic, docs/history.md section 5) but at row g * SLOT_MAX + (the tile's index in the splat's own tile rectangle), which the
     // per-splat launch computes for itself and reads as ONE contiguous run per splat.  The scattered side of the exchange is
     // now the stores of this kernel, which is bound by instruction issue and does not wait for them.  A row carries the number
     // of the forward it belongs to (FitWs.stamp) in its eleventh float: pairs nobody walks -- behind the tile's deepest

@@ -71,7 +71,11 @@ def _no_intersections(P, a_idx, b_idx, ea, eb):
 def concave_hull(points, concavity=2.0, length_threshold=0.0):
     """(n,2) points -> (m,2) ring vertices (not closed): ``concave_hull_py`` below, run by its statement-by-statement C++ twin
     in libgflow_hip.so (gfl_concave_hull, csrc/gfl_hull.hip: a host function, ~2 ms where the numpy version takes 125 for the
-    6 000 moving splats of a 480p frame); tests/test_host_logic.py holds the two against each other."""
+    6 000 moving splats of a 480p frame); tests/test_host_logic.py holds the two against each other.
+    No fallback to the numpy statement when the library is missing (ADVICE r05 asked for one): gflow_amd has ONE way of
+    computing anything -- the library --, a missing libgflow_hip.so is a build error that every entry point reports the same
+    way (_lib.load), and a mask path that silently takes another implementation on some machines is how two machines come to
+    disagree.  ``concave_hull_py`` stays importable for whoever wants the numpy statement explicitly."""
     import ctypes
     from . import _lib
     P = np.ascontiguousarray(np.unique(np.asarray(points, dtype=np.float64).reshape(-1, 2), axis=0))

@@ -710,7 +710,7 @@ class SimpleGaussian:
                 # gfl_fit_snapshot_stage -- into a shadow engine), BESIDE the next iterations instead of between them.  Inside
                 # the iteration's own graph the snapshot cost 115-140 us every tenth iteration, 4-5 % of a clip fit; two
                 # independent chains of launches share the chip well (two clips on one GPU: 1.43x), a fork inside a graph
-                # does not.
+                # does not (docs/history.md section 7).
                 # They stay on the DEVICE until the end of this train() call (a ring of uint8 images in HBM: 3.7 MB each at
                 # 480p, 50 per call) and leave for page-locked memory in ONE copy then.  A copy to the host while the
                 # iterations run holds up whatever kernel is running beside it for as long as it lasts -- 65 us, every
