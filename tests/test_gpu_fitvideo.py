@@ -537,7 +537,10 @@ def test_bench_with_two_ranks_on_this_box():
     # window's block stays beside it
     first = d["roofline_first_frame_window"]
     assert first and first["kernel"] in d["kernels"] and 0 < first["frac"] < 1
-    assert d["roofline"] and d["roofline"]["kernel"].startswith("fused_blend_") and 0 < d["roofline"]["frac"] < 1
+    # (the dominant kernel BY THE LIBRARY'S EVENTS: the backward blend on a GPU of its own; two ranks sharing one device delay
+    #  each other's launches and any of the three timed kernels can come out longest -- one run in ten it was the loss pair)
+    assert d["roofline"] and 0 < d["roofline"]["frac"] < 1
+    assert d["roofline"]["kernel"].startswith("fused_blend_") or d["roofline"]["kernel"] in ("loss", "blend_fwd", "blend_bwd")
     for w in ("step_window_camera", "step_window_clip"):
         assert d[w]["ms_per_step"] > 0 and d[w]["splats"] >= 60000 and d[w]["work"]["units_8x8_bwd"] > 0, d[w]
     assert d["ms_per_step"] > 0 and "cpu_baseline" not in d

@@ -27,6 +27,9 @@ def unit_stats(eng, chunk=16384):
     ncontrib = eng.n_contrib.long()
     yy, xx = torch.meshgrid(torch.arange(16, device=dev), torch.arange(16, device=dev), indexing="ij")
     tot = dict(valid=0, live=0, u_fwd=0, u_bwd=0)
+    edges = torch.tensor([0, 1, 2, 4, 8, 16, 32, 64], device=dev)          # buckets (0,1], (1,2], (2,4], ... (32,64] lanes of a unit
+    h_fwd = torch.zeros(7, dtype=torch.long, device=dev)
+    h_bwd = torch.zeros(7, dtype=torch.long, device=dev)
     for s in range(0, K, chunk):
         sl = slice(s, min(K, s + chunk))
         fx = (tx[sl, None, None] + xx[None]).float()
@@ -45,10 +48,16 @@ def unit_stats(eng, chunk=16384):
         tot["live"] += int(live.sum())
         tot["u_fwd"] += int(v8.any(-1).sum())
         tot["u_bwd"] += int(l8.any(-1).sum())
+        nv, nl = v8.sum(-1).flatten(), l8.sum(-1).flatten()
+        h_fwd += torch.histc(torch.bucketize(nv[nv > 0], edges, right=False).float() - 1, bins=7, min=0, max=7).long()
+        h_bwd += torch.histc(torch.bucketize(nl[nl > 0], edges, right=False).float() - 1, bins=7, min=0, max=7).long()
     ln = lens.float()
     return {"K": K, "splats": int(eng.N), "pixel_splat_pairs_visible": tot["valid"], "pixel_splat_pairs_live": tot["live"],
             "units_8x8_fwd": tot["u_fwd"], "units_8x8_bwd": tot["u_bwd"],
             "lane_efficiency_fwd": tot["valid"] / max(64 * tot["u_fwd"], 1),
             "lane_efficiency_bwd": tot["live"] / max(64 * tot["u_bwd"], 1),
+            # share of the units by how many of their 64 lanes see the splat: 1, 2, 3-4, 5-8, 9-16, 17-32, 33-64
+            "lanes_per_unit_hist_fwd": [round(float(v) / max(tot["u_fwd"], 1), 4) for v in h_fwd.tolist()],
+            "lanes_per_unit_hist_bwd": [round(float(v) / max(tot["u_bwd"], 1), 4) for v in h_bwd.tolist()],
             "tile_list_mean": float(ln.mean()), "tile_list_p99": float(ln.kthvalue(max(1, int(0.99 * ln.numel()))).values),
             "tile_list_max": int(lens.max()), "tiles_over_512": int((lens > 512).sum())}
