@@ -107,12 +107,6 @@ __device__ void loss_tail(const LossTail& t) {
 // (freeze_rgb, trainer.py:537-540) -- the three colour sums are neither formed nor reduced (18 VALU ops in the wave
 // reduce-scatter instead of 27 per unit).  6: the camera-only stage (freeze_all_splats) -- every splat gradient is zeroed
 // afterwards, and the pose gradient needs only the five moments and the depth feature's gradient (16 ops).
-// units with at most this many live lanes skip the wave reduce-scatter (see the kernel); 0: never
-#ifndef GFL_BWD_LOW_LANES
-#define GFL_BWD_LOW_LANES 0
-#endif
-constexpr int BWD_LOW_LANES = GFL_BWD_LOW_LANES;
-
 template <int SUMS>
 __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __restrict__ rec,
                                                               const int32_t* __restrict__ ids,
@@ -265,8 +259,7 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
                 const float4 p0 = recs[j].p0, p1 = recs[j].p1, p2 = recs[j].p2;
                 float alpha, G;
                 const bool valid = splat_alpha2(p0, p1, fx, fy, alpha, G) && (pos < last);
-                const unsigned long long vbits = __ballot(valid);
-                if (vbits == 0ull) continue;
+                if (__ballot(valid) == 0ull) continue;
 #ifdef GFL_TRACE
                 trace_lanes += __popcll(__ballot(valid));
 #endif
@@ -274,22 +267,6 @@ __global__ void __launch_bounds__(256, 8) fused_blend_bwd_kernel(const float* __
                 // (an interleaved two-splat version of this body was measured slower, twice)
                 float v[10];
                 blend_bwd_terms(p0, p1, p2, fx, fy, valid, alpha, G, g0, g1, g2, g3, T, S, v);
-                if (BWD_LOW_LANES > 0 && __popcll(vbits) <= BWD_LOW_LANES) {
-                    // A unit with a handful of live lanes (a sub-pixel splat of a densification pile: most units of a clip state):
-                    // the lanes that see the splat add their terms straight into the pair's LDS row -- 6 / 7 / 10 ds_add_f32 with
-                    // up to BWD_LOW_LANES lanes each -- instead of the wave-wide reduce-scatter (16 / 18 / 27 VALU ops with swaps
-                    // and DPP for sums that have at most that many non-zero addends).  The kernel is bound by VALU issue (70 % busy);
-                    // its LDS pipeline is 8 % busy (SQ_ACTIVE_INST_LDS 2.3 M against SQ_ACTIVE_INST_VALU 28.6 M quad-cycles).
-                    if (valid) {
-                        float* a = &acc[j][0];
-                        atomicAdd(a + 0, v[0]); atomicAdd(a + 1, v[1]); atomicAdd(a + 2, v[2]); atomicAdd(a + 3, v[3]);
-                        atomicAdd(a + 4, v[4]);
-                        if (SUMS >= 7) atomicAdd(a + 5, v[5]);
-                        if (SUMS == 10) { atomicAdd(a + 6, v[6]); atomicAdd(a + 7, v[7]); atomicAdd(a + 8, v[8]); }
-                        atomicAdd(a + 9, v[9]);
-                    }
-                    continue;
-                }
                 float mine;
                 if (SUMS == 6) {
                     const float v6[6] = {v[0], v[1], v[2], v[3], v[4], v[9]};
