@@ -694,9 +694,11 @@ def main():
     # ------------------------------------------------ the clip's own two stages, pinned the same way (rank 0's scene)
     clip_windows = None
     want_cw = (args.only_window in ("camera", "joint")) or (not args.only_window and not args.no_clip_windows and not args.no_clip)
-    if want_cw and (H, W, N_SPLATS) == (480, 854, 60000):
+    # (rank 0 only, and with a LOCAL synchronisation in place of the collective barrier: a secondary measurement must not be able
+    #  to leave the other ranks of an N > 1 run waiting in a barrier it never reaches)
+    if want_cw and rank == 0 and (H, W, N_SPLATS) == (480, 854, 60000):
         try:
-            clip_windows = measure_clip_windows(dev, rank, args, barrier, lib,
+            clip_windows = measure_clip_windows(dev, rank, args, torch.cuda.synchronize, lib,
                                                 which=(args.only_window,) if args.only_window else ("camera", "joint"))
         except Exception as e:                       # secondary windows must not cost the line
             clip_windows = {"error": f"{type(e).__name__}: {e}"}
