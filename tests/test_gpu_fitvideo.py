@@ -20,6 +20,22 @@ def _clip(n=3, H=96, W=128, seed=0):
     return S.make_clip(n, H, W, seed=seed)
 
 
+def _reach_the_same(alone, run_again, frames=3, db=1.2, splats=0.06):
+    """Two fits of the same clips reach the same quality: within the run-to-run spread of ONE fit (the backward's LDS adds are
+    unordered; thirty pairs sampled on one box, tools/conc_loop.py: up to 0.60 dB per frame and 2.7 % of the splats).  The bounds are
+    SAMPLED, so a miss is not a verdict: the fits are run once more and held to the same bounds (repeat rather than
+    loosen) -- two independent misses in a row do not happen by spread, and a clip that shared anything with another is off by
+    tens of dB every time (more than 5 dB fails at once)."""
+    for attempt in (0, 1):
+        got = run_again()
+        worst_db = max(abs(a["psnr_sum"] - b["psnr_sum"]) / frames for a, b in zip(alone, got))
+        worst_n = max(abs(a["splats_final"] - b["splats_final"]) / a["splats_final"] for a, b in zip(alone, got))
+        assert worst_db < 5.0, (alone, got)
+        if worst_db < db and worst_n <= splats:
+            return got
+    raise AssertionError(f"twice outside the run-to-run spread: {worst_db:.2f} dB per frame, {worst_n:.3f} of the splats: {alone} {got}")
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_three_frame_clip_runs_and_improves(fused):
     from gflow_amd.fit_video import fit_clip
@@ -37,9 +53,8 @@ def test_fused_and_operator_clips_reach_similar_quality():
     from gflow_amd.fit_video import fit_clip
     frames = _clip(seed=1)
     a = fit_clip(frames, DEV, SMALL, seed=0, fused=True)
-    b = fit_clip(frames, DEV, SMALL, seed=0, fused=False)
-    assert abs(a["psnr_sum"] - b["psnr_sum"]) / 3 < 1.5
-    assert abs(a["splats_final"] - b["splats_final"]) <= 0.06 * b["splats_final"]      # (~2 700 splats: up to 3 % apart run to run)
+    # (~2 700 splats: up to 3 % apart run to run)
+    _reach_the_same([a], lambda: [fit_clip(frames, DEV, SMALL, seed=0, fused=False)], db=1.5)
 
 
 def test_camera_only_phase_moves_the_pose_not_the_splats():
@@ -119,9 +134,8 @@ def test_clip_read_back_from_disk_fits_like_the_in_memory_clip(tmp_path):
     seq = gio.write_sequence(frames, str(tmp_path / "clip"))
     disk = gio.load_sequence(seq, frame_range=len(frames))
     a = fit_clip(frames, DEV, SMALL, seed=0)
-    b = fit_clip(disk, DEV, SMALL, seed=0)
+    b = _reach_the_same([a], lambda: [fit_clip(disk, DEV, SMALL, seed=0)], db=1.0, splats=1.0)[0]
     assert b["frames"] == 3 and b["iterations"] == a["iterations"]
-    assert abs(a["psnr_sum"] - b["psnr_sum"]) / 3 < 1.0, (a, b)
 
 
 @pytest.mark.parametrize("fused", [True, False])
@@ -238,16 +252,11 @@ def test_concurrent_fits_on_one_device_equal_the_fits_one_after_another():
     from gflow_amd.fit_video import fit_clip, fit_clips_concurrent
     clips = [_clip(seed=s) for s in (11, 12, 13)]
     alone = [fit_clip(c, DEV, SMALL, seed=i, snapshot_interval=10) for i, c in enumerate(clips)]
-    together = fit_clips_concurrent(clips, DEV, SMALL, seeds=[0, 1, 2], snapshot_interval=10)
+    together = _reach_the_same(alone, lambda: fit_clips_concurrent(clips, DEV, SMALL, seeds=[0, 1, 2], snapshot_interval=10))
     torch.cuda.synchronize()
     assert len(together) == 3
     for a, b in zip(alone, together):
         assert b["frames"] == 3 and b["iterations"] == a["iterations"] and b["clips"] == 1
-        # (the backward's LDS atomics are unordered: two runs of ONE fit differ as much.  Thirty pairs sampled on one box,
-        #  tools/conc_loop.py: up to 0.60 dB per frame and 2.7 % of the splats -- the old bounds, 0.7 dB and 4 %, failed one
-        #  run of the suite in a dozen; a clip that shared anything with another would be off by tens of dB)
-        assert abs(a["psnr_sum"] - b["psnr_sum"]) / 3 < 1.2, (a, b)
-        assert abs(a["splats_final"] - b["splats_final"]) <= 0.06 * a["splats_final"], (a, b)
     # an exception inside one clip's fit reaches the caller
     with pytest.raises(Exception):
         fit_clips_concurrent([clips[0], [dict(clips[1][0], image=None)]], DEV, SMALL)
@@ -264,12 +273,10 @@ def test_partitioned_concurrent_fits_stay_on_their_shares_and_fit_the_same():
     from gflow_amd.fused import FitEngine
     clips = [_clip(seed=s) for s in (11, 12)]
     turns = fit_clips_concurrent(clips, DEV, SMALL, seeds=[0, 1], snapshot_interval=10)
-    parts = fit_clips_concurrent(clips, DEV, SMALL, seeds=[0, 1], snapshot_interval=10, partition=True)
+    parts = _reach_the_same(turns, lambda: fit_clips_concurrent(clips, DEV, SMALL, seeds=[0, 1], snapshot_interval=10, partition=True))
     torch.cuda.synchronize()
     for a, b in zip(turns, parts):
         assert b["frames"] == 3 and b["iterations"] == a["iterations"]
-        assert abs(a["psnr_sum"] - b["psnr_sum"]) / 3 < 1.2, (a, b)          # (bounds of the test above: run-to-run spread of ONE fit)
-        assert abs(a["splats_final"] - b["splats_final"]) <= 0.06 * a["splats_final"], (a, b)
     shares = _lib.cu_partition(2, torch.device(DEV, 0))
     assert [n for _, n in shares] == [128, 128]
     eng = FitEngine(128, 96, 4096, torch.device(DEV, 0), cu_count=shares[0][1])
@@ -628,11 +635,11 @@ def test_concurrent_fits_draw_their_trajectories_too():
     cfg = dict(SMALL, traj_num=100, traj_offset=2)
     clips = [_clip(seed=s) for s in (21, 22)]
     alone = [fit_clip(c, DEV, cfg, seed=i, snapshot_interval=10) for i, c in enumerate(clips)]
-    together = fit_clips_concurrent(clips, DEV, cfg, seeds=[0, 1], snapshot_interval=10, chunk=7)
+    together = _reach_the_same(alone, lambda: fit_clips_concurrent(clips, DEV, cfg, seeds=[0, 1], snapshot_interval=10, chunk=7),
+                               splats=1.0)
     torch.cuda.synchronize()
     for a, b in zip(alone, together):
         assert b["iterations"] == a["iterations"] and b["rasterisations"] == a["rasterisations"]
-        assert abs(a["psnr_sum"] - b["psnr_sum"]) / 3 < 1.2, (a, b)       # (as test_concurrent_fits_on_one_device...: up to 0.6 seen)
 
 
 def test_host_writes_invalidate_the_reserved_regions():
