@@ -2,7 +2,7 @@
 composite is sampled.  The shipped build uses 0 (pixel centres at integer coordinates).  Here the SAME sources are built a
 second time with -DGFL_PIXEL_CENTER=0.5f (into a scratch directory; hipcc is on the GPU box) and a process of its own loads
 that build (GFLOW_HIP_LIB) and holds it against the oracle with oracle.msplat_oracle.PIXEL_CENTER = 0.5: the five operators,
-the fused render operator and its gradients, and a fused fit iteration -- so that a maintainer who learns that upstream
+the fused render operator and its gradients, and the fused fit iteration (tests/test_gpu_fused.py's oracle-parity tests, called with the constant flipped) -- so that a maintainer who learns that upstream
 samples at +0.5 flips ONE constant on each side and is covered by the same parity suite."""
 import os
 import shutil
@@ -59,7 +59,16 @@ def _probe():
     with torch.no_grad():
         og = R.render_multiple([*[s[k].to(dev) for k in NAMES], s["intr"].to(dev), s["extr"].to(dev), 0.33, W, H], ["center"])
     close_frac(og["center"], oc["center"].detach(), 1e-4, 1e-5, bad_frac=3e-4, hard=2e-2, what="center")
-    print("pixel-centre 0.5 build: operators, fused operator and gradients match the oracle at 0.5")
+    # the fused FIT iteration of the same build: the oracle-parity tests of tests/test_gpu_fused.py, called as functions with the
+    # oracle's constant at 0.5 (forward, all gradients, three optimiser steps, the three snapshot images)
+    from tests import test_gpu_fused as TF
+    s2 = random_scene(2500, 168, 120, seed=31, sigma_px=2.5, tilt=False)
+    setup = (s2, TF._raw_from_scene(s2), *TF._targets(s2["H"], s2["W"], 5))
+    TF.test_fused_forward_matches_oracle_and_operator_path(setup)
+    TF.test_fused_gradients_match_oracle(setup)
+    TF.test_fused_three_steps_track_the_oracle(setup)
+    TF.test_snapshot_images_match_the_oracle(setup)
+    print("pixel-centre 0.5 build: operators, fused operator, gradients and the fused fit iteration match the oracle at 0.5")
 
 
 pytestmark = pytest.mark.gpu
