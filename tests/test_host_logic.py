@@ -423,3 +423,27 @@ def test_cu_partition_masks_are_disjoint_shares_of_every_xcd():
                 assert sum((bits >> (cu * 8 + x)) & 1 for cu in range(32)) == 32 // parts
             assert bits & seen == 0
             seen |= bits
+
+
+def test_bench_window_report_and_clip_iteration_model():
+    """bench.py's round-6 bookkeeping, on made-up numbers: a window's roofline entries are algorithmic bytes / the library's stage
+    time against 8 TB/s, and the clip model weighs the three windows by the stages' shares of a 60-frame clip's 27 050 iterations."""
+    import bench
+    assert abs(sum(bench.STAGE_SHARE.values()) - 1.0) < 1e-12
+    assert abs(bench.STAGE_SHARE["joint"] - 59 * 300 / 27050) < 1e-12
+    N, K, P = 72000, 222000.0, 480 * 854
+    m = {"ms_per_step": 0.19, "timed_region_s": 0.0038, "K_mean": K, "K_list": [220000, 224000], "void_iterations": 0, "splats": N,
+         "stage_ms": {"blend_fwd": 0.040, "loss": 0.030, "blend_bwd": 0.060, "tile_sort": 0.01}, "repeats": {"n": 10, "median": 0.188}}
+    w = bench.window_report(m, "joint", {"blend_bwd": "fused_blend_bwd_kernel<7>"}, N, P)
+    b = 44 * K + 24 * P + 40 * N
+    assert w["kernels"]["blend_bwd"]["algorithmic_bytes"] == b and w["kernels"]["blend_bwd"]["kernel"] == "fused_blend_bwd_kernel<7>"
+    assert abs(w["kernels"]["blend_bwd"]["frac_of_hbm_peak"] - b / 0.060e-3 / 1e9 / 8000.0) < 1e-12
+    assert w["share_of_the_clips_iterations"] == bench.STAGE_SHARE["joint"] and w["ms_per_step_repeats"]["median"] == 0.188
+    assert w["algorithmic_bytes_per_iteration"] == 724 * N + 124 * K + 96 * P
+    local = {"elapsed": 0.0039, "steps": 20}
+    cw = {"camera": {"ms_per_step": 0.200}, "joint": {"ms_per_step": 0.187}}
+    cm = bench.clip_iteration_model(local, cw, {"wall_s": 5.9, "iterations": 27050.0}, world=1)
+    want = bench.STAGE_SHARE["first_frame"] * 0.195 + bench.STAGE_SHARE["camera"] * 0.200 + bench.STAGE_SHARE["joint"] * 0.187
+    assert abs(cm["windows_weighted_ms_per_iteration"] - want) < 1e-9
+    assert abs(cm["clip_fit_ms_per_iteration"] - 5.9 / 27050 * 1e3) < 1e-9 and 0 < cm["unexplained_frac"] < 0.2
+    assert bench.clip_iteration_model(local, None, None) is None
